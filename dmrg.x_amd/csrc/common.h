@@ -1,0 +1,63 @@
+// Internal helpers shared by the HIP translation units of libdmrgx_hip.so (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdint>
+#include <string>
+#include <vector>
+#include "dmrgx.h"
+
+namespace dmrgx {
+
+void set_error(const char* fmt, ...);
+
+#define DMRGX_HIP(call)                                                                              \
+    do {                                                                                             \
+        hipError_t e__ = (call);                                                                     \
+        if (e__ != hipSuccess) {                                                                     \
+            ::dmrgx::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e__)); \
+            return DMRGX_ERR_DEVICE;                                                                 \
+        }                                                                                            \
+    } while (0)
+
+#define DMRGX_CHK(call)                    \
+    do {                                   \
+        dmrgx_status s__ = (call);         \
+        if (s__ != DMRGX_OK) return s__;   \
+    } while (0)
+
+#define DMRGX_FAIL(code, ...)              \
+    do {                                   \
+        ::dmrgx::set_error(__VA_ARGS__);   \
+        return (code);                     \
+    } while (0)
+
+// RAII device buffer owned by a plan.
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }
+    dmrgx_status alloc(size_t n) {
+        release();
+        if (n == 0) return DMRGX_OK;
+        hipError_t e = hipMalloc(&p, n);
+        if (e != hipSuccess) { p = nullptr; set_error("hipMalloc(%zu) failed: %s", n, hipGetErrorString(e)); return DMRGX_ERR_MEM; }
+        bytes = n;
+        return DMRGX_OK;
+    }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; bytes = 0; } }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+template <class T>
+dmrgx_status upload(DevBuf& buf, const std::vector<T>& host, hipStream_t st) {
+    DMRGX_CHK(buf.alloc(host.size() * sizeof(T)));
+    if (!host.empty()) DMRGX_HIP(hipMemcpyAsync(buf.p, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice, st));
+    return DMRGX_OK;
+}
+
+}  // namespace dmrgx

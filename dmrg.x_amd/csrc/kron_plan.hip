@@ -1,0 +1,533 @@
+// K1: matrix-free superblock Hamiltonian apply  y = H_sb x  on the target-Sz sector.
+//
+// Replaces KronSumConstructShell + MatMult_KronSumShell (reference src/DMRGKron.cpp:1706-1917).  The reference
+// evaluates, for every row, sum_t a_t sum_l sum_r A_t[l,l'] B_t[r,r'] x[..] (unfactored, :1844-1864).  Here the
+// same operator is applied in factored, operator-merged form per KronBlock k=(IL,IR):
+//
+//     Y_k = H_L[IL] X_k  +  X_k H_R[IR]^T  +  sum_g  Abar_g[IL->IL'] ( X_k' Bhat_g[IR->IR']^T )
+//
+// where g runs over groups of terms sharing one operator on one side (the side with fewer distinct operators),
+// the other side's operators being pre-summed with their coefficients (Abar_g = sum_t a_t A_t) at plan time.
+// Stage 1 computes T_{g,k} = X_k' Bhat^T, stage 2 accumulates all groups into Y_k; both stages are ONE launch
+// each of the grouped MFMA-f64 GEMM (ggemm.hip) over host-built task tables, with operator zero-cells skipped
+// and identity cells (new-site operators) turned into scaled copies.  X_k is the row-major n_L x n_R matrix at
+// the KronBlock offset (reference include/DMRGKron.hpp:198-209, 603-612).
+//
+// Multi-GPU: the right index of every KronBlock is split into world_size contiguous stripes; rank r owns
+// column stripe r of every Y_k.  A full vector is stored rank-major (segment r = all stripes of rank r), so one
+// RCCL all-gather of equal-sized segments rebuilds x for the next apply.
+#include "ggemm.h"
+#include <algorithm>
+#include <map>
+#include <set>
+#include <tuple>
+#include <cstring>
+#include <memory>
+#include <new>
+
+namespace dmrgx {
+
+namespace {
+
+struct NCell {              // normalised operator cell (transpose folded in)
+    int32_t q, r0, c0, nr, nc, kind;
+    double scale;
+    const double* data;     // caller's device memory (only read during plan creation)
+    int64_t ld;
+    bool tr;                // element (i,j) of the cell is data[j*ld + i]
+};
+
+struct PCell {              // plan-owned cell: dense data lives in the arena at `off` (row-major, ld = nc)
+    int32_t q, r0, c0, nr, nc, kind;
+    double scale;
+    int64_t off;
+};
+
+struct CopyTask {           // dst[i*ldd + j] (+)= a * src(i,j)
+    int64_t dst_off;        // arena element offset
+    const double* src;
+    int64_t lds;
+    int32_t nr, nc, ldd, tr;
+    double a;
+    int32_t round;          // contributions to the same destination are applied in separate launches
+};
+
+struct CopyTile { int32_t task, ti, tj, pad; };
+
+__global__ void __launch_bounds__(256)
+cell_copy_kernel(const CopyTile* __restrict__ tiles, const CopyTask* __restrict__ tasks, double* __restrict__ arena)
+{
+    __shared__ double buf[32][33];
+    const CopyTile t = tiles[blockIdx.x];
+    const CopyTask k = tasks[t.task];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    const int i0 = t.ti * 32, j0 = t.tj * 32;
+    double* dst = arena + k.dst_off;
+    if (!k.tr) {
+        for (int r = ty; r < 32; r += 8) {
+            const int i = i0 + r, j = j0 + tx;
+            if (i < k.nr && j < k.nc) dst[(size_t)i * k.ldd + j] += k.a * k.src[(size_t)i * k.lds + j];
+        }
+    } else {
+        // dst(i,j) = src[j*lds + i]: read coalesced along i, transpose through LDS
+        for (int r = ty; r < 32; r += 8) {
+            const int j = j0 + r, i = i0 + tx;
+            buf[r][tx] = (i < k.nr && j < k.nc) ? k.src[(size_t)j * k.lds + i] : 0.0;
+        }
+        __syncthreads();
+        for (int r = ty; r < 32; r += 8) {
+            const int i = i0 + r, j = j0 + tx;
+            if (i < k.nr && j < k.nc) dst[(size_t)i * k.ldd + j] += k.a * buf[tx][r];
+        }
+    }
+}
+
+// striped <-> reference vector layout
+struct LayoutSeg { int64_t ref_off, full_off; int32_t nrow, ncol, ref_ld, full_ld; };
+__global__ void layout_copy_kernel(const LayoutSeg* __restrict__ segs, const double* __restrict__ src, double* __restrict__ dst, int to_striped)
+{
+    const LayoutSeg s = segs[blockIdx.y];
+    const int64_t n = (int64_t)s.nrow * s.ncol;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = e / s.ncol, j = e % s.ncol;
+        const int64_t a = s.ref_off + i * s.ref_ld + j, b = s.full_off + i * s.full_ld + j;
+        if (to_striped) dst[b] = src[a]; else dst[a] = src[b];
+    }
+}
+
+}  // namespace
+}  // namespace dmrgx
+
+using namespace dmrgx;
+
+// Bases selectable by a task-table entry: the plan's arena, the apply's x and y.
+enum : int32_t { BASE_ARENA = 0, BASE_X = 1, BASE_Y = 2 };
+
+namespace dmrgx {
+// Task tables are built with element offsets + base selectors and patched into absolute pointers per apply by
+// a tiny kernel, so the ggemm kernel itself only ever sees plain pointers.
+struct RelProd { int64_t a_off, b_off; int32_t lda, ldb, K, kind; double alpha; int32_t a_base, b_base; };
+struct RelGroup { int64_t c_off; int32_t c_base, ldc, M, N, prod_begin, prod_end, n_axpy, accumulate; };
+
+__global__ void patch_tables_kernel(const RelProd* __restrict__ rp, GProd* __restrict__ gp, int np,
+                                    const RelGroup* __restrict__ rg, GGroup* __restrict__ gg, int ng,
+                                    double* arena, const double* x, double* y)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const double* bases[3] = {arena, x, y};
+    if (i < np) {
+        const RelProd r = rp[i];
+        GProd g;
+        g.A = bases[r.a_base] + r.a_off; g.B = bases[r.b_base] + r.b_off;
+        g.lda = r.lda; g.ldb = r.ldb; g.K = r.K; g.kind = r.kind; g.alpha = r.alpha;
+        gp[i] = g;
+    }
+    if (i < ng) {
+        const RelGroup r = rg[i];
+        GGroup g;
+        g.C = const_cast<double*>(bases[r.c_base]) + r.c_off;
+        g.ldc = r.ldc; g.M = r.M; g.N = r.N; g.prod_begin = r.prod_begin; g.prod_end = r.prod_end;
+        g.n_axpy = r.n_axpy; g.accumulate = r.accumulate;
+        gg[i] = g;
+    }
+}
+}  // namespace dmrgx
+
+struct dmrgx_kron_plan {
+    int32_t world = 1, rank = 0;
+    dmrgx_kron_info info{};
+    DevBuf arena;                       // operators + intermediates
+    DevBuf d_rprods, d_rgroups;         // relative tables (stage 1 then stage 2, one array)
+    DevBuf d_prods, d_groups;           // patched absolute tables
+    DevBuf d_tiles1, d_tiles2;
+    int32_t nprods = 0, ngroups = 0, ntiles1 = 0, ntiles2 = 0;
+    DevBuf d_layout;
+    int32_t nlayout = 0;
+    const double* last_x = nullptr;     // tables are re-patched only when the (x,y) pair changes
+    double* last_y = nullptr;
+};
+
+namespace {
+
+dmrgx_status normalise_op(const dmrgx_secop* op, const dmrgx_sectors& sec, const char* what, std::vector<NCell>& out)
+{
+    out.clear();
+    if (!op) return DMRGX_OK;
+    if (op->ncells < 0 || (op->ncells > 0 && !op->cells)) DMRGX_FAIL(DMRGX_ERR_ARG, "%s: bad cell list", what);
+    for (int32_t i = 0; i < op->ncells; ++i) {
+        const dmrgx_cell& c = op->cells[i];
+        NCell n;
+        if (!op->transposed) { n.q = c.row_sector; n.r0 = c.r0; n.c0 = c.c0; n.nr = c.nr; n.nc = c.nc; n.tr = false; }
+        else { n.q = c.row_sector - op->shift; n.r0 = c.c0; n.c0 = c.r0; n.nr = c.nc; n.nc = c.nr; n.tr = true; }
+        n.kind = c.kind; n.scale = c.scale; n.data = c.data; n.ld = c.ld;
+        const int32_t qc = n.q + op->shift;
+        if (n.q < 0 || n.q >= sec.nsec || qc < 0 || qc >= sec.nsec)
+            DMRGX_FAIL(DMRGX_ERR_OUTOFRANGE, "%s: cell %d sector (%d -> %d) out of range [0,%d)", what, i, n.q, qc, sec.nsec);
+        if (n.nr <= 0 || n.nc <= 0 || n.r0 < 0 || n.c0 < 0 || n.r0 + n.nr > sec.size[n.q] || n.c0 + n.nc > sec.size[qc])
+            DMRGX_FAIL(DMRGX_ERR_OUTOFRANGE, "%s: cell %d rectangle [%d+%d, %d+%d) exceeds block %d x %d", what, i,
+                       n.r0, n.nr, n.c0, n.nc, sec.size[n.q], sec.size[qc]);
+        if (n.kind == DMRGX_CELL_IDENT) { if (n.nr != n.nc) DMRGX_FAIL(DMRGX_ERR_ARG, "%s: identity cell %d not square", what, i); }
+        else if (n.kind == DMRGX_CELL_DENSE) {
+            if (!n.data || n.ld < (n.tr ? n.nr : n.nc)) DMRGX_FAIL(DMRGX_ERR_ARG, "%s: dense cell %d has no data / bad ld", what, i);
+        } else DMRGX_FAIL(DMRGX_ERR_ARG, "%s: cell %d has unknown kind %d", what, i, n.kind);
+        out.push_back(n);
+    }
+    return DMRGX_OK;
+}
+
+struct Builder {
+    std::vector<RelProd> prods;
+    std::vector<RelGroup> groups;
+    std::vector<GTile> tiles1, tiles2;
+    double flops_alg = 0, flops_exec = 0;
+
+    // open a group; products are appended afterwards with add_*; close() sorts AXPY first
+    int32_t open(int32_t c_base, int64_t c_off, int32_t ldc, int32_t M, int32_t N, int32_t accumulate) {
+        RelGroup g{c_off, c_base, ldc, M, N, (int32_t)prods.size(), (int32_t)prods.size(), 0, accumulate};
+        groups.push_back(g);
+        return (int32_t)groups.size() - 1;
+    }
+    void add_gemm(int32_t a_base, int64_t a_off, int32_t lda, int32_t b_base, int64_t b_off, int32_t ldb, int32_t K) {
+        prods.push_back(RelProd{a_off, b_off, lda, ldb, K, GPROD_GEMM, 1.0, a_base, b_base});
+    }
+    void add_axpy(int32_t s_base, int64_t s_off, int32_t lds, double alpha) {
+        prods.push_back(RelProd{0, s_off, 0, lds, 0, GPROD_AXPY, alpha, BASE_ARENA, s_base});
+    }
+    void close(int32_t g, int stage) {
+        RelGroup& G = groups[g];
+        G.prod_end = (int32_t)prods.size();
+        std::stable_sort(prods.begin() + G.prod_begin, prods.end(), [](const RelProd& a, const RelProd& b) { return a.kind > b.kind; });
+        G.n_axpy = 0;
+        for (int32_t p = G.prod_begin; p < G.prod_end; ++p) {
+            const double mn = (double)G.M * G.N;
+            if (prods[p].kind == GPROD_AXPY) { G.n_axpy++; flops_alg += 2.0 * mn; }
+            else {
+                flops_alg += 2.0 * mn * prods[p].K;
+                const double tm = (G.M + GG_BM - 1) / GG_BM, tn = (G.N + GG_BN - 1) / GG_BN;
+                flops_exec += 2.0 * tm * tn * GG_BM * GG_BN * (double)(((prods[p].K + GG_BK - 1) / GG_BK) * GG_BK);
+            }
+        }
+        ggemm_append_tiles(stage == 1 ? tiles1 : tiles2, g, G.M, G.N);
+    }
+};
+
+}  // namespace
+
+extern "C" dmrgx_status dmrgx_kron_plan_create(const dmrgx_kron_desc* d, void* stream, dmrgx_kron_plan** out)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (!d || !out) DMRGX_FAIL(DMRGX_ERR_ARG, "kron_plan_create: null argument");
+    *out = nullptr;
+    const int32_t W = d->world_size <= 0 ? 1 : d->world_size, me = d->rank;
+    if (me < 0 || me >= W) DMRGX_FAIL(DMRGX_ERR_ARG, "kron_plan_create: rank %d outside world %d", me, W);
+    const dmrgx_sectors& SL = d->left;
+    const dmrgx_sectors& SR = d->right;
+    if (SL.nsec <= 0 || SR.nsec <= 0 || !SL.size || !SR.size) DMRGX_FAIL(DMRGX_ERR_ARG, "kron_plan_create: empty sector table");
+    for (int i = 0; i < SL.nsec; ++i) if (SL.size[i] <= 0) DMRGX_FAIL(DMRGX_ERR_ARG, "left sector %d has size %d", i, SL.size[i]);
+    for (int i = 0; i < SR.nsec; ++i) if (SR.size[i] <= 0) DMRGX_FAIL(DMRGX_ERR_ARG, "right sector %d has size %d", i, SR.size[i]);
+    const int32_t nb = d->nblocks;
+    if (nb <= 0 || !d->block_il || !d->block_ir) DMRGX_FAIL(DMRGX_ERR_ARG, "kron_plan_create: no KronBlocks");
+
+    // ---- layout ------------------------------------------------------------------------------------------
+    std::map<std::pair<int32_t, int32_t>, int32_t> kmap;
+    std::vector<int64_t> ref_off(nb + 1, 0);
+    for (int32_t k = 0; k < nb; ++k) {
+        const int32_t il = d->block_il[k], ir = d->block_ir[k];
+        if (il < 0 || il >= SL.nsec || ir < 0 || ir >= SR.nsec) DMRGX_FAIL(DMRGX_ERR_OUTOFRANGE, "KronBlock %d = (%d,%d) out of range", k, il, ir);
+        if (!kmap.emplace(std::make_pair(il, ir), k).second) DMRGX_FAIL(DMRGX_ERR_ARG, "KronBlock (%d,%d) listed twice", il, ir);
+        ref_off[k + 1] = ref_off[k] + (int64_t)SL.size[il] * SR.size[ir];
+    }
+    const int64_t N = ref_off[nb];
+    auto nLk = [&](int32_t k) { return SL.size[d->block_il[k]]; };
+    auto nRk = [&](int32_t k) { return SR.size[d->block_ir[k]]; };
+    // stripes: columns [cb(k,w), cb(k,w+1)) of block k belong to rank w
+    auto cb = [&](int32_t k, int32_t w) { return (int32_t)(((int64_t)nRk(k) * w) / W); };
+    std::vector<std::vector<int64_t>> seg_off(W, std::vector<int64_t>(nb + 1, 0));
+    int64_t max_seg = 0;
+    for (int32_t w = 0; w < W; ++w) {
+        for (int32_t k = 0; k < nb; ++k) seg_off[w][k + 1] = seg_off[w][k] + (int64_t)nLk(k) * (cb(k, w + 1) - cb(k, w));
+        max_seg = std::max(max_seg, seg_off[w][nb]);
+    }
+    const int64_t seg_stride = (W == 1) ? N : ((max_seg + 63) / 64) * 64;
+    auto panel_off = [&](int32_t k, int32_t w) { return (int64_t)w * seg_stride + seg_off[w][k]; };   // in a full vector
+    auto panel_ld = [&](int32_t k, int32_t w) { return cb(k, w + 1) - cb(k, w); };
+
+    // ---- operators ---------------------------------------------------------------------------------------
+    if (d->n_left_ops < 0 || d->n_right_ops < 0 || d->nterms < 0) DMRGX_FAIL(DMRGX_ERR_ARG, "negative count");
+    std::vector<std::vector<NCell>> Lops(d->n_left_ops), Rops(d->n_right_ops);
+    std::vector<NCell> HL, HR;
+    for (int32_t i = 0; i < d->n_left_ops; ++i) DMRGX_CHK(normalise_op(&d->left_ops[i], SL, "left op", Lops[i]));
+    for (int32_t i = 0; i < d->n_right_ops; ++i) DMRGX_CHK(normalise_op(&d->right_ops[i], SR, "right op", Rops[i]));
+    if (d->h_left) { if (d->h_left->shift != 0) DMRGX_FAIL(DMRGX_ERR_ARG, "H_L must have shift 0"); DMRGX_CHK(normalise_op(d->h_left, SL, "H_L", HL)); }
+    if (d->h_right) { if (d->h_right->shift != 0) DMRGX_FAIL(DMRGX_ERR_ARG, "H_R must have shift 0"); DMRGX_CHK(normalise_op(d->h_right, SR, "H_R", HR)); }
+
+    // term groups: merge on the side with MORE distinct operators, keyed by the operator on the other side
+    std::set<int32_t> usedL, usedR;
+    for (int32_t t = 0; t < d->nterms; ++t) {
+        const dmrgx_term& T = d->terms[t];
+        if (T.left_op < 0 || T.left_op >= d->n_left_ops || T.right_op < 0 || T.right_op >= d->n_right_ops)
+            DMRGX_FAIL(DMRGX_ERR_OUTOFRANGE, "term %d references operator (%d,%d) out of range", t, T.left_op, T.right_op);
+        if (d->left_ops[T.left_op].shift + d->right_ops[T.right_op].shift != 0)
+            DMRGX_FAIL(DMRGX_ERR_ARG, "term %d does not conserve Sz (shifts %d,%d)", t, d->left_ops[T.left_op].shift, d->right_ops[T.right_op].shift);
+        if (T.a != 0.0) { usedL.insert(T.left_op); usedR.insert(T.right_op); }
+    }
+    const bool key_right = usedR.size() <= usedL.size();   // groups keyed by right op => left ops get merged
+    struct Group { int32_t sA, sB; std::vector<PCell> left, rightT; };   // rightT: cells of Bhat^T
+    std::vector<Group> G;
+    std::vector<CopyTask> copies;
+    int64_t arena_ops = 0;   // elements
+    auto new_dense = [&](int32_t nr, int32_t nc) { int64_t o = arena_ops; arena_ops += (int64_t)nr * nc; return o; };
+
+    // merged (or raw) cell list for one side: sum_t coeff_t * op_t ; transpose_out => store cells transposed
+    auto build_side = [&](const std::vector<std::pair<double, const std::vector<NCell>*>>& contrib, bool transpose_out, std::vector<PCell>& dst) {
+        std::map<std::tuple<int32_t, int32_t, int32_t, int32_t, int32_t, int32_t>, int32_t> index;   // key -> dst idx
+        std::map<int32_t, int32_t> rounds;
+        for (auto& ct : contrib) {
+            for (const NCell& c : *ct.second) {
+                auto key = std::make_tuple(c.q, c.r0, c.c0, c.nr, c.nc, c.kind);
+                auto it = index.find(key);
+                int32_t di;
+                if (it == index.end()) {
+                    PCell pc;
+                    pc.kind = c.kind; pc.scale = 0.0; pc.off = -1;
+                    if (!transpose_out) { pc.q = c.q; pc.r0 = c.r0; pc.c0 = c.c0; pc.nr = c.nr; pc.nc = c.nc; }
+                    else { pc.q = c.q; pc.r0 = c.c0; pc.c0 = c.r0; pc.nr = c.nc; pc.nc = c.nr; }   // q stays the ROW sector of the un-transposed op
+                    if (c.kind == DMRGX_CELL_DENSE) pc.off = new_dense(pc.nr, pc.nc);
+                    dst.push_back(pc);
+                    di = (int32_t)dst.size() - 1;
+                    index.emplace(key, di);
+                } else di = it->second;
+                if (c.kind == DMRGX_CELL_IDENT) dst[di].scale += ct.first * c.scale;
+                else {
+                    CopyTask k;
+                    k.dst_off = dst[di].off; k.src = c.data; k.lds = c.ld;
+                    k.nr = dst[di].nr; k.nc = dst[di].nc; k.ldd = dst[di].nc;
+                    k.tr = (c.tr != transpose_out) ? 1 : 0;
+                    k.a = ct.first; k.round = rounds[di]++;
+                    copies.push_back(k);
+                }
+            }
+        }
+    };
+
+    {
+        std::map<int32_t, std::vector<int32_t>> by_key;   // key op -> term indices
+        for (int32_t t = 0; t < d->nterms; ++t) if (d->terms[t].a != 0.0) by_key[key_right ? d->terms[t].right_op : d->terms[t].left_op].push_back(t);
+        for (auto& kv : by_key) {
+            Group g;
+            std::vector<std::pair<double, const std::vector<NCell>*>> cl, cr;
+            if (key_right) {
+                g.sB = d->right_ops[kv.first].shift; g.sA = -g.sB;
+                cr.push_back({1.0, &Rops[kv.first]});
+                for (int32_t t : kv.second) cl.push_back({d->terms[t].a, &Lops[d->terms[t].left_op]});
+            } else {
+                g.sA = d->left_ops[kv.first].shift; g.sB = -g.sA;
+                cl.push_back({1.0, &Lops[kv.first]});
+                for (int32_t t : kv.second) cr.push_back({d->terms[t].a, &Rops[d->terms[t].right_op]});
+            }
+            build_side(cl, false, g.left);
+            build_side(cr, true, g.rightT);
+            G.push_back(std::move(g));
+        }
+    }
+    std::vector<PCell> PHL, PHRT;
+    build_side({{1.0, &HL}}, false, PHL);
+    build_side({{1.0, &HR}}, true, PHRT);
+
+    // ---- intermediates: T_{g,k} (n_L(IL') x my stripe of IR) and T_R,k (n_L x my stripe) ------------------
+    int64_t arena_T = 0;
+    std::vector<std::vector<int64_t>> Toff(G.size(), std::vector<int64_t>(nb, -1));
+    std::vector<std::vector<int32_t>> Ksrc(G.size(), std::vector<int32_t>(nb, -1));
+    for (size_t g = 0; g < G.size(); ++g)
+        for (int32_t k = 0; k < nb; ++k) {
+            auto it = kmap.find({d->block_il[k] + G[g].sA, d->block_ir[k] + G[g].sB});
+            if (it == kmap.end()) continue;
+            Ksrc[g][k] = it->second;
+            Toff[g][k] = arena_ops + arena_T;
+            arena_T += (int64_t)nLk(it->second) * panel_ld(k, me);
+        }
+    std::vector<int64_t> TRoff(nb, -1);
+    if (!PHRT.empty())
+        for (int32_t k = 0; k < nb; ++k) { TRoff[k] = arena_ops + arena_T; arena_T += (int64_t)nLk(k) * panel_ld(k, me); }
+
+    // ---- task tables ---------------------------------------------------------------------------------------
+    Builder B;
+    // stage 1:  T[:, cols] = X_src[:, krange] * cellT   for every transposed right cell of the block (IR -> IR')
+    auto stage1 = [&](const std::vector<PCell>& cellsT, int32_t sB, int32_t k, int32_t ksrc, int64_t toff) {
+        const int32_t ir = d->block_ir[k], cs = cb(k, me), ce = cb(k, me + 1), w = ce - cs;
+        if (w <= 0) return;
+        const int32_t M = nLk(ksrc);
+        for (const PCell& c : cellsT) {
+            if (c.q != ir) continue;                         // cell of block (ir -> ir+sB), stored transposed:
+            const int32_t o0 = std::max(c.c0, cs), o1 = std::min(c.c0 + c.nc, ce);   // output columns (index in sector ir)
+            if (o0 >= o1) continue;
+            (void)sB;
+            if (c.kind == DMRGX_CELL_DENSE) {
+                const int32_t g = B.open(BASE_ARENA, toff + (o0 - cs), w, M, o1 - o0, 0);
+                for (int32_t p = 0; p < W; ++p) {            // contraction index r' in [c.r0, c.r0+c.nr) split over source panels
+                    const int32_t k0 = std::max(c.r0, cb(ksrc, p)), k1 = std::min(c.r0 + c.nr, cb(ksrc, p + 1));
+                    if (k0 >= k1) continue;
+                    B.add_gemm(BASE_X, panel_off(ksrc, p) + (k0 - cb(ksrc, p)), panel_ld(ksrc, p),
+                               BASE_ARENA, c.off + (int64_t)(k0 - c.r0) * c.nc + (o0 - c.c0), c.nc, k1 - k0);
+                }
+                B.close(g, 1);
+            } else {                                         // identity cell: T[:, c] = scale * X_src[:, r0 + (c - c0)]
+                for (int32_t p = 0; p < W; ++p) {
+                    const int32_t s0 = std::max(c.r0 + (o0 - c.c0), cb(ksrc, p)), s1 = std::min(c.r0 + (o1 - c.c0), cb(ksrc, p + 1));
+                    if (s0 >= s1) continue;
+                    const int32_t oc = c.c0 + (s0 - c.r0);
+                    const int32_t g = B.open(BASE_ARENA, toff + (oc - cs), w, M, s1 - s0, 0);
+                    B.add_axpy(BASE_X, panel_off(ksrc, p) + (s0 - cb(ksrc, p)), panel_ld(ksrc, p), c.scale);
+                    B.close(g, 1);
+                }
+            }
+        }
+    };
+    for (size_t g = 0; g < G.size(); ++g)
+        for (int32_t k = 0; k < nb; ++k) if (Ksrc[g][k] >= 0) stage1(G[g].rightT, G[g].sB, k, Ksrc[g][k], Toff[g][k]);
+    if (!PHRT.empty()) for (int32_t k = 0; k < nb; ++k) stage1(PHRT, 0, k, k, TRoff[k]);
+    const int32_t n_groups_stage1 = (int32_t)B.groups.size();
+
+    // stage 2:  Y_k[rows, stripe] = sum over left cells covering `rows`
+    for (int32_t k = 0; k < nb; ++k) {
+        const int32_t il = d->block_il[k], w = panel_ld(k, me), nl = nLk(k);
+        if (w <= 0) continue;
+        std::set<int32_t> cuts = {0, nl};
+        for (size_t g = 0; g < G.size(); ++g) if (Ksrc[g][k] >= 0) for (const PCell& c : G[g].left) if (c.q == il) { cuts.insert(c.r0); cuts.insert(c.r0 + c.nr); }
+        for (const PCell& c : PHL) if (c.q == il) { cuts.insert(c.r0); cuts.insert(c.r0 + c.nr); }
+        std::vector<int32_t> cv(cuts.begin(), cuts.end());
+        for (size_t s = 0; s + 1 < cv.size(); ++s) {
+            const int32_t ra = cv[s], rb = cv[s + 1];
+            const int32_t grp = B.open(BASE_Y, seg_off[me][k] + (int64_t)ra * w, w, rb - ra, w, 0);
+            for (size_t g = 0; g < G.size(); ++g) {
+                if (Ksrc[g][k] < 0) continue;
+                for (const PCell& c : G[g].left) {
+                    if (c.q != il || c.r0 > ra || c.r0 + c.nr < rb) continue;
+                    if (c.kind == DMRGX_CELL_DENSE)
+                        B.add_gemm(BASE_ARENA, c.off + (int64_t)(ra - c.r0) * c.nc, c.nc, BASE_ARENA, Toff[g][k] + (int64_t)c.c0 * w, w, c.nc);
+                    else
+                        B.add_axpy(BASE_ARENA, Toff[g][k] + (int64_t)(c.c0 + (ra - c.r0)) * w, w, c.scale);
+                }
+            }
+            for (const PCell& c : PHL) {                      // H_L (x) 1 : B operand is this rank's own panel of X_k
+                if (c.q != il || c.r0 > ra || c.r0 + c.nr < rb) continue;
+                if (c.kind == DMRGX_CELL_DENSE)
+                    B.add_gemm(BASE_ARENA, c.off + (int64_t)(ra - c.r0) * c.nc, c.nc, BASE_X, panel_off(k, me) + (int64_t)c.c0 * w, w, c.nc);
+                else
+                    B.add_axpy(BASE_X, panel_off(k, me) + (int64_t)(c.c0 + (ra - c.r0)) * w, w, c.scale);
+            }
+            if (TRoff[k] >= 0) B.add_axpy(BASE_ARENA, TRoff[k] + (int64_t)ra * w, w, 1.0);   // 1 (x) H_R
+            B.close(grp, 2);
+        }
+    }
+
+    // ---- device objects ------------------------------------------------------------------------------------
+    dmrgx_kron_plan* P = new (std::nothrow) dmrgx_kron_plan();
+    if (!P) DMRGX_FAIL(DMRGX_ERR_MEM, "out of host memory");
+    std::unique_ptr<dmrgx_kron_plan> guard(P);
+    P->world = W; P->rank = me;
+    DMRGX_CHK(P->arena.alloc((size_t)std::max<int64_t>(arena_ops + arena_T, 1) * sizeof(double)));
+    DMRGX_HIP(hipMemsetAsync(P->arena.p, 0, P->arena.bytes, st));
+    {   // operator copies, one launch per accumulation round
+        int32_t max_round = -1;
+        for (auto& c : copies) max_round = std::max(max_round, c.round);
+        DevBuf d_tasks;
+        DMRGX_CHK(upload(d_tasks, copies, st));
+        for (int32_t r = 0; r <= max_round; ++r) {
+            std::vector<CopyTile> ct;
+            for (size_t i = 0; i < copies.size(); ++i) if (copies[i].round == r)
+                for (int32_t ti = 0; ti < (copies[i].nr + 31) / 32; ++ti)
+                    for (int32_t tj = 0; tj < (copies[i].nc + 31) / 32; ++tj) ct.push_back(CopyTile{(int32_t)i, ti, tj, 0});
+            if (ct.empty()) continue;
+            DevBuf d_ct;
+            DMRGX_CHK(upload(d_ct, ct, st));
+            hipLaunchKernelGGL(cell_copy_kernel, dim3((unsigned)ct.size()), dim3(256), 0, st, d_ct.as<CopyTile>(), d_tasks.as<CopyTask>(), P->arena.as<double>());
+            DMRGX_HIP(hipGetLastError());
+            DMRGX_HIP(hipStreamSynchronize(st));   // d_ct is freed at scope exit
+        }
+        DMRGX_HIP(hipStreamSynchronize(st));
+    }
+    P->nprods = (int32_t)B.prods.size(); P->ngroups = (int32_t)B.groups.size();
+    P->ntiles1 = (int32_t)B.tiles1.size(); P->ntiles2 = (int32_t)B.tiles2.size();
+    DMRGX_CHK(upload(P->d_rprods, B.prods, st));
+    DMRGX_CHK(upload(P->d_rgroups, B.groups, st));
+    DMRGX_CHK(upload(P->d_tiles1, B.tiles1, st));
+    DMRGX_CHK(upload(P->d_tiles2, B.tiles2, st));
+    DMRGX_CHK(P->d_prods.alloc(std::max<size_t>(B.prods.size(), 1) * sizeof(GProd)));
+    DMRGX_CHK(P->d_groups.alloc(std::max<size_t>(B.groups.size(), 1) * sizeof(GGroup)));
+    {   // layout conversion table (reference order <-> rank-major stripes)
+        std::vector<LayoutSeg> segs;
+        for (int32_t k = 0; k < nb; ++k) for (int32_t w = 0; w < W; ++w) {
+            if (panel_ld(k, w) <= 0) continue;
+            segs.push_back(LayoutSeg{ref_off[k] + cb(k, w), panel_off(k, w), nLk(k), panel_ld(k, w), nRk(k), panel_ld(k, w)});
+        }
+        P->nlayout = (int32_t)segs.size();
+        DMRGX_CHK(upload(P->d_layout, segs, st));
+    }
+    DMRGX_HIP(hipStreamSynchronize(st));
+
+    dmrgx_kron_info& I = P->info;
+    I.n_states = N; I.vec_len = (W == 1) ? N : (int64_t)W * seg_stride; I.local_offset = (int64_t)me * seg_stride;
+    I.local_len = (W == 1) ? N : seg_stride; I.seg_stride = seg_stride;
+    I.flops_alg = B.flops_alg; I.flops_exec = B.flops_exec;
+    double opbytes = 0;
+    auto cellbytes = [&](const std::vector<PCell>& v) { for (auto& c : v) if (c.kind == DMRGX_CELL_DENSE) opbytes += 8.0 * c.nr * c.nc; };
+    for (auto& g : G) { cellbytes(g.left); cellbytes(g.rightT); }
+    cellbytes(PHL); cellbytes(PHRT);
+    I.bytes_alg = opbytes + 8.0 * ((double)N + (double)seg_off[me][nb]);
+    I.bytes_workspace = 16.0 * (double)arena_T;
+    I.n_groups = (int32_t)G.size(); I.n_tiles_stage1 = P->ntiles1; I.n_tiles_stage2 = P->ntiles2;
+    (void)n_groups_stage1;
+    *out = guard.release();
+    return DMRGX_OK;
+}
+
+extern "C" dmrgx_status dmrgx_kron_plan_info(const dmrgx_kron_plan* plan, dmrgx_kron_info* info)
+{
+    if (!plan || !info) DMRGX_FAIL(DMRGX_ERR_ARG, "kron_plan_info: null argument");
+    *info = plan->info;
+    return DMRGX_OK;
+}
+
+extern "C" dmrgx_status dmrgx_kron_apply(dmrgx_kron_plan* P, const double* x_full, double* y_local, void* stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (!P || !x_full || !y_local) DMRGX_FAIL(DMRGX_ERR_ARG, "kron_apply: null argument");
+    if (P->last_x != x_full || P->last_y != y_local) {
+        const int n = std::max(P->nprods, P->ngroups);
+        if (n > 0) {
+            hipLaunchKernelGGL(patch_tables_kernel, dim3((n + 255) / 256), dim3(256), 0, st,
+                               P->d_rprods.as<RelProd>(), P->d_prods.as<GProd>(), P->nprods,
+                               P->d_rgroups.as<RelGroup>(), P->d_groups.as<GGroup>(), P->ngroups,
+                               P->arena.as<double>(), x_full, y_local);
+            DMRGX_HIP(hipGetLastError());
+        }
+        P->last_x = x_full; P->last_y = y_local;
+    }
+    DMRGX_CHK(ggemm_launch(P->d_tiles1.as<GTile>(), P->d_groups.as<GGroup>(), P->d_prods.as<GProd>(), P->ntiles1, st));
+    DMRGX_CHK(ggemm_launch(P->d_tiles2.as<GTile>(), P->d_groups.as<GGroup>(), P->d_prods.as<GProd>(), P->ntiles2, st));
+    return DMRGX_OK;
+}
+
+extern "C" dmrgx_status dmrgx_kron_plan_destroy(dmrgx_kron_plan* plan)
+{
+    if (!plan) return DMRGX_OK;
+    (void)hipDeviceSynchronize();
+    delete plan;
+    return DMRGX_OK;
+}
+
+static dmrgx_status layout_copy(const dmrgx_kron_plan* P, const double* src, double* dst, int to_striped, hipStream_t st)
+{
+    if (!P || !src || !dst) DMRGX_FAIL(DMRGX_ERR_ARG, "kron_vec layout copy: null argument");
+    if (P->nlayout == 0) return DMRGX_OK;
+    hipLaunchKernelGGL(layout_copy_kernel, dim3(64, (unsigned)P->nlayout), dim3(256), 0, st, P->d_layout.as<LayoutSeg>(), src, dst, to_striped);
+    DMRGX_HIP(hipGetLastError());
+    return DMRGX_OK;
+}
+
+extern "C" dmrgx_status dmrgx_kron_vec_to_striped(const dmrgx_kron_plan* plan, const double* v_ref_dev, double* v_full_dev, void* stream)
+{ return layout_copy(plan, v_ref_dev, v_full_dev, 1, (hipStream_t)stream); }
+
+extern "C" dmrgx_status dmrgx_kron_vec_from_striped(const dmrgx_kron_plan* plan, const double* v_full_dev, double* v_ref_dev, void* stream)
+{ return layout_copy(plan, v_full_dev, v_ref_dev, 0, (hipStream_t)stream); }

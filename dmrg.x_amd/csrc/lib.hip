@@ -1,0 +1,55 @@
+// libdmrgx_hip.so: library-level entry points (error reporting, device probe, plain GEMM wrapper).
+#include "ggemm.h"
+
+namespace dmrgx {
+static thread_local std::string g_last_error;
+void set_error(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+}
+}  // namespace dmrgx
+
+using namespace dmrgx;
+
+extern "C" int32_t dmrgx_abi_version(void) { return DMRGX_ABI_VERSION; }
+
+extern "C" const char* dmrgx_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" dmrgx_status dmrgx_device_count(int32_t* n)
+{
+    if (!n) DMRGX_FAIL(DMRGX_ERR_ARG, "device_count: null argument");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess || c <= 0) {
+        *n = 0;
+        DMRGX_FAIL(DMRGX_ERR_DEVICE, "no HIP device available (%s): the dmrgx hot path has no CPU fallback", hipGetErrorString(e));
+    }
+    *n = c;
+    return DMRGX_OK;
+}
+
+extern "C" dmrgx_status dmrgx_dgemm_nn(int32_t M, int32_t N, int32_t K, const double* A, int64_t lda,
+                                       const double* B, int64_t ldb, double* C, int64_t ldc, void* stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (M < 0 || N < 0 || K < 0 || (M && N && (!C || ldc < N)) || (M && N && K && (!A || !B || lda < K || ldb < N)))
+        DMRGX_FAIL(DMRGX_ERR_ARG, "dgemm_nn: bad argument (M=%d N=%d K=%d)", M, N, K);
+    if (M == 0 || N == 0) return DMRGX_OK;
+    std::vector<GProd> prods;
+    if (K > 0) prods.push_back(GProd{A, B, (int32_t)lda, (int32_t)ldb, K, GPROD_GEMM, 1.0});
+    std::vector<GGroup> groups = {GGroup{C, (int32_t)ldc, M, N, 0, (int32_t)prods.size(), 0, 0}};
+    std::vector<GTile> tiles;
+    ggemm_append_tiles(tiles, 0, M, N);
+    DevBuf dp, dg, dt;
+    if (prods.empty()) prods.push_back(GProd{nullptr, nullptr, 0, 0, 0, GPROD_GEMM, 0.0});
+    DMRGX_CHK(upload(dp, prods, st));
+    DMRGX_CHK(upload(dg, groups, st));
+    DMRGX_CHK(upload(dt, tiles, st));
+    DMRGX_CHK(ggemm_launch(dt.as<GTile>(), dg.as<GGroup>(), dp.as<GProd>(), (int32_t)tiles.size(), st));
+    DMRGX_HIP(hipStreamSynchronize(st));   // tables are freed on return
+    return DMRGX_OK;
+}

@@ -1,0 +1,156 @@
+"""Host-side handle of the HIP superblock plan, mirroring the reference's shell-matrix life cycle:
+
+    KronBlocks_t::KronSumConstruct(Terms, H)  ->  KronPlan(superblock)          (src/DMRGKron.cpp:759-841,1871-1917)
+    MatMult(H, x, y)                          ->  KronPlan.apply(x, y)          (src/DMRGKron.cpp:1827-1869)
+    MatDestroy_KronSumShell(&H)               ->  KronPlan.destroy()            (src/DMRGKron.cpp:1919-1942)
+    EPSSolve(H) (EPS_HEP, SMALLEST_REAL)      ->  KronPlan.eigs_lowest()        (include/DMRGBlockContainer.hpp:1488-1499)
+
+torch is used only to own device memory and streams; every computation goes through the C ABI (_capi).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _capi
+from .workloads import OpSm, OpSz, OpSp, CELL_DENSE, CELL_IDENT
+
+
+def _i32(values):
+    arr = (C.c_int32 * len(values))(*[int(v) for v in values])
+    return arr
+
+
+class KronPlan:
+    def __init__(self, sb, device="cuda:0", world_size=1, rank=0, stream=None):
+        _capi.require_device()          # fails loudly without a GPU: no CPU fallback
+        self.sb = sb
+        self.device = torch.device(device)
+        self._keep = []                 # ctypes arrays + device tensors that must outlive plan creation
+        L = _capi.lib()
+
+        def secop(op, transposed=False, shift=None):
+            cells = (_capi.Cell * max(len(op.cells), 1))()
+            for i, c in enumerate(op.cells):
+                cells[i].row_sector, cells[i].r0, cells[i].c0, cells[i].nr, cells[i].nc = c.row_sector, c.r0, c.c0, c.nr, c.nc
+                cells[i].kind, cells[i].scale = c.kind, c.scale
+                if c.kind == CELL_DENSE:
+                    t = torch.from_numpy(np.ascontiguousarray(c.array, dtype=np.float64)).to(self.device)
+                    self._keep.append(t)
+                    cells[i].data, cells[i].ld = t.data_ptr(), c.nc
+            self._keep.append(cells)
+            s = _capi.SecOp()
+            s.shift = op.shift if shift is None else shift
+            s.transposed = 1 if transposed else 0
+            s.ncells = len(op.cells)
+            s.cells = cells
+            return s
+
+        # distinct (op, site) operators per side in term order; Sm(i) = transposed Sp(i) (never materialised)
+        def side(ops, which):
+            index, lst = {}, []
+            for t in sb.terms:
+                key = (t[1], t[2]) if which == 0 else (t[3], t[4])
+                if key in index:
+                    continue
+                op, site = key
+                if op == OpSm:
+                    lst.append(secop(ops[(OpSp, site)], transposed=True, shift=-1))
+                else:
+                    lst.append(secop(ops[(op, site)]))
+                index[key] = len(lst) - 1
+            arr = (_capi.SecOp * max(len(lst), 1))(*lst)
+            self._keep.append(arr)
+            return index, arr, len(lst)
+
+        li, larr, nl = side(sb.left_ops, 0)
+        ri, rarr, nr = side(sb.right_ops, 1)
+        terms = (_capi.Term * max(len(sb.terms), 1))()
+        for i, t in enumerate(sb.terms):
+            terms[i].a, terms[i].left_op, terms[i].right_op = t[0], li[(t[1], t[2])], ri[(t[3], t[4])]
+        hl, hr = secop(sb.h_left), secop(sb.h_right)
+        d = _capi.KronDesc()
+        ls, rs = _i32(sb.left_sizes), _i32(sb.right_sizes)
+        bil, bir = _i32([b[0] for b in sb.blocks]), _i32([b[1] for b in sb.blocks])
+        d.left.nsec, d.left.size = len(sb.left_sizes), ls
+        d.right.nsec, d.right.size = len(sb.right_sizes), rs
+        d.nblocks, d.block_il, d.block_ir = len(sb.blocks), bil, bir
+        d.n_left_ops, d.n_right_ops, d.left_ops, d.right_ops = nl, nr, larr, rarr
+        d.h_left, d.h_right = C.pointer(hl), C.pointer(hr)
+        d.nterms, d.terms = len(sb.terms), terms
+        d.world_size, d.rank = world_size, rank
+        self._handle = C.c_void_p()
+        st = self._stream_ptr(stream)
+        with torch.cuda.device(self.device):
+            _capi.check(L.dmrgx_kron_plan_create(C.byref(d), st, C.byref(self._handle)))
+        self._keep.clear()              # the plan owns copies of every operator
+        info = _capi.KronInfo()
+        _capi.check(L.dmrgx_kron_plan_info(self._handle, C.byref(info)))
+        self.info = info
+        self.world_size, self.rank = world_size, rank
+
+    @staticmethod
+    def _stream_ptr(stream):
+        if stream is None:
+            stream = torch.cuda.current_stream()
+        return C.c_void_p(stream.cuda_stream)
+
+    def new_vector(self):
+        return torch.zeros(self.info.vec_len, dtype=torch.float64, device=self.device)
+
+    def apply(self, x_full, y_local, stream=None):
+        """y_local <- (H x_full)[this rank's segment]  ==  MatMult_KronSumShell."""
+        assert x_full.dtype == torch.float64 and y_local.dtype == torch.float64
+        assert x_full.numel() >= self.info.vec_len and y_local.numel() >= self.info.local_len
+        _capi.check(_capi.lib().dmrgx_kron_apply(self._handle, C.c_void_p(x_full.data_ptr()), C.c_void_p(y_local.data_ptr()),
+                                                 self._stream_ptr(stream)))
+
+    def to_striped(self, v_ref, v_full, stream=None):
+        _capi.check(_capi.lib().dmrgx_kron_vec_to_striped(self._handle, C.c_void_p(v_ref.data_ptr()), C.c_void_p(v_full.data_ptr()),
+                                                          self._stream_ptr(stream)))
+
+    def from_striped(self, v_full, v_ref, stream=None):
+        _capi.check(_capi.lib().dmrgx_kron_vec_from_striped(self._handle, C.c_void_p(v_full.data_ptr()), C.c_void_p(v_ref.data_ptr()),
+                                                            self._stream_ptr(stream)))
+
+    def eigs_lowest(self, ncv=16, max_it=1000, tol=1e-8, seed=1, psi0=None, allgather=None, allreduce=None, stream=None):
+        """Lowest eigenpair (EPS_HEP / EPS_SMALLEST_REAL / nev=1).  Returns (e0, psi_full tensor, stats)."""
+        opts = _capi.EigsOpts()
+        opts.ncv, opts.max_it, opts.tol, opts.seed = ncv, max_it, tol, seed
+        psi = self.new_vector()
+        if psi0 is not None:
+            psi.copy_(psi0)
+            opts.use_initial = 1
+        self._cb = (_capi.ALLGATHER_FN(allgather) if allgather else _capi.ALLGATHER_FN(),
+                    _capi.ALLREDUCE_FN(allreduce) if allreduce else _capi.ALLREDUCE_FN())
+        opts.allgather, opts.allreduce_sum = self._cb
+        e0 = C.c_double(0.0)
+        stats = _capi.EigsStats()
+        _capi.check(_capi.lib().dmrgx_eigs_lowest(self._handle, C.byref(opts), C.byref(e0), C.c_void_p(psi.data_ptr()),
+                                                  C.byref(stats), self._stream_ptr(stream)))
+        return e0.value, psi, stats
+
+    def destroy(self):
+        if self._handle:
+            _capi.check(_capi.lib().dmrgx_kron_plan_destroy(self._handle))
+            self._handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+def dgemm_nn(A, B, out=None):
+    """C = A @ B through the MFMA grouped-GEMM kernel (row-major f64 device tensors)."""
+    assert A.dtype == torch.float64 and B.dtype == torch.float64 and A.is_contiguous() and B.is_contiguous()
+    M, K = A.shape
+    K2, N = B.shape
+    assert K == K2
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float64, device=A.device)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _capi.check(_capi.lib().dmrgx_dgemm_nn(M, N, K, C.c_void_p(A.data_ptr()), K, C.c_void_p(B.data_ptr()), N,
+                                           C.c_void_p(out.data_ptr()), N, st))
+    return out

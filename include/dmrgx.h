@@ -1,0 +1,174 @@
+/* dmrgx.h -- C ABI of the MI355X-native DMRG hot path (libdmrgx_hip.so).
+ *
+ * This is the drop-in boundary: the host sweep engine (C++, mirrors DMRGBlock / DMRGKron /
+ * DMRGBlockContainer of jnvance/DMRG.x) reaches every device computation through these entry points and
+ * nothing else.  Plain pointers and sizes only; no C++/torch types; every function returns a dmrgx_status
+ * (0 = success), never throws, and records a message retrievable with dmrgx_last_error().
+ *
+ * What each entry point replaces in the reference (paths relative to the reference tree):
+ *   dmrgx_kron_plan_create   <- KronBlocks_t::KronSumConstruct -> KronSumConstructShell
+ *                               (src/DMRGKron.cpp:759-841, 1871-1917: term filtering is the caller's job,
+ *                               operator fetch 891-989, per-row descriptors 1706-1824)
+ *   dmrgx_kron_apply         <- MatMult_KronSumShell (src/DMRGKron.cpp:1827-1869), the MATOP_MULT callback
+ *                               registered at src/DMRGKron.cpp:1912-1914
+ *   dmrgx_kron_plan_destroy  <- MatDestroy_KronSumShell (src/DMRGKron.cpp:1919-1942)
+ *   dmrgx_eigs_lowest        <- EPSSolve(EPS_HEP, EPS_SMALLEST_REAL, nev=1) as configured at
+ *                               include/DMRGBlockContainer.hpp:1488-1499 [SLEPc Krylov-Schur, external]
+ *   dmrgx_rdm_truncate       <- GetTruncation + EigRDM_BlockDiag + FillRotation_BlockDiag
+ *                               (include/DMRGBlockContainer.hpp:1656-2057)
+ *   dmrgx_rotate_ops         <- Block::SpinBase::RotateOperators (src/DMRGBlock.cpp:677-823)
+ *   dmrgx_enlarge_ops        <- MatKronEyeConstruct + block-H KronSum (src/DMRGKron.cpp:52-456, 612)
+ *
+ * Data model.  All floating point is f64 real (include/DMRGKron.hpp:395-399).  A block's basis is split in
+ * Sz sectors (descending Sz); an operator with sector shift s (Op_t value: Sm=-1, Sz=0, Sp=+1,
+ * include/DMRGBlock.hpp:19-27) is non-zero only in blocks (row sector q -> column sector q+s).  On the device
+ * an operator is a list of *cells*: dense row-major rectangles (or scaled identities) inside those blocks.
+ * The superblock vector of the target sector is the concatenation over KronBlocks k=(IL,IR) of the row-major
+ * n_L(IL) x n_R(IR) matrices X_k (include/DMRGKron.hpp:160-209, 603-612).
+ *
+ * Threading: a plan is used from one host thread at a time; all work is enqueued on the hipStream_t passed as
+ * `void* stream` (NULL = default stream).  Device pointers must come from the current HIP device.
+ */
+#ifndef DMRGX_H
+#define DMRGX_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DMRGX_ABI_VERSION 1
+
+typedef int32_t dmrgx_status;
+enum {
+    DMRGX_OK = 0,
+    DMRGX_ERR_ARG = 62,          /* = PETSC_ERR_ARG_WRONG: malformed descriptor                     */
+    DMRGX_ERR_OUTOFRANGE = 63,   /* = PETSC_ERR_ARG_OUTOFRANGE: index/sector out of range            */
+    DMRGX_ERR_MEM = 55,          /* = PETSC_ERR_MEM                                                  */
+    DMRGX_ERR_DEVICE = 97,       /* HIP runtime error / no device                                    */
+    DMRGX_ERR_NOTCONV = 91,      /* eigensolver did not converge within max_it                       */
+    DMRGX_ERR_INTERNAL = 77
+};
+
+/* ---- library ---------------------------------------------------------------------------------------- */
+int32_t      dmrgx_abi_version(void);
+const char*  dmrgx_last_error(void);                 /* thread-local, valid until the next failing call  */
+dmrgx_status dmrgx_device_count(int32_t* n);         /* fails loudly (DMRGX_ERR_DEVICE) without a GPU     */
+
+/* ---- operator cells --------------------------------------------------------------------------------- */
+enum { DMRGX_CELL_DENSE = 1, DMRGX_CELL_IDENT = 2 };
+
+typedef struct {
+    int32_t row_sector;   /* q: row sector of the (q -> q+shift) block this cell lives in               */
+    int32_t r0, c0;       /* top-left corner inside that block                                          */
+    int32_t nr, nc;       /* extent (IDENT: nr == nc)                                                   */
+    int32_t kind;         /* DMRGX_CELL_DENSE | DMRGX_CELL_IDENT                                        */
+    double  scale;        /* IDENT: the cell equals scale * I.  DENSE: ignored                          */
+    const double* data;   /* DENSE: device pointer to element (r0,c0); row-major, leading dimension ld */
+    int64_t ld;
+} dmrgx_cell;
+
+/* One operator of one block.  `transposed` != 0 means the operator is the transpose of the stored cells
+ * (Sm(i) = Sp(i)^T, src/DMRGBlock.cpp:630-632): the cells then describe the stored operator (whose shift is
+ * -shift) and are read transposed -- no Sm is ever materialised. */
+typedef struct {
+    int32_t shift;        /* sector shift of the operator AS USED (after the optional transpose)        */
+    int32_t transposed;
+    int32_t ncells;
+    const dmrgx_cell* cells;   /* host array */
+} dmrgx_secop;
+
+/* Sector table of one (enlarged) block: sizes of the Sz sectors in descending-Sz order. */
+typedef struct {
+    int32_t nsec;
+    const int32_t* size;  /* host array [nsec] */
+} dmrgx_sectors;
+
+/* ---- K1: superblock plan ---------------------------------------------------------------------------- */
+/* One inter-block term a * A(left op) (x) B(right op)  (Hamiltonians::Term after the filtering/reflection of
+ * src/DMRGKron.cpp:788-807).  left_op / right_op index into desc->left_ops / desc->right_ops. */
+typedef struct {
+    double  a;
+    int32_t left_op;
+    int32_t right_op;
+} dmrgx_term;
+
+typedef struct {
+    dmrgx_sectors left, right;
+    int32_t nblocks;               /* KronBlocks of the target sector, in the reference's order        */
+    const int32_t* block_il;       /* [nblocks] left sector index  (include/DMRGKron.hpp:160-171)      */
+    const int32_t* block_ir;       /* [nblocks] right sector index                                     */
+    int32_t n_left_ops, n_right_ops;
+    const dmrgx_secop* left_ops;   /* distinct (op,site) operators of the left block used by terms     */
+    const dmrgx_secop* right_ops;
+    const dmrgx_secop* h_left;     /* H_L (shift 0), term [H_L (x) 1]  (src/DMRGKron.cpp:939-944); may be NULL */
+    const dmrgx_secop* h_right;    /* H_R (shift 0), term [1 (x) H_R]  (src/DMRGKron.cpp:946-951); may be NULL */
+    int32_t nterms;
+    const dmrgx_term* terms;
+    /* striping of the right index over ranks; world_size == 1 -> plain layout */
+    int32_t world_size, rank;
+} dmrgx_kron_desc;
+
+typedef struct dmrgx_kron_plan dmrgx_kron_plan;
+
+typedef struct {
+    int64_t n_states;          /* N_sb = sum_k n_L n_R                                                  */
+    int64_t vec_len;           /* length of a full device vector (== n_states when world_size == 1)     */
+    int64_t local_offset;      /* this rank's segment inside a full vector                              */
+    int64_t local_len;         /* length of this rank's segment (incl. padding)                         */
+    int64_t seg_stride;        /* stride between rank segments                                          */
+    double  flops_alg;         /* algorithmic flops of ONE apply on THIS rank (SURVEY 8d F_alg)         */
+    double  bytes_alg;         /* algorithmic bytes of ONE apply on THIS rank (SURVEY 8d B_alg)         */
+    double  flops_exec;        /* flops the tiled kernels actually issue (padding included)             */
+    double  bytes_workspace;   /* bytes of intermediates written+read per apply (not part of B_alg)     */
+    int32_t n_groups;          /* merged (A,B) operator pairs                                           */
+    int32_t n_tiles_stage1, n_tiles_stage2;
+} dmrgx_kron_info;
+
+dmrgx_status dmrgx_kron_plan_create(const dmrgx_kron_desc* desc, void* stream, dmrgx_kron_plan** out);
+dmrgx_status dmrgx_kron_plan_info(const dmrgx_kron_plan* plan, dmrgx_kron_info* info);
+/* y_local <- (H x)[this rank's segment].  x_full: full vector (vec_len), y_local: points at the start of this
+ * rank's segment of a full vector or at a separate buffer of local_len doubles.  world_size==1: y = H x. */
+dmrgx_status dmrgx_kron_apply(dmrgx_kron_plan* plan, const double* x_full, double* y_local, void* stream);
+dmrgx_status dmrgx_kron_plan_destroy(dmrgx_kron_plan* plan);
+/* Convert between the reference's vector layout (KronBlocks order, n_states doubles, host or device) and the
+ * striped full-vector layout (identity copy when world_size == 1). */
+dmrgx_status dmrgx_kron_vec_to_striped(const dmrgx_kron_plan* plan, const double* v_ref_dev, double* v_full_dev, void* stream);
+dmrgx_status dmrgx_kron_vec_from_striped(const dmrgx_kron_plan* plan, const double* v_full_dev, double* v_ref_dev, void* stream);
+
+/* ---- generic grouped f64 GEMM (used by K1/K3/K6; exposed for tests) ---------------------------------- */
+/* C[M x N] (row-major, ldc) = A[M x K] (row-major, lda) * B[K x N] (row-major, ldb), device pointers. */
+dmrgx_status dmrgx_dgemm_nn(int32_t M, int32_t N, int32_t K, const double* A, int64_t lda,
+                            const double* B, int64_t ldb, double* C, int64_t ldc, void* stream);
+
+/* ---- K2: lowest eigenpair of the planned superblock Hamiltonian -------------------------------------- */
+typedef struct {
+    int32_t ncv;        /* Krylov subspace size (SLEPc default for nev=1: 16)                            */
+    int32_t max_it;     /* maximum number of restarts                                                    */
+    double  tol;        /* converged when ||r|| <= tol * |theta|  (SLEPc default criterion, default 1e-8) */
+    uint64_t seed;      /* start vector: counter-based uniform(-1,1) stream of this seed, unless ...      */
+    int32_t use_initial; /* ... use_initial != 0: psi_full holds the start vector                         */
+    /* collective hooks for world_size > 1 (NULL when world_size == 1).  They must be stream-ordered on
+     * `stream`: allgather(sendbuf=this rank's segment, full vector) and allreduce_sum(buf, count). */
+    dmrgx_status (*allgather)(void* user, double* full_vec, int64_t seg_stride, void* stream);
+    dmrgx_status (*allreduce_sum)(void* user, double* buf, int64_t count, void* stream);
+    void* user;
+} dmrgx_eigs_opts;
+
+typedef struct {
+    int32_t n_matvec;       /* number of dmrgx_kron_apply calls ("superblock MatMults")                  */
+    int32_t n_restart;
+    int32_t converged;
+    double  residual;       /* final ||H psi - e0 psi||                                                  */
+    double  seconds;        /* wall time of the solve (host clock around a stream sync)                  */
+} dmrgx_eigs_stats;
+
+dmrgx_status dmrgx_eigs_lowest(dmrgx_kron_plan* plan, const dmrgx_eigs_opts* opts, double* e0,
+                               double* psi_full, dmrgx_eigs_stats* stats, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DMRGX_H */

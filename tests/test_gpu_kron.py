@@ -1,0 +1,164 @@
+"""Parity tests proper (-m gpu): the HIP superblock path through the C ABI vs the CPU oracle.
+
+Tolerances: f64 throughout; the HIP path sums in a different order than the reference's row loop
+(src/DMRGKron.cpp:1844-1864), so the bar is 1e-13 relative to max|y| (north_star: 1e-10 relative on E0).
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import oracle_shell_from_superblock
+from oracle.kron_c import ShellApplyC
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-13
+
+
+@pytest.fixture(scope="module")
+def mods(pkg):
+    from dmrgx_amd import superblock, workloads, _capi
+    _capi.require_device()
+    return superblock, workloads, _capi
+
+
+def _apply(plan, x):
+    xd = torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    yd = torch.full_like(xd, float("nan"))      # y must be overwritten, not accumulated (src/DMRGKron.cpp:1840)
+    plan.apply(xd, yd)
+    torch.cuda.synchronize()
+    return yd.cpu().numpy()
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 1, 1), (5, 7, 3), (64, 64, 16), (65, 63, 17), (130, 257, 100), (300, 40, 513), (17, 1, 64), (1, 200, 5)])
+def test_dgemm_nn_vs_torch_fp64(mods, M, N, K):
+    sbm, _, _ = mods
+    g = torch.Generator(device="cpu").manual_seed(M * 1000 + N * 10 + K)
+    A = torch.randn(M, K, dtype=torch.float64, generator=g).cuda()
+    B = torch.randn(K, N, dtype=torch.float64, generator=g).cuda()
+    C = sbm.dgemm_nn(A, B)
+    ref = A @ B
+    assert torch.allclose(C, ref, rtol=0, atol=1e-13 * max(1.0, float(ref.abs().max())) * K ** 0.5)
+
+
+def test_dgemm_identity_asymmetric(mods):
+    """A = I with an asymmetric B catches a transposed C-fragment map (guide 'Always A=I-check')."""
+    sbm, _, _ = mods
+    n = 80
+    B = (torch.arange(n * n, dtype=torch.float64).reshape(n, n) * 1.0 + 0.25).cuda()
+    C = sbm.dgemm_nn(torch.eye(n, dtype=torch.float64).cuda(), B)
+    assert torch.equal(C, B)
+
+
+@pytest.mark.parametrize("m,Ly,cfg", [(8, 1, "cfg1"), (16, 2, "cfg2"), (40, 3, "cfg2"), (96, 4, "cfg2"), (64, 3, "cfg3"), (70, 2, "cfg5")])
+def test_apply_matches_reference_row_loop(mods, m, Ly, cfg):
+    sbm, wl, _ = mods
+    sb = wl.synthetic_superblock(cfg, m=m, Ly=Ly, seed=100 + m)
+    plan = sbm.KronPlan(sb)
+    ref = ShellApplyC(oracle_shell_from_superblock(sb))
+    rng = np.random.default_rng(m)
+    for _ in range(2):
+        x = rng.standard_normal(sb.n_states)
+        y, y_ref = _apply(plan, x), ref.apply(x)
+        assert np.abs(y - y_ref).max() <= RTOL * np.abs(y_ref).max()
+    plan.destroy()
+
+
+def test_apply_medium_vs_factored_numpy(mods):
+    sbm, wl, _ = mods
+    sb = wl.synthetic_superblock("cfg2", m=256, Ly=4)
+    plan = sbm.KronPlan(sb)
+    x = np.random.default_rng(1).standard_normal(sb.n_states)
+    y, y_ref = _apply(plan, x), wl.apply_factored_numpy(sb, x)
+    assert np.abs(y - y_ref).max() <= RTOL * np.abs(y_ref).max()
+    plan.destroy()
+
+
+def test_striped_plans_reassemble_full_apply(mods):
+    """world_size 2 and 3 emulated on one GPU: each rank's stripe of y, gathered, equals the unstriped apply."""
+    sbm, wl, _ = mods
+    sb = wl.synthetic_superblock("cfg2", m=60, Ly=3, seed=11)
+    x = np.random.default_rng(2).standard_normal(sb.n_states)
+    full = sbm.KronPlan(sb)
+    y_ref = _apply(full, x)
+    for W in (2, 3):
+        plans = [sbm.KronPlan(sb, world_size=W, rank=r) for r in range(W)]
+        info = plans[0].info
+        xd = torch.from_numpy(x).cuda()
+        xs = torch.zeros(info.vec_len, dtype=torch.float64, device="cuda")
+        plans[0].to_striped(xd, xs)
+        ys = torch.zeros_like(xs)
+        for r, p in enumerate(plans):
+            assert p.info.seg_stride == info.seg_stride and p.info.local_offset == r * info.seg_stride
+            p.apply(xs, ys[p.info.local_offset:p.info.local_offset + p.info.local_len])
+        yd = torch.zeros_like(xd)
+        plans[0].from_striped(ys, yd)
+        torch.cuda.synchronize()
+        assert np.abs(yd.cpu().numpy() - y_ref).max() <= RTOL * np.abs(y_ref).max()
+        for p in plans:
+            p.destroy()
+    full.destroy()
+
+
+@pytest.mark.parametrize("cfg", ["cfg2", "cfg3", "cfg4"])
+def test_full_size_properties(mods, cfg):
+    """BASELINE sizes: size-independent properties -- linearity and symmetry <u,Hv> = <Hu,v>."""
+    sbm, wl, _ = mods
+    sb = wl.synthetic_superblock(cfg)
+    plan = sbm.KronPlan(sb)
+    n = sb.n_states
+    g = torch.Generator(device="cuda").manual_seed(5)
+    u = torch.randn(n, dtype=torch.float64, device="cuda", generator=g)
+    v = torch.randn(n, dtype=torch.float64, device="cuda", generator=g)
+    Hu, Hv, Hc = torch.empty_like(u), torch.empty_like(u), torch.empty_like(u)
+    plan.apply(u, Hu); plan.apply(v, Hv); plan.apply(2.0 * u - 0.5 * v, Hc)
+    torch.cuda.synchronize()
+    scale = float(Hu.abs().max() + Hv.abs().max())
+    assert float((Hc - (2.0 * Hu - 0.5 * Hv)).abs().max()) <= 1e-12 * scale
+    a, b = float(torch.dot(u, Hv)), float(torch.dot(Hu, v))
+    assert abs(a - b) <= 1e-11 * float(Hu.norm() * v.norm())
+    assert plan.info.n_states == n and plan.info.flops_alg > 0
+    plan.destroy()
+
+
+def test_eigs_lowest_vs_dense(mods):
+    sbm, wl, _ = mods
+    sb = wl.synthetic_superblock("cfg2", m=32, Ly=2, seed=3)
+    plan = sbm.KronPlan(sb)
+    n = sb.n_states
+    H = np.stack([wl.apply_factored_numpy(sb, e) for e in np.eye(n)], axis=1)
+    assert np.abs(H - H.T).max() < 1e-12 * np.abs(H).max()
+    w = np.linalg.eigvalsh(H)
+    e0, psi, stats = plan.eigs_lowest(tol=1e-12, seed=9)
+    assert stats.converged == 1 and stats.n_matvec > 0
+    assert abs(e0 - w[0]) <= 1e-10 * abs(w[0])          # north_star tolerance on E0
+    r = torch.empty_like(psi)
+    plan.apply(psi, r)
+    assert float((r - e0 * psi).norm()) <= 1e-8 * abs(e0)
+    assert abs(float(psi.norm()) - 1.0) < 1e-12
+    plan.destroy()
+
+
+def test_eigs_tiny_problem_smaller_than_ncv(mods):
+    sbm, wl, _ = mods
+    sb = wl.synthetic_superblock("cfg1", m=4, Ly=1, seed=3)
+    plan = sbm.KronPlan(sb)
+    n = sb.n_states
+    H = np.stack([wl.apply_factored_numpy(sb, e) for e in np.eye(n)], axis=1)
+    e0, psi, stats = plan.eigs_lowest(tol=1e-12)
+    assert abs(e0 - np.linalg.eigvalsh(H)[0]) <= 1e-10 * max(1.0, abs(e0))
+    plan.destroy()
+
+
+def test_bad_descriptor_is_rejected_with_reference_codes(mods):
+    sbm, wl, capi = mods
+    sb = wl.synthetic_superblock("cfg2", m=16, Ly=2)
+    sb.blocks = sb.blocks + [sb.blocks[0]]
+    with pytest.raises(capi.DmrgxError) as ei:
+        sbm.KronPlan(sb)
+    assert ei.value.code == capi.DMRGX_ERR_ARG
+    sb = wl.synthetic_superblock("cfg2", m=16, Ly=2)
+    key = next(iter(sb.left_ops))
+    sb.left_ops[key].cells[0].r0 += 10_000      # planted out-of-range cell, cf. tests/UnitTests_DMRGBlock.cpp:112
+    with pytest.raises(capi.DmrgxError) as ei:
+        sbm.KronPlan(sb)
+    assert ei.value.code == capi.DMRGX_ERR_OUTOFRANGE
