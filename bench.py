@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""Benchmark of the DMRG hot path on MI355X: superblock MatMults/s inside the ground-state eigensolve.
+
+A "step" is one Lanczos step of the eigensolve on one synthetic superblock of a BASELINE.json config:
+one superblock MatMult (the Sz-sector block-sparse Kronecker apply, == MatMult_KronSumShell) plus its
+reorthogonalisation passes and the amortised thick restart.  Inputs (operators, vectors) are resident in HBM
+before the timed region.  value = MatMults/s of the whole job (all ranks work on ONE superblock: strong scaling).
+
+  python bench.py --gpus N --steps K --warmup W [--workload cfg4]
+  N > 1: launched by torch.distributed.run, one rank per GPU, RCCL all-gather / all-reduce over xGMI.
+
+The JSON line also carries `roofline` (dominant kernel = the grouped MFMA-f64 GEMM, timed with HIP events on
+its own stream inside the timed region) and `cpu_baseline` (the oracle's literal restatement of the
+reference's row loop, timed on this host's cores on a bounded row sample; N = 1, rank 0 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+F64_PEAK_TFLOPS = 78.6   # MI355X dense f64 MFMA peak (AMD datasheet; v_mfma_f64_16x16x4 = 64 cycles/SIMD measured:
+                         # 72-75 TF/s sustained at the clock the chip holds, profiles/r01_mfma_f64_probe.txt)
+HBM_PEAK_TBS = 8.0
+
+
+def cpu_baseline(sb, budget_s=15.0):
+    """Literal reference row loop (oracle/kron_ref.c) on all host cores over evenly spread row chunks."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import oracle_shell_from_superblock
+    from oracle.kron_c import ShellApplyC
+    shell = oracle_shell_from_superblock(sb)
+    ref = ShellApplyC(shell)
+    N = shell.N
+    x = np.random.default_rng(0).standard_normal(N)
+    total_flops = float(ref.flops())
+    nthreads = int(os.environ.get("DMRGX_CPU_THREADS", min(len(os.sched_getaffinity(0)), 16)))   # box share: 16 cores per GPU
+    nchunk = 8
+
+    def run(rows):
+        rows = int(min(max(rows, 8 * nthreads), N // nchunk))
+        t, f = 0.0, 0.0
+        for c in range(nchunk):
+            r0 = max(0, min(N - rows, int((c + 0.5) * N / nchunk) - rows // 2))
+            t0 = time.perf_counter()
+            ref.apply(x, r0, r0 + rows, nthreads)
+            t += time.perf_counter() - t0
+            f += float(ref.flops(r0, r0 + rows))
+        return t, f, rows * nchunk
+    rows = 8 * nthreads
+    t, f, nrows = run(rows)
+    while t < budget_s / 4 and nrows < N // 2:      # grow the sample until it is a meaningful fraction of the budget
+        rows = int(rows * min(8.0, max(2.0, 0.8 * budget_s / max(t, 1e-3))))
+        t, f, nrows = run(rows)
+    full_time = t * total_flops / f
+    return {"value": 1.0 / full_time, "unit": "MatMults/s", "cores": int(ref.threads_used), "kind": "port",
+            "sample": f"{nrows} of {N} rows in {nchunk} evenly spread chunks ({t:.1f} s measured, "
+                      f"{f / t / 1e9:.1f} GF/s unfactored), extrapolated by the row loop's exact flop count "
+                      f"({total_flops / 1e9:.0f} GF per MatMult)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--workload", default="cfg4", help="BASELINE.json config: cfg1..cfg5 (default cfg4 = J1-J2 20x8, m=2048)")
+    ap.add_argument("--ncv", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        sys.exit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from __graft_entry__ import load_package
+    load_package()
+    from dmrgx_amd.superblock import KronPlan
+    from dmrgx_amd.workloads import synthetic_superblock, CONFIGS
+    from dmrgx_amd import collectives
+
+    sb = synthetic_superblock(args.workload)
+    plan = KronPlan(sb, device=f"cuda:{local_rank}", world_size=world, rank=rank)
+    info = plan.info
+    hooks = collectives.torch_hooks(dist, rank, world) if world > 1 else {}
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    plan.eigs_lowest(ncv=args.ncv, tol=1e-300, seed=1, max_matvec=max(args.warmup, 1), **hooks)   # untimed warm-up
+    barrier()
+    plan.timing(True)
+    t0 = time.perf_counter()
+    _, _, stats = plan.eigs_lowest(ncv=args.ncv, tol=1e-300, seed=2, max_matvec=args.steps, **hooks)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    plan.timing(False)
+    assert stats.n_matvec == args.steps, (stats.n_matvec, args.steps)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms4, napp = plan.timing_read()
+    ms1, ms2 = ms4[0] + ms4[1], ms4[2] + ms4[3]
+    # dominant kernel: the grouped MFMA-f64 GEMM; 64x64 instantiation unless DMRGX_TILES=mixed routes the
+    # 128-aligned cores to the 128x128 one.  Two launches of it per MatMult (stage 1, stage 2).
+    launches = 2 * napp
+    if info.n_tiles_big > 0:
+        kernel, avg_ms, flops_per_launch = "dmrgx::ggemm_kernel<4,2,2,4>", (ms4[0] + ms4[2]) / max(launches, 1), info.flops_alg_big / 2.0
+    else:
+        kernel, avg_ms, flops_per_launch = "dmrgx::ggemm_kernel<2,2,2,2>", (ms4[1] + ms4[3]) / max(launches, 1), info.flops_alg / 2.0
+    achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+    gemm_all = info.flops_alg / max((ms1 + ms2) / max(napp, 1) * 1e-3, 1e-12) / 1e12     # all four GEMM launches together
+
+    # K1 in isolation (MatMult only, no Lanczos vector work)
+    x = torch.randn(info.vec_len, dtype=torch.float64, device="cuda")
+    y = torch.zeros(info.vec_len, dtype=torch.float64, device="cuda")
+    yl = y[info.local_offset:info.local_offset + info.local_len]
+    for _ in range(3):
+        plan.apply(x, yl)
+    barrier()
+    t1 = time.perf_counter()
+    for _ in range(20):
+        plan.apply(x, yl)
+    barrier()
+    iso = 20 / (time.perf_counter() - t1)
+
+    out = {
+        "metric": "superblock MatMults/sec inside the ground-state eigensolve (Lanczos step = 1 MatMult + reorthogonalisation)",
+        "value": args.steps / elapsed, "unit": "MatMults/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"{args.workload}: {CONFIGS[args.workload]['desc']}; mid-sweep column cut, sector profile sigma=1.8 (SURVEY 8d)",
+                   "m": CONFIGS[args.workload]["m"], "n_states": int(info.n_states), "n_terms": len(sb.terms) + 2,
+                   "ncv": args.ncv, "parallelism": f"right-index stripes over {world} GPU(s)"},
+        "matmult_isolated_per_s": iso,
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": F64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved / F64_PEAK_TFLOPS, "traffic": None,
+                     "kernel": kernel, "avg_launch_ms": avg_ms, "launches": launches,
+                     "flops_alg_per_launch": flops_per_launch, "all_gemm_launches_tflops": gemm_all,
+                     "ms_per_matmult_by_launch": {"stage1_128": ms4[0] / max(napp, 1), "stage1_64": ms4[1] / max(napp, 1),
+                                                  "stage2_128": ms4[2] / max(napp, 1), "stage2_64": ms4[3] / max(napp, 1)},
+                     "tiles_128": info.n_tiles_big,
+                     "flops_alg_per_matmult": info.flops_alg, "bytes_alg_per_matmult": info.bytes_alg,
+                     "flops_exec_per_matmult": info.flops_exec,
+                     "stage1_ms_per_matmult": ms1 / max(napp, 1), "stage2_ms_per_matmult": ms2 / max(napp, 1),
+                     "tiles_stage1": info.n_tiles_stage1, "tiles_stage2": info.n_tiles_stage2,
+                     "hbm_frac_of_peak": (info.bytes_alg + info.bytes_workspace) / max((ms1 + ms2) / max(napp, 1) * 1e-3, 1e-12) / (HBM_PEAK_TBS * 1e12)},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(sb)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out))
+    plan.destroy()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

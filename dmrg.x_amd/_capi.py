@@ -53,7 +53,8 @@ class KronDesc(C.Structure):
 class KronInfo(C.Structure):
     _fields_ = [("n_states", C.c_int64), ("vec_len", C.c_int64), ("local_offset", C.c_int64), ("local_len", C.c_int64),
                 ("seg_stride", C.c_int64), ("flops_alg", C.c_double), ("bytes_alg", C.c_double), ("flops_exec", C.c_double),
-                ("bytes_workspace", C.c_double), ("n_groups", C.c_int32), ("n_tiles_stage1", C.c_int32), ("n_tiles_stage2", C.c_int32)]
+                ("bytes_workspace", C.c_double), ("n_groups", C.c_int32), ("n_tiles_stage1", C.c_int32), ("n_tiles_stage2", C.c_int32),
+                ("n_tiles_big", C.c_int32), ("flops_alg_big", C.c_double)]
 
 
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
@@ -62,7 +63,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_voi
 
 class EigsOpts(C.Structure):
     _fields_ = [("ncv", C.c_int32), ("max_it", C.c_int32), ("tol", C.c_double), ("seed", C.c_uint64),
-                ("use_initial", C.c_int32), ("allgather", ALLGATHER_FN), ("allreduce_sum", ALLREDUCE_FN), ("user", C.c_void_p)]
+                ("use_initial", C.c_int32), ("max_matvec", C.c_int32), ("allgather", ALLGATHER_FN), ("allreduce_sum", ALLREDUCE_FN), ("user", C.c_void_p)]
 
 
 class EigsStats(C.Structure):
@@ -79,8 +80,11 @@ SIGNATURES = {
     "dmrgx_kron_plan_info": (C.c_int32, [C.c_void_p, C.POINTER(KronInfo)]),
     "dmrgx_kron_apply": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dmrgx_kron_plan_destroy": (C.c_int32, [C.c_void_p]),
+    "dmrgx_kron_plan_timing": (C.c_int32, [C.c_void_p, C.c_int32]),
+    "dmrgx_kron_plan_timing_read": (C.c_int32, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "dmrgx_kron_vec_to_striped": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dmrgx_kron_vec_from_striped": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dmrgx_stripe_bounds": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "dmrgx_dgemm_nn": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
                                    C.c_void_p, C.c_int64, C.c_void_p]),
     "dmrgx_eigs_lowest": (C.c_int32, [C.c_void_p, C.POINTER(EigsOpts), C.POINTER(C.c_double), C.c_void_p,

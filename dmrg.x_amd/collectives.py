@@ -1,0 +1,32 @@
+"""Collective hooks of the eigensolver for world_size > 1, over torch.distributed (backend "nccl" == RCCL).
+
+The C ABI asks for two stream-ordered callbacks (include/dmrgx.h, dmrgx_eigs_opts): an in-place all-gather of
+the Krylov vector's rank segments and a sum all-reduce of a few doubles.  They replace the reference's
+VecScatter-to-all inside every MatMult (src/DMRGKron.cpp:1833-1834) and the MPI_Allreduce behind SLEPc's
+VecDot/VecNorm.  Raw device pointers from the library are wrapped zero-copy as torch tensors.
+"""
+import torch
+
+
+class _Raw:
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f8", "data": (int(ptr), False), "version": 2}
+
+
+def _view(ptr, n, device):
+    return torch.as_tensor(_Raw(ptr, n), device=device)
+
+
+def torch_hooks(dist, rank, world):
+    device = torch.device("cuda", torch.cuda.current_device())
+
+    def allgather(user, full_ptr, seg_stride, stream):
+        full = _view(full_ptr, seg_stride * world, device)
+        dist.all_gather_into_tensor(full, full[rank * seg_stride:(rank + 1) * seg_stride])
+        return 0
+
+    def allreduce(user, buf_ptr, count, stream):
+        dist.all_reduce(_view(buf_ptr, count, device))
+        return 0
+
+    return {"allgather": allgather, "allreduce": allreduce}

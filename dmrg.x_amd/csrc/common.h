@@ -33,6 +33,9 @@ void set_error(const char* fmt, ...);
         return (code);                     \
     } while (0)
 
+// Stripe rule of the multi-GPU layout: rank w owns columns [stripe_cut(n,W,w), stripe_cut(n,W,w+1)) of a KronBlock.
+inline int32_t stripe_cut(int32_t n, int32_t W, int32_t w) { return (int32_t)(((int64_t)n * w) / W); }
+
 // RAII device buffer owned by a plan.
 struct DevBuf {
     void* p = nullptr;

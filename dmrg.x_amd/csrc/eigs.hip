@@ -286,7 +286,10 @@ extern "C" dmrgx_status dmrgx_eigs_lowest(dmrgx_kron_plan* plan, const dmrgx_eig
     std::vector<double> Qdev;
     while (true) {
         DMRGX_HIP(hipMemsetAsync(Hrow(k), 0, (size_t)(m + 1 - k) * row * sizeof(double), st));
-        for (int j = k; j < m; ++j) {
+        int jend = m;                                         // benchmark mode: stop after exactly max_matvec MatMults
+        if (opts->max_matvec > 0) jend = std::min(m, k + std::max(0, opts->max_matvec - n_matvec));
+        const bool capped = jend < m || (opts->max_matvec > 0 && n_matvec + (m - k) >= opts->max_matvec);
+        for (int j = k; j < jend; ++j) {
             DMRGX_CHK(matvec(vec(j), w));
             ++n_matvec;
             DMRGX_CHK(multi_dot(j + 1));                      // pass 1
@@ -298,6 +301,22 @@ extern "C" dmrgx_status dmrgx_eigs_lowest(dmrgx_kron_plan* plan, const dmrgx_eig
         }
         DMRGX_HIP(hipMemcpyAsync(hbuf.data(), dScal.p, (size_t)(m + 1) * row * sizeof(double), hipMemcpyDeviceToHost, st));
         DMRGX_HIP(hipStreamSynchronize(st));
+        if (jend < m) {                                       // truncated cycle: Rayleigh-Ritz on the jend columns built so far
+            const int mm = jend;
+            if (mm < 1) break;
+            std::vector<double> A((size_t)mm * mm, 0.0), th, Qs;
+            for (int j = 0; j < mm; ++j) for (int i = 0; i <= j; ++i) {
+                const double v = (j >= k) ? hbuf[(size_t)j * row + i] : T[(size_t)i * m + j];
+                A[(size_t)i * mm + j] = v; A[(size_t)j * mm + i] = v;
+            }
+            jacobi_eigh(mm, A, th, Qs);
+            lambda = th[0];
+            resid = std::fabs(std::sqrt(std::max(0.0, hbuf[(size_t)(mm - 1) * row + m + 1])) * Qs[(size_t)(mm - 1) * mm + 0]);
+            Q.assign((size_t)m * m, 0.0);
+            for (int i = 0; i < mm; ++i) Q[(size_t)i * m + 0] = Qs[(size_t)i * mm + 0];
+            ++restarts;
+            break;
+        }
         // projected matrix: kept Ritz block is diagonal, new columns come from the recorded coefficients
         for (int j = k; j < m; ++j)
             for (int i = 0; i <= j; ++i) { T[(size_t)i * m + j] = hbuf[(size_t)j * row + i]; T[(size_t)j * m + i] = T[(size_t)i * m + j]; }
@@ -308,7 +327,7 @@ extern "C" dmrgx_status dmrgx_eigs_lowest(dmrgx_kron_plan* plan, const dmrgx_eig
         resid = std::fabs(beta_m * Q[(size_t)(m - 1) * m + 0]);
         ++restarts;
         if (resid <= tol * std::max(std::fabs(lambda), 1e-300) || m == N) { converged = 1; break; }
-        if (restarts >= max_it) break;
+        if (restarts >= max_it || capped) break;
         // thick restart: keep the kk lowest Ritz vectors + the residual direction V[m]
         const int kk = std::max(1, std::min(m / 2, m - 1));
         Qdev.assign((size_t)m * kk, 0.0);

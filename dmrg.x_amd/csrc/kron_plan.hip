@@ -95,6 +95,16 @@ __global__ void layout_copy_kernel(const LayoutSeg* __restrict__ segs, const dou
     }
 }
 
+// y[e] += slab_0[e] + slab_1[e] + ...  (fixed order: bit-reproducible split-K)
+__global__ void slab_reduce_kernel(double* __restrict__ y, const double* __restrict__ slabs, int64_t ylen, int nslab)
+{
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < ylen; e += (int64_t)gridDim.x * blockDim.x) {
+        double v = y[e];
+        for (int s = 0; s < nslab; ++s) v += slabs[(int64_t)s * ylen + e];
+        y[e] = v;
+    }
+}
+
 }  // namespace
 }  // namespace dmrgx
 
@@ -139,12 +149,18 @@ struct dmrgx_kron_plan {
     DevBuf arena;                       // operators + intermediates
     DevBuf d_rprods, d_rgroups;         // relative tables (stage 1 then stage 2, one array)
     DevBuf d_prods, d_groups;           // patched absolute tables
-    DevBuf d_tiles1, d_tiles2;
-    int32_t nprods = 0, ngroups = 0, ntiles1 = 0, ntiles2 = 0;
+    DevBuf d_tiles1, d_tiles2, d_tiles1b, d_tiles2b;
+    int32_t nprods = 0, ngroups = 0, ntiles1 = 0, ntiles2 = 0, ntiles1b = 0, ntiles2b = 0;
     DevBuf d_layout;
     int32_t nlayout = 0;
+    int64_t slab_off = 0, ylen = 0;     // split-K partial-sum slabs inside the arena
+    int32_t nslab = 0;
     const double* last_x = nullptr;     // tables are re-patched only when the (x,y) pair changes
     double* last_y = nullptr;
+    bool timing = false;                // per-stage HIP-event timing (dmrgx_kron_plan_timing)
+    std::vector<hipEvent_t> ev;         // 3 events per recorded apply
+    size_t ev_used = 0;
+    ~dmrgx_kron_plan() { for (hipEvent_t e : ev) (void)hipEventDestroy(e); }
 };
 
 namespace {
@@ -178,8 +194,62 @@ dmrgx_status normalise_op(const dmrgx_secop* op, const dmrgx_sectors& sec, const
 struct Builder {
     std::vector<RelProd> prods;
     std::vector<RelGroup> groups;
-    std::vector<GTile> tiles1, tiles2;
-    double flops_alg = 0, flops_exec = 0;
+    std::vector<GTile> tiles1, tiles2, tiles1b, tiles2b;   // 64x64 lists and 128x128 lists per stage
+    std::vector<int32_t> stage2_groups;
+    double flops_alg = 0, flops_exec = 0, flops_alg_big = 0;
+    bool big = ggemm_use_big_tiles();
+    int32_t max_split = 1;
+
+    int32_t ksteps(int32_t g) const {      // cost of one tile of group g in k-steps of the GEMM stream
+        int32_t c = 0;
+        for (int32_t p = groups[g].prod_begin; p < groups[g].prod_end; ++p)
+            c += prods[p].kind == GPROD_GEMM ? (prods[p].K + GG_BK - 1) / GG_BK : 1;
+        return c;
+    }
+
+    // Stage-2 output tiles carry the whole operator list of a KronBlock (K ~ 10^4 at m = 2048) and there are fewer
+    // of them than workgroup slots, so long product lists are cut into up to 8 contiguous segments ("split-K").
+    // Segment 0 writes y, segment s >= 1 writes slab s-1 (same layout as y, in the arena); a fixed-order reduce
+    // kernel adds the slabs into y afterwards, so the result stays bit-reproducible (no atomics).
+    void finalize_stage2(int64_t slab_base, int64_t ylen) {
+        double total = 0;
+        for (int32_t g : stage2_groups) {
+            const RelGroup& G = groups[g];
+            total += (double)ksteps(g) * ((G.M + GG_BM - 1) / GG_BM) * ((G.N + GG_BN - 1) / GG_BN);
+        }
+        const double seg_target = std::max(total / 2048.0, 8.0);
+        const size_t ng = stage2_groups.size();
+        for (size_t gi = 0; gi < ng; ++gi) {
+            const int32_t g = stage2_groups[gi];
+            const int32_t cost = ksteps(g);
+            const int32_t gemm_begin = groups[g].prod_begin + groups[g].n_axpy, gemm_end = groups[g].prod_end;
+            int32_t S = (int32_t)std::min<double>(8.0, std::max(1.0, std::ceil(cost / seg_target)));
+            S = std::max(1, std::min(S, gemm_end - gemm_begin));
+            if (S == 1) { ggemm_append_tiles_mixed(tiles2b, tiles2, g, groups[g].M, groups[g].N, cost, big); continue; }
+            max_split = std::max(max_split, S);
+            int32_t gcost = 0;
+            for (int32_t p = gemm_begin; p < gemm_end; ++p) gcost += (prods[p].K + GG_BK - 1) / GG_BK;
+            int32_t p = gemm_begin, done = 0;
+            for (int32_t sidx = 0; sidx < S; ++sidx) {
+                const int32_t want = (int32_t)(((int64_t)gcost * (sidx + 1)) / S);
+                const int32_t b = p;
+                int32_t c = 0;
+                while (p < gemm_end && (done < want || p == b) && (gemm_end - p) > (S - 1 - sidx)) { const int32_t k = (prods[p].K + GG_BK - 1) / GG_BK; done += k; c += k; ++p; }
+                if (sidx == S - 1) while (p < gemm_end) { c += (prods[p].K + GG_BK - 1) / GG_BK; ++p; }
+                if (sidx == 0) {
+                    groups[g].prod_end = p;
+                    ggemm_append_tiles_mixed(tiles2b, tiles2, g, groups[g].M, groups[g].N, c + groups[g].n_axpy, big);
+                } else {
+                    RelGroup ng2 = groups[g];
+                    ng2.c_base = BASE_ARENA;
+                    ng2.c_off = slab_base + (int64_t)(sidx - 1) * ylen + groups[g].c_off;
+                    ng2.prod_begin = b; ng2.prod_end = p; ng2.n_axpy = 0; ng2.accumulate = 0;
+                    groups.push_back(ng2);
+                    ggemm_append_tiles_mixed(tiles2b, tiles2, (int32_t)groups.size() - 1, ng2.M, ng2.N, c, big);
+                }
+            }
+        }
+    }
 
     // open a group; products are appended afterwards with add_*; close() sorts AXPY first
     int32_t open(int32_t c_base, int64_t c_off, int32_t ldc, int32_t M, int32_t N, int32_t accumulate) {
@@ -205,9 +275,11 @@ struct Builder {
                 flops_alg += 2.0 * mn * prods[p].K;
                 const double tm = (G.M + GG_BM - 1) / GG_BM, tn = (G.N + GG_BN - 1) / GG_BN;
                 flops_exec += 2.0 * tm * tn * GG_BM * GG_BN * (double)(((prods[p].K + GG_BK - 1) / GG_BK) * GG_BK);
+                if (big) flops_alg_big += 2.0 * (double)((G.M / 128) * 128) * (double)((G.N / 128) * 128) * prods[p].K;
             }
         }
-        ggemm_append_tiles(stage == 1 ? tiles1 : tiles2, g, G.M, G.N);
+        if (stage == 1) ggemm_append_tiles_mixed(tiles1b, tiles1, g, G.M, G.N, ksteps(g), big);
+        else stage2_groups.push_back(g);
     }
 };
 
@@ -241,7 +313,7 @@ extern "C" dmrgx_status dmrgx_kron_plan_create(const dmrgx_kron_desc* d, void* s
     auto nLk = [&](int32_t k) { return SL.size[d->block_il[k]]; };
     auto nRk = [&](int32_t k) { return SR.size[d->block_ir[k]]; };
     // stripes: columns [cb(k,w), cb(k,w+1)) of block k belong to rank w
-    auto cb = [&](int32_t k, int32_t w) { return (int32_t)(((int64_t)nRk(k) * w) / W); };
+    auto cb = [&](int32_t k, int32_t w) { return stripe_cut(nRk(k), W, w); };
     std::vector<std::vector<int64_t>> seg_off(W, std::vector<int64_t>(nb + 1, 0));
     int64_t max_seg = 0;
     for (int32_t w = 0; w < W; ++w) {
@@ -421,12 +493,22 @@ extern "C" dmrgx_status dmrgx_kron_plan_create(const dmrgx_kron_desc* d, void* s
         }
     }
 
+    const int64_t ylen = (W == 1) ? N : seg_stride;
+    const int64_t slab_base = arena_ops + arena_T;
+    B.finalize_stage2(slab_base, ylen);
+    const int64_t arena_slabs = (int64_t)(B.max_split - 1) * ylen;
+    ggemm_schedule(B.tiles1);
+    ggemm_schedule(B.tiles2);
+    ggemm_schedule(B.tiles1b);
+    ggemm_schedule(B.tiles2b);
+
     // ---- device objects ------------------------------------------------------------------------------------
     dmrgx_kron_plan* P = new (std::nothrow) dmrgx_kron_plan();
     if (!P) DMRGX_FAIL(DMRGX_ERR_MEM, "out of host memory");
     std::unique_ptr<dmrgx_kron_plan> guard(P);
     P->world = W; P->rank = me;
-    DMRGX_CHK(P->arena.alloc((size_t)std::max<int64_t>(arena_ops + arena_T, 1) * sizeof(double)));
+    DMRGX_CHK(P->arena.alloc((size_t)std::max<int64_t>(arena_ops + arena_T + arena_slabs, 1) * sizeof(double)));
+    P->slab_off = slab_base; P->ylen = ylen; P->nslab = B.max_split - 1;
     DMRGX_HIP(hipMemsetAsync(P->arena.p, 0, P->arena.bytes, st));
     {   // operator copies, one launch per accumulation round
         int32_t max_round = -1;
@@ -449,10 +531,13 @@ extern "C" dmrgx_status dmrgx_kron_plan_create(const dmrgx_kron_desc* d, void* s
     }
     P->nprods = (int32_t)B.prods.size(); P->ngroups = (int32_t)B.groups.size();
     P->ntiles1 = (int32_t)B.tiles1.size(); P->ntiles2 = (int32_t)B.tiles2.size();
+    P->ntiles1b = (int32_t)B.tiles1b.size(); P->ntiles2b = (int32_t)B.tiles2b.size();
     DMRGX_CHK(upload(P->d_rprods, B.prods, st));
     DMRGX_CHK(upload(P->d_rgroups, B.groups, st));
     DMRGX_CHK(upload(P->d_tiles1, B.tiles1, st));
     DMRGX_CHK(upload(P->d_tiles2, B.tiles2, st));
+    DMRGX_CHK(upload(P->d_tiles1b, B.tiles1b, st));
+    DMRGX_CHK(upload(P->d_tiles2b, B.tiles2b, st));
     DMRGX_CHK(P->d_prods.alloc(std::max<size_t>(B.prods.size(), 1) * sizeof(GProd)));
     DMRGX_CHK(P->d_groups.alloc(std::max<size_t>(B.groups.size(), 1) * sizeof(GGroup)));
     {   // layout conversion table (reference order <-> rank-major stripes)
@@ -475,8 +560,9 @@ extern "C" dmrgx_status dmrgx_kron_plan_create(const dmrgx_kron_desc* d, void* s
     for (auto& g : G) { cellbytes(g.left); cellbytes(g.rightT); }
     cellbytes(PHL); cellbytes(PHRT);
     I.bytes_alg = opbytes + 8.0 * ((double)N + (double)seg_off[me][nb]);
-    I.bytes_workspace = 16.0 * (double)arena_T;
-    I.n_groups = (int32_t)G.size(); I.n_tiles_stage1 = P->ntiles1; I.n_tiles_stage2 = P->ntiles2;
+    I.bytes_workspace = 16.0 * (double)arena_T + 8.0 * (double)ylen * (2.0 * (B.max_split - 1) + (B.max_split > 1 ? 2.0 : 0.0));
+    I.n_groups = (int32_t)G.size(); I.n_tiles_stage1 = P->ntiles1 + P->ntiles1b; I.n_tiles_stage2 = P->ntiles2 + P->ntiles2b;
+    I.n_tiles_big = P->ntiles1b + P->ntiles2b; I.flops_alg_big = B.flops_alg_big;
     (void)n_groups_stage1;
     *out = guard.release();
     return DMRGX_OK;
@@ -504,8 +590,45 @@ extern "C" dmrgx_status dmrgx_kron_apply(dmrgx_kron_plan* P, const double* x_ful
         }
         P->last_x = x_full; P->last_y = y_local;
     }
-    DMRGX_CHK(ggemm_launch(P->d_tiles1.as<GTile>(), P->d_groups.as<GGroup>(), P->d_prods.as<GProd>(), P->ntiles1, st));
-    DMRGX_CHK(ggemm_launch(P->d_tiles2.as<GTile>(), P->d_groups.as<GGroup>(), P->d_prods.as<GProd>(), P->ntiles2, st));
+    hipEvent_t* e = nullptr;
+    if (P->timing && P->ev_used + 5 <= 5 * 4096) {
+        while (P->ev.size() < P->ev_used + 5) { hipEvent_t x; DMRGX_HIP(hipEventCreate(&x)); P->ev.push_back(x); }
+        e = &P->ev[P->ev_used];
+        P->ev_used += 5;
+    }
+    // four launches: {stage 1, stage 2} x {128x128 core tiles, 64x64 remainder tiles}, each bracketed by events
+    if (e) DMRGX_HIP(hipEventRecord(e[0], st));
+    DMRGX_CHK(ggemm_launch(P->d_tiles1b.as<GTile>(), P->d_groups.as<GGroup>(), P->d_prods.as<GProd>(), P->ntiles1b, st, 1));
+    if (e) DMRGX_HIP(hipEventRecord(e[1], st));
+    DMRGX_CHK(ggemm_launch(P->d_tiles1.as<GTile>(), P->d_groups.as<GGroup>(), P->d_prods.as<GProd>(), P->ntiles1, st, 0));
+    if (e) DMRGX_HIP(hipEventRecord(e[2], st));
+    DMRGX_CHK(ggemm_launch(P->d_tiles2b.as<GTile>(), P->d_groups.as<GGroup>(), P->d_prods.as<GProd>(), P->ntiles2b, st, 1));
+    if (e) DMRGX_HIP(hipEventRecord(e[3], st));
+    DMRGX_CHK(ggemm_launch(P->d_tiles2.as<GTile>(), P->d_groups.as<GGroup>(), P->d_prods.as<GProd>(), P->ntiles2, st, 0));
+    if (e) DMRGX_HIP(hipEventRecord(e[4], st));
+    if (P->nslab > 0) {
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(2048), dim3(256), 0, st, y_local, P->arena.as<double>() + P->slab_off, P->ylen, P->nslab);
+        DMRGX_HIP(hipGetLastError());
+    }
+    return DMRGX_OK;
+}
+
+extern "C" dmrgx_status dmrgx_kron_plan_timing(dmrgx_kron_plan* P, int32_t enable)
+{
+    if (!P) DMRGX_FAIL(DMRGX_ERR_ARG, "kron_plan_timing: null plan");
+    if (enable) P->ev_used = 0;
+    P->timing = enable != 0;
+    return DMRGX_OK;
+}
+
+extern "C" dmrgx_status dmrgx_kron_plan_timing_read(dmrgx_kron_plan* P, double* ms, int64_t* n_applies)
+{
+    if (!P || !ms || !n_applies) DMRGX_FAIL(DMRGX_ERR_ARG, "kron_plan_timing_read: null argument");
+    ms[0] = ms[1] = ms[2] = ms[3] = 0.0; *n_applies = (int64_t)(P->ev_used / 5);
+    for (size_t i = 0; i + 4 < P->ev_used; i += 5) {
+        DMRGX_HIP(hipEventSynchronize(P->ev[i + 4]));
+        for (int k = 0; k < 4; ++k) { float t = 0; DMRGX_HIP(hipEventElapsedTime(&t, P->ev[i + k], P->ev[i + k + 1])); ms[k] += t; }
+    }
     return DMRGX_OK;
 }
 

@@ -32,6 +32,14 @@ extern "C" dmrgx_status dmrgx_device_count(int32_t* n)
     return DMRGX_OK;
 }
 
+extern "C" dmrgx_status dmrgx_stripe_bounds(int32_t n_right, int32_t world_size, int32_t rank, int32_t* c0, int32_t* c1)
+{
+    if (!c0 || !c1 || n_right < 0 || world_size <= 0 || rank < 0 || rank >= world_size) DMRGX_FAIL(DMRGX_ERR_ARG, "stripe_bounds: bad argument");
+    *c0 = dmrgx::stripe_cut(n_right, world_size, rank);
+    *c1 = dmrgx::stripe_cut(n_right, world_size, rank + 1);
+    return DMRGX_OK;
+}
+
 extern "C" dmrgx_status dmrgx_dgemm_nn(int32_t M, int32_t N, int32_t K, const double* A, int64_t lda,
                                        const double* B, int64_t ldb, double* C, int64_t ldc, void* stream)
 {
@@ -42,14 +50,16 @@ extern "C" dmrgx_status dmrgx_dgemm_nn(int32_t M, int32_t N, int32_t K, const do
     std::vector<GProd> prods;
     if (K > 0) prods.push_back(GProd{A, B, (int32_t)lda, (int32_t)ldb, K, GPROD_GEMM, 1.0});
     std::vector<GGroup> groups = {GGroup{C, (int32_t)ldc, M, N, 0, (int32_t)prods.size(), 0, 0}};
-    std::vector<GTile> tiles;
-    ggemm_append_tiles(tiles, 0, M, N);
-    DevBuf dp, dg, dt;
+    std::vector<GTile> tiles, big;
+    ggemm_append_tiles_mixed(big, tiles, 0, M, N);
+    DevBuf dp, dg, dt, db;
     if (prods.empty()) prods.push_back(GProd{nullptr, nullptr, 0, 0, 0, GPROD_GEMM, 0.0});
     DMRGX_CHK(upload(dp, prods, st));
     DMRGX_CHK(upload(dg, groups, st));
     DMRGX_CHK(upload(dt, tiles, st));
-    DMRGX_CHK(ggemm_launch(dt.as<GTile>(), dg.as<GGroup>(), dp.as<GProd>(), (int32_t)tiles.size(), st));
+    DMRGX_CHK(upload(db, big, st));
+    DMRGX_CHK(ggemm_launch(db.as<GTile>(), dg.as<GGroup>(), dp.as<GProd>(), (int32_t)big.size(), st, 1));
+    DMRGX_CHK(ggemm_launch(dt.as<GTile>(), dg.as<GGroup>(), dp.as<GProd>(), (int32_t)tiles.size(), st, 0));
     DMRGX_HIP(hipStreamSynchronize(st));   // tables are freed on return
     return DMRGX_OK;
 }

@@ -113,10 +113,13 @@ class KronPlan:
         _capi.check(_capi.lib().dmrgx_kron_vec_from_striped(self._handle, C.c_void_p(v_full.data_ptr()), C.c_void_p(v_ref.data_ptr()),
                                                             self._stream_ptr(stream)))
 
-    def eigs_lowest(self, ncv=16, max_it=1000, tol=1e-8, seed=1, psi0=None, allgather=None, allreduce=None, stream=None):
-        """Lowest eigenpair (EPS_HEP / EPS_SMALLEST_REAL / nev=1).  Returns (e0, psi_full tensor, stats)."""
+    def eigs_lowest(self, ncv=16, max_it=1000, tol=1e-8, seed=1, psi0=None, allgather=None, allreduce=None, stream=None,
+                    max_matvec=0):
+        """Lowest eigenpair (EPS_HEP / EPS_SMALLEST_REAL / nev=1).  Returns (e0, psi_full tensor, stats).
+
+        max_matvec > 0 (benchmarks): run exactly that many Lanczos steps; non-convergence is then not an error."""
         opts = _capi.EigsOpts()
-        opts.ncv, opts.max_it, opts.tol, opts.seed = ncv, max_it, tol, seed
+        opts.ncv, opts.max_it, opts.tol, opts.seed, opts.max_matvec = ncv, max_it, tol, seed, max_matvec
         psi = self.new_vector()
         if psi0 is not None:
             psi.copy_(psi0)
@@ -126,9 +129,20 @@ class KronPlan:
         opts.allgather, opts.allreduce_sum = self._cb
         e0 = C.c_double(0.0)
         stats = _capi.EigsStats()
-        _capi.check(_capi.lib().dmrgx_eigs_lowest(self._handle, C.byref(opts), C.byref(e0), C.c_void_p(psi.data_ptr()),
-                                                  C.byref(stats), self._stream_ptr(stream)))
+        rc = _capi.lib().dmrgx_eigs_lowest(self._handle, C.byref(opts), C.byref(e0), C.c_void_p(psi.data_ptr()),
+                                           C.byref(stats), self._stream_ptr(stream))
+        if not (rc == _capi.DMRGX_ERR_NOTCONV and max_matvec > 0):
+            _capi.check(rc)
         return e0.value, psi, stats
+
+    def timing(self, enable):
+        _capi.check(_capi.lib().dmrgx_kron_plan_timing(self._handle, 1 if enable else 0))
+
+    def timing_read(self):
+        """-> ([ms stage-1 128-tiles, ms stage-1 64-tiles, ms stage-2 128-tiles, ms stage-2 64-tiles], applies recorded)."""
+        ms, n = (C.c_double * 4)(), C.c_int64(0)
+        _capi.check(_capi.lib().dmrgx_kron_plan_timing_read(self._handle, ms, C.byref(n)))
+        return list(ms), n.value
 
     def destroy(self):
         if self._handle:

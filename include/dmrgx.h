@@ -125,6 +125,8 @@ typedef struct {
     double  bytes_workspace;   /* bytes of intermediates written+read per apply (not part of B_alg)     */
     int32_t n_groups;          /* merged (A,B) operator pairs                                           */
     int32_t n_tiles_stage1, n_tiles_stage2;
+    int32_t n_tiles_big;       /* of those, 128x128 macro tiles (the rest are 64x64)                      */
+    double  flops_alg_big;     /* part of flops_alg executed by the 128x128 kernel                        */
 } dmrgx_kron_info;
 
 dmrgx_status dmrgx_kron_plan_create(const dmrgx_kron_desc* desc, void* stream, dmrgx_kron_plan** out);
@@ -133,10 +135,21 @@ dmrgx_status dmrgx_kron_plan_info(const dmrgx_kron_plan* plan, dmrgx_kron_info* 
  * rank's segment of a full vector or at a separate buffer of local_len doubles.  world_size==1: y = H x. */
 dmrgx_status dmrgx_kron_apply(dmrgx_kron_plan* plan, const double* x_full, double* y_local, void* stream);
 dmrgx_status dmrgx_kron_plan_destroy(dmrgx_kron_plan* plan);
+/* Optional per-launch timing of the two GEMM stages with HIP events recorded on the apply's own stream
+ * (the reference's analogue is the -DDMRG_KRON_TIMINGS accumulators, include/MiscTools.hpp:17-59).
+ * enable != 0 resets and starts recording (up to 4096 applies), enable == 0 stops. */
+dmrgx_status dmrgx_kron_plan_timing(dmrgx_kron_plan* plan, int32_t enable);
+/* Synchronises the recorded events and returns the summed kernel time in milliseconds of the four GEMM launches
+ * of an apply: ms[0] stage-1 128x128 tiles, ms[1] stage-1 64x64 tiles, ms[2] stage-2 128x128, ms[3] stage-2 64x64. */
+dmrgx_status dmrgx_kron_plan_timing_read(dmrgx_kron_plan* plan, double* ms4, int64_t* n_applies);
 /* Convert between the reference's vector layout (KronBlocks order, n_states doubles, host or device) and the
  * striped full-vector layout (identity copy when world_size == 1). */
 dmrgx_status dmrgx_kron_vec_to_striped(const dmrgx_kron_plan* plan, const double* v_ref_dev, double* v_full_dev, void* stream);
 dmrgx_status dmrgx_kron_vec_from_striped(const dmrgx_kron_plan* plan, const double* v_full_dev, double* v_ref_dev, void* stream);
+
+/* Host-only helper (no device needed): columns [*c0, *c1) of a KronBlock whose right sector has n_right states
+ * belong to rank `rank` of `world_size` -- the stripe rule used by every plan. */
+dmrgx_status dmrgx_stripe_bounds(int32_t n_right, int32_t world_size, int32_t rank, int32_t* c0, int32_t* c1);
 
 /* ---- generic grouped f64 GEMM (used by K1/K3/K6; exposed for tests) ---------------------------------- */
 /* C[M x N] (row-major, ldc) = A[M x K] (row-major, lda) * B[K x N] (row-major, ldb), device pointers. */
@@ -150,6 +163,8 @@ typedef struct {
     double  tol;        /* converged when ||r|| <= tol * |theta|  (SLEPc default criterion, default 1e-8) */
     uint64_t seed;      /* start vector: counter-based uniform(-1,1) stream of this seed, unless ...      */
     int32_t use_initial; /* ... use_initial != 0: psi_full holds the start vector                         */
+    int32_t max_matvec;  /* > 0: stop after exactly this many MatMults (status DMRGX_ERR_NOTCONV unless converged
+                            earlier); used by benchmarks to time a fixed number of Lanczos steps               */
     /* collective hooks for world_size > 1 (NULL when world_size == 1).  They must be stream-ordered on
      * `stream`: allgather(sendbuf=this rank's segment, full vector) and allreduce_sum(buf, count). */
     dmrgx_status (*allgather)(void* user, double* full_vec, int64_t seg_stride, void* stream);

@@ -1,0 +1,90 @@
+"""CPU suite: the C-ABI library loads, exports every symbol include/dmrgx.h declares, refuses to compute without a
+GPU (no CPU fallback), and the host-side logic (workload generator, stripe layout incl. a world_size-2 gloo run)."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    hdr = open(os.path.join(ROOT, "include", "dmrgx.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(dmrgx_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"dmrgx_status"}
+    assert len(declared) >= 12
+    lib = pkg._capi.lib()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/dmrgx.h but not exported"
+    assert declared == set(pkg._capi.SIGNATURES), "ctypes binding out of sync with the header"
+    assert lib.dmrgx_abi_version() == 1
+
+
+def test_product_does_not_import_oracle():
+    """The product package must never route through the CPU oracle."""
+    for fn in os.listdir(os.path.join(ROOT, "dmrg.x_amd")):
+        if fn.endswith(".py"):
+            src = open(os.path.join(ROOT, "dmrg.x_amd", fn)).read()
+            assert "import oracle" not in src and "from oracle" not in src, fn
+    for fn in os.listdir(os.path.join(ROOT, "dmrg.x_amd", "csrc")):
+        if fn.endswith((".hip", ".h", ".cpp", ".hpp")):
+            assert "oracle" not in open(os.path.join(ROOT, "dmrg.x_amd", "csrc", fn)).read(), fn
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="only meaningful on a host without a GPU")
+def test_fails_loudly_without_gpu(pkg):
+    with pytest.raises(pkg._capi.DmrgxError) as ei:
+        pkg._capi.require_device()
+    assert ei.value.code == pkg._capi.DMRGX_ERR_DEVICE and "no CPU fallback" in str(ei.value)
+    from dmrgx_amd.superblock import KronPlan
+    from dmrgx_amd.workloads import synthetic_superblock
+    with pytest.raises(pkg._capi.DmrgxError):
+        KronPlan(synthetic_superblock("cfg1", m=4, Ly=1))
+
+
+def test_sector_profile_and_term_counts(pkg):
+    from dmrgx_amd import workloads as wl
+    assert list(wl.kept_profile(2048).values()) == [1, 9, 38, 113, 244, 388, 462, 388, 244, 113, 38, 9, 1]
+    sb = wl.synthetic_superblock("cfg4")
+    assert sum(sb.left_sizes) == 4096 and len(sb.terms) == 72 and len(sb.blocks) == 14
+    assert sb.n_states == sum(sb.left_sizes[a] * sb.right_sizes[b] for a, b in sb.blocks)
+    assert all(sb.left_qn[a] + sb.right_qn[b] == 0 for a, b in sb.blocks)
+    sb5 = wl.synthetic_superblock("cfg5", m=64)
+    assert len(sb5.terms) == 16            # XY: no Sz terms, no NNN (reference quirk)
+    x = np.random.default_rng(0).standard_normal(wl.synthetic_superblock("cfg2", m=16, Ly=2).n_states)
+    sb2 = wl.synthetic_superblock("cfg2", m=16, Ly=2)
+    H = np.stack([wl.apply_factored_numpy(sb2, e) for e in np.eye(sb2.n_states)], axis=1)
+    assert np.abs(H - H.T).max() < 1e-12 * np.abs(H).max()
+
+
+def test_stripe_bounds_partition(pkg):
+    import ctypes as C
+    lib = pkg._capi.lib()
+    for n in (0, 1, 5, 64, 850, 1693):
+        for W in (1, 2, 3, 8):
+            cuts = []
+            for r in range(W):
+                a, b = C.c_int32(), C.c_int32()
+                assert lib.dmrgx_stripe_bounds(n, W, r, C.byref(a), C.byref(b)) == 0
+                cuts.append((a.value, b.value))
+            assert cuts[0][0] == 0 and cuts[-1][1] == n
+            assert all(cuts[i][1] == cuts[i + 1][0] for i in range(W - 1))
+            assert max(b - a for a, b in cuts) - min(b - a for a, b in cuts) <= 1
+    a, b = C.c_int32(), C.c_int32()
+    assert lib.dmrgx_stripe_bounds(10, 2, 2, C.byref(a), C.byref(b)) == pkg._capi.DMRGX_ERR_ARG
+
+
+def test_world_size_2_striped_apply_over_gloo():
+    """N>1 path on CPU: two gloo ranks each compute their right-index stripe of y = H x (numpy, stripe rule from the
+    C ABI), all-gather the rank-major segments, and rank 0 checks the result against the unstriped apply."""
+    script = os.path.join(ROOT, "tests", "gloo_striped_worker.py")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29617", PYTHONPATH=ROOT)
+    procs = [subprocess.Popen([sys.executable, script, str(r), "2"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert "striped apply ok" in outs[0]
