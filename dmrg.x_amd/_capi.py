@@ -98,6 +98,9 @@ def lib():
     """Load libdmrgx_hip.so (built by `make` / __graft_entry__.build()).  Raises if absent: no fallback."""
     global _lib
     if _lib is None:
+        # torch ships its own HIP runtime (same SONAME as /opt/rocm's).  It must be the copy the process loads first,
+        # otherwise torch later finds "No HIP GPUs": import torch before dlopen-ing the kernel library.
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} not built: run `make` (hipcc --offload-arch=gfx950). "
                               "The dmrgx hot path has no CPU fallback.")
