@@ -87,6 +87,19 @@ SIGNATURES = {
     "dmrgx_stripe_bounds": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "dmrgx_dgemm_nn": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
                                    C.c_void_p, C.c_int64, C.c_void_p]),
+    "dmrgx_rdm_create": (C.c_int32, [C.POINTER(Sectors), C.POINTER(Sectors), C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                     C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "dmrgx_rdm_eigenvalues": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_double)]),
+    "dmrgx_rdm_eigenvectors": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
+    "dmrgx_rdm_info": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32)]),
+    "dmrgx_rdm_destroy": (C.c_int32, [C.c_void_p]),
+    "dmrgx_malloc": (C.c_int32, [C.POINTER(C.c_void_p), C.c_size_t]),
+    "dmrgx_free": (C.c_int32, [C.c_void_p]),
+    "dmrgx_memcpy_h2d": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "dmrgx_memcpy_d2h": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "dmrgx_memcpy_d2d": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "dmrgx_memset_zero": (C.c_int32, [C.c_void_p, C.c_size_t, C.c_void_p]),
+    "dmrgx_stream_sync": (C.c_int32, [C.c_void_p]),
     "dmrgx_eigs_lowest": (C.c_int32, [C.c_void_p, C.POINTER(EigsOpts), C.POINTER(C.c_double), C.c_void_p,
                                       C.POINTER(EigsStats), C.c_void_p]),
 }

@@ -63,3 +63,23 @@ extern "C" dmrgx_status dmrgx_dgemm_nn(int32_t M, int32_t N, int32_t K, const do
     DMRGX_HIP(hipStreamSynchronize(st));   // tables are freed on return
     return DMRGX_OK;
 }
+
+extern "C" dmrgx_status dmrgx_malloc(void** p, size_t bytes)
+{
+    if (!p) DMRGX_FAIL(DMRGX_ERR_ARG, "malloc: null argument");
+    *p = nullptr;
+    if (bytes == 0) return DMRGX_OK;
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) { *p = nullptr; DMRGX_FAIL(DMRGX_ERR_MEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); }
+    return DMRGX_OK;
+}
+extern "C" dmrgx_status dmrgx_free(void* p) { if (p) DMRGX_HIP(hipFree(p)); return DMRGX_OK; }
+extern "C" dmrgx_status dmrgx_memcpy_h2d(void* d, const void* s, size_t n, void* st)
+{ if (n) DMRGX_HIP(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, (hipStream_t)st)); return DMRGX_OK; }
+extern "C" dmrgx_status dmrgx_memcpy_d2h(void* d, const void* s, size_t n, void* st)
+{ if (n) { DMRGX_HIP(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, (hipStream_t)st)); DMRGX_HIP(hipStreamSynchronize((hipStream_t)st)); } return DMRGX_OK; }
+extern "C" dmrgx_status dmrgx_memcpy_d2d(void* d, const void* s, size_t n, void* st)
+{ if (n) DMRGX_HIP(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, (hipStream_t)st)); return DMRGX_OK; }
+extern "C" dmrgx_status dmrgx_memset_zero(void* d, size_t n, void* st)
+{ if (n) DMRGX_HIP(hipMemsetAsync(d, 0, n, (hipStream_t)st)); return DMRGX_OK; }
+extern "C" dmrgx_status dmrgx_stream_sync(void* st) { DMRGX_HIP(hipStreamSynchronize((hipStream_t)st)); return DMRGX_OK; }

@@ -168,3 +168,47 @@ def dgemm_nn(A, B, out=None):
     _capi.check(_capi.lib().dmrgx_dgemm_nn(M, N, K, C.c_void_p(A.data_ptr()), K, C.c_void_p(B.data_ptr()), N,
                                            C.c_void_p(out.data_ptr()), N, st))
     return out
+
+
+class ReducedDensityMatrices:
+    """Device RDM blocks + spectra of a superblock state (GetTruncation's rank-0 loop,
+    include/DMRGBlockContainer.hpp:1715-1775).  psi: device tensor in the reference's vector layout."""
+
+    def __init__(self, left_sizes, right_sizes, blocks, psi):
+        L = _capi.lib()
+        self.left_sizes, self.right_sizes, self.blocks = list(left_sizes), list(right_sizes), list(blocks)
+        ls, rs = _i32(left_sizes), _i32(right_sizes)
+        sl, sr = _capi.Sectors(len(left_sizes), ls), _capi.Sectors(len(right_sizes), rs)
+        bil, bir = _i32([b[0] for b in blocks]), _i32([b[1] for b in blocks])
+        self._handle = C.c_void_p()
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _capi.check(L.dmrgx_rdm_create(C.byref(sl), C.byref(sr), len(blocks), bil, bir, C.c_void_p(psi.data_ptr()), st, C.byref(self._handle)))
+        n = C.c_int32(0)
+        _capi.check(L.dmrgx_rdm_info(self._handle, C.byref(n)))
+        self.sweeps = n.value
+
+    def size(self, side, k):
+        return (self.left_sizes[self.blocks[k][0]], self.right_sizes[self.blocks[k][1]])[side]
+
+    def eigenvalues(self, side, k):
+        out = (C.c_double * self.size(side, k))()
+        _capi.check(_capi.lib().dmrgx_rdm_eigenvalues(self._handle, side, k, out))
+        return np.array(out)
+
+    def eigenvectors(self, side, k, count):
+        n = self.size(side, k)
+        dst = torch.empty((count, n), dtype=torch.float64, device="cuda")
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _capi.check(_capi.lib().dmrgx_rdm_eigenvectors(self._handle, side, k, count, C.c_void_p(dst.data_ptr()), n, st))
+        return dst
+
+    def destroy(self):
+        if self._handle:
+            _capi.check(_capi.lib().dmrgx_rdm_destroy(self._handle))
+            self._handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass

@@ -183,6 +183,32 @@ typedef struct {
 dmrgx_status dmrgx_eigs_lowest(dmrgx_kron_plan* plan, const dmrgx_eigs_opts* opts, double* e0,
                                double* psi_full, dmrgx_eigs_stats* stats, void* stream);
 
+/* ---- K3/K4: reduced density matrices + full spectra ------------------------------------------------------ */
+/* For every KronBlock k of the layout: rho_L = Psi Psi^T, rho_R = Psi^T Psi (Psi = n_L x n_R row-major slice of
+ * psi_dev in the reference's vector layout) and ALL eigenpairs of each, largest first -- the device part of
+ * GetTruncation / EigRDM_BlockDiag (include/DMRGBlockContainer.hpp:1715-1775, 1962-2003).  The global sort, the
+ * m-cut and the sector bookkeeping (:1795, 1850-1892) stay with the caller. side: 0 = left (rho_L), 1 = right. */
+typedef struct dmrgx_rdm dmrgx_rdm;
+dmrgx_status dmrgx_rdm_create(const dmrgx_sectors* left, const dmrgx_sectors* right, int32_t nblocks,
+                              const int32_t* block_il, const int32_t* block_ir, const double* psi_dev,
+                              void* stream, dmrgx_rdm** out);
+/* host_out[0..n) = eigenvalues of block k's matrix, descending (n = sector size on that side). */
+dmrgx_status dmrgx_rdm_eigenvalues(const dmrgx_rdm* rdm, int32_t side, int32_t k, double* host_out);
+/* dst_dev[r*ld + i], r < count: the eigenvector of the r-th largest eigenvalue as a ROW (a row of RotMatT,
+ * == FillRotation_BlockDiag, include/DMRGBlockContainer.hpp:2032-2054). */
+dmrgx_status dmrgx_rdm_eigenvectors(const dmrgx_rdm* rdm, int32_t side, int32_t k, int32_t count, double* dst_dev, int64_t ld, void* stream);
+dmrgx_status dmrgx_rdm_info(const dmrgx_rdm* rdm, int32_t* n_sweeps);
+dmrgx_status dmrgx_rdm_destroy(dmrgx_rdm* rdm);
+
+/* ---- device memory (so that the host engine needs no HIP headers) ------------------------------------------ */
+dmrgx_status dmrgx_malloc(void** dev_ptr, size_t bytes);
+dmrgx_status dmrgx_free(void* dev_ptr);
+dmrgx_status dmrgx_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes, void* stream);
+dmrgx_status dmrgx_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes, void* stream);   /* synchronises the stream */
+dmrgx_status dmrgx_memcpy_d2d(void* dst_dev, const void* src_dev, size_t bytes, void* stream);
+dmrgx_status dmrgx_memset_zero(void* dst_dev, size_t bytes, void* stream);
+dmrgx_status dmrgx_stream_sync(void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -162,3 +162,35 @@ def test_bad_descriptor_is_rejected_with_reference_codes(mods):
     with pytest.raises(capi.DmrgxError) as ei:
         sbm.KronPlan(sb)
     assert ei.value.code == capi.DMRGX_ERR_OUTOFRANGE
+
+
+@pytest.mark.parametrize("sizes", [([3, 5], [4, 2]), ([70, 1, 33], [20, 64, 65]), ([130, 40], [90, 200])])
+def test_rdm_spectra_and_eigenvectors_vs_lapack(mods, sizes):
+    """K3/K4 vs numpy (LAPACK, as the reference's EPSLAPACK): eigenvalues of Psi Psi^T / Psi^T Psi, orthonormal
+    eigenvector rows that diagonalise the block (eigenvectors are compared through invariants, their phases and
+    the basis inside degenerate/null spaces are not pinned by the reference)."""
+    sbm, _, _ = mods
+    ls, rs = sizes
+    blocks = [(i, len(rs) - 1 - i) for i in range(min(len(ls), len(rs)))]
+    rng = np.random.default_rng(sum(ls))
+    psi = rng.standard_normal(sum(ls[a] * rs[b] for a, b in blocks))
+    psi /= np.linalg.norm(psi)
+    rdm = sbm.ReducedDensityMatrices(ls, rs, blocks, torch.from_numpy(psi).cuda())
+    off = 0
+    tot = [0.0, 0.0]
+    for k, (a, b) in enumerate(blocks):
+        Psi = psi[off:off + ls[a] * rs[b]].reshape(ls[a], rs[b])
+        off += ls[a] * rs[b]
+        for side, rho in ((0, Psi @ Psi.T), (1, Psi.T @ Psi)):
+            w_ref = np.linalg.eigvalsh(rho)[::-1]
+            w = rdm.eigenvalues(side, k)
+            n = rho.shape[0]
+            assert np.abs(w - w_ref).max() <= 3e-15 * n * np.abs(w_ref).max() + 1e-17      # backward-stable level: c*n*eps*||rho||
+            assert np.all(np.diff(w) <= 0)
+            n = rho.shape[0]
+            U = rdm.eigenvectors(side, k, n).cpu().numpy()          # rows = eigenvectors
+            assert np.abs(U @ U.T - np.eye(n)).max() < 1e-13
+            assert np.abs(U @ rho @ U.T - np.diag(w)).max() < 3e-15 * n * np.abs(w).max() + 1e-16
+            tot[side] += w.sum()
+    assert abs(tot[0] - 1.0) < 1e-13 and abs(tot[1] - 1.0) < 1e-13      # Tr rho = <psi|psi>
+    rdm.destroy()
