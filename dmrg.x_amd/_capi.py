@@ -57,6 +57,15 @@ class KronInfo(C.Structure):
                 ("n_tiles_big", C.c_int32), ("flops_alg_big", C.c_double)]
 
 
+class AxpyTask(C.Structure):
+    _fields_ = [("dst", C.c_void_p), ("dst_base", C.c_void_p), ("src", C.c_void_p), ("ldd", C.c_int64), ("lds", C.c_int64),
+                ("nr", C.c_int32), ("nc", C.c_int32), ("transposed", C.c_int32), ("alpha", C.c_double)]
+
+
+class Rotation(C.Structure):
+    _fields_ = [("n_new", C.c_int32), ("old_sector", C.POINTER(C.c_int32)), ("kept", C.POINTER(C.c_int32)), ("rot_t", C.POINTER(C.c_void_p))]
+
+
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
 
@@ -93,6 +102,8 @@ SIGNATURES = {
     "dmrgx_rdm_eigenvectors": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
     "dmrgx_rdm_info": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32)]),
     "dmrgx_rdm_destroy": (C.c_int32, [C.c_void_p]),
+    "dmrgx_cells_axpy": (C.c_int32, [C.c_int32, C.POINTER(AxpyTask), C.c_void_p]),
+    "dmrgx_rotate_ops": (C.c_int32, [C.POINTER(Sectors), C.POINTER(Rotation), C.c_int32, C.POINTER(SecOp), C.POINTER(C.POINTER(C.c_void_p)), C.c_void_p]),
     "dmrgx_malloc": (C.c_int32, [C.POINTER(C.c_void_p), C.c_size_t]),
     "dmrgx_free": (C.c_int32, [C.c_void_p]),
     "dmrgx_memcpy_h2d": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

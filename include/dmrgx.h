@@ -200,6 +200,31 @@ dmrgx_status dmrgx_rdm_eigenvectors(const dmrgx_rdm* rdm, int32_t side, int32_t 
 dmrgx_status dmrgx_rdm_info(const dmrgx_rdm* rdm, int32_t* n_sweeps);
 dmrgx_status dmrgx_rdm_destroy(dmrgx_rdm* rdm);
 
+/* ---- K6: operator rotation + dense-cell accumulate ------------------------------------------------------------ */
+/* dst[i*ldd + j] += alpha * src(i,j), src(i,j) = src[i*lds + j] or (transposed) src[j*lds + i]; nr x nc is the shape of
+ * the DESTINATION rectangle.  Tasks whose destinations may overlap must carry the same dst_base (e.g. the owning
+ * sector block): they are then applied in submission order; dst_base == NULL means "no overlap with other tasks". */
+typedef struct {
+    double* dst; const double* dst_base; const double* src;
+    int64_t ldd, lds; int32_t nr, nc; int32_t transposed; double alpha;
+} dmrgx_axpy_task;
+dmrgx_status dmrgx_cells_axpy(int32_t ntasks, const dmrgx_axpy_task* tasks, void* stream);
+
+/* Truncation as a block rotation: new sector a keeps kept[a] states of old sector old_sector[a] (ascending), rows of
+ * RotMatT for it are rot_t[a] (kept[a] x n_old, row-major, ld = n_old; device) -- include/DMRGBlockContainer.hpp:2032-2054. */
+typedef struct {
+    int32_t n_new;
+    const int32_t* old_sector;
+    const int32_t* kept;
+    const double* const* rot_t;
+} dmrgx_rotation;
+/* For every source operator o (cells in the OLD sector basis): dst_blocks[o][a] <- RT_a . O_{q -> q+shift} . RT_a'^T with
+ * q = old_sector[a] and a' the new sector cut from old sector q+shift; dst_blocks[o][a] is a caller-allocated dense
+ * kept[a] x kept[a'] row-major block (ignored / may be NULL when a' does not exist).  == RotateOperators
+ * (src/DMRGBlock.cpp:763-772) for Sz(i), Sp(i) and H at once. */
+dmrgx_status dmrgx_rotate_ops(const dmrgx_sectors* old_sectors, const dmrgx_rotation* rot, int32_t nops,
+                              const dmrgx_secop* src_ops, double* const* const* dst_blocks, void* stream);
+
 /* ---- device memory (so that the host engine needs no HIP headers) ------------------------------------------ */
 dmrgx_status dmrgx_malloc(void** dev_ptr, size_t bytes);
 dmrgx_status dmrgx_free(void* dev_ptr);

@@ -194,3 +194,98 @@ def test_rdm_spectra_and_eigenvectors_vs_lapack(mods, sizes):
             tot[side] += w.sum()
     assert abs(tot[0] - 1.0) < 1e-13 and abs(tot[1] - 1.0) < 1e-13      # Tr rho = <psi|psi>
     rdm.destroy()
+
+
+def _secop_from(op, keep):
+    """ctypes dmrgx_secop for a workloads.SectorOperator; device tensors appended to `keep`."""
+    import ctypes as C
+    from dmrgx_amd import _capi
+    cells = (_capi.Cell * max(len(op.cells), 1))()
+    for i, c in enumerate(op.cells):
+        cells[i].row_sector, cells[i].r0, cells[i].c0, cells[i].nr, cells[i].nc, cells[i].kind, cells[i].scale = c.row_sector, c.r0, c.c0, c.nr, c.nc, c.kind, c.scale
+        if c.kind == 1:
+            t = torch.from_numpy(np.ascontiguousarray(c.array)).cuda()
+            keep.append(t)
+            cells[i].data, cells[i].ld = t.data_ptr(), c.nc
+    keep.append(cells)
+    s = _capi.SecOp()
+    s.shift, s.transposed, s.ncells, s.cells = op.shift, 0, len(op.cells), cells
+    return s
+
+
+def test_rotate_ops_vs_numpy(mods):
+    """K6 vs numpy: O' = RotMatT . O . RotMat (src/DMRGBlock.cpp:766-771) for Sz-, Sp- and H-type operators with
+    structurally sparse cells, an identity cell, and a sector dropped by the truncation."""
+    import ctypes as C
+    sbm, wl, capi = mods
+    rng = np.random.default_rng(5)
+    sizes = [5, 70, 33, 8, 130]
+    sub = [(2, 3), (40, 30), (33, 0), (0, 8), (65, 65)]
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    ops = [wl._old_site_op(rng, 0, sizes, sub), wl._old_site_op(rng, +1, sizes, sub), wl._sym_block_op(rng, sizes)]
+    ident = wl.SectorOperator(+1, [wl.OpCell(1, 40, 0, 30, 30, wl.CELL_IDENT, 0.75), wl.OpCell(0, 0, 10, 5, 5, wl.CELL_DENSE, 0.0, rng.standard_normal((5, 5)))])
+    ops.append(ident)
+    old_sector, kept = [0, 1, 3, 4], [3, 41, 8, 70]           # old sector 2 is truncated away entirely
+    RT = [rng.standard_normal((m, sizes[q])) for q, m in zip(old_sector, kept)]
+    keep = []
+    rt_dev = [torch.from_numpy(r).cuda() for r in RT]
+    secops = (capi.SecOp * len(ops))(*[_secop_from(o, keep) for o in ops])
+    new_of_old = {q: a for a, q in enumerate(old_sector)}
+    dst, dst_arrays = [], []
+    for o in ops:
+        row = (C.c_void_p * len(old_sector))()
+        blocks = []
+        for a, q in enumerate(old_sector):
+            ap = new_of_old.get(q + o.shift)
+            if ap is None:
+                blocks.append(None)
+                continue
+            t = torch.full((kept[a], kept[ap]), float("nan"), dtype=torch.float64, device="cuda")
+            blocks.append(t)
+            row[a] = t.data_ptr()
+        dst.append(blocks)
+        dst_arrays.append(row)
+    dst_pp = (C.POINTER(C.c_void_p) * len(ops))(*[C.cast(r, C.POINTER(C.c_void_p)) for r in dst_arrays])
+    sizes_c = (C.c_int32 * len(sizes))(*sizes)
+    sec = capi.Sectors(len(sizes), sizes_c)
+    rot = capi.Rotation()
+    osec, kp = (C.c_int32 * 4)(*old_sector), (C.c_int32 * 4)(*kept)
+    rts = (C.c_void_p * 4)(*[t.data_ptr() for t in rt_dev])
+    rot.n_new, rot.old_sector, rot.kept, rot.rot_t = 4, osec, kp, rts
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    capi.check(capi.lib().dmrgx_rotate_ops(C.byref(sec), C.byref(rot), len(ops), secops, dst_pp, st))
+    torch.cuda.synchronize()
+    for o, blocks in zip(ops, dst):
+        dense = wl.operator_to_dense_blocks(o, sizes)
+        for a, q in enumerate(old_sector):
+            ap = new_of_old.get(q + o.shift)
+            if ap is None:
+                continue
+            blk = dense.get(q, np.zeros((sizes[q], sizes[q + o.shift])))
+            ref = RT[a] @ blk @ RT[ap].T
+            got = blocks[a].cpu().numpy()
+            assert np.abs(got - ref).max() <= 1e-13 * max(1.0, np.abs(ref).max()), (o.shift, a)
+
+
+def test_cells_axpy_vs_numpy(mods):
+    """Dense-cell accumulate (plain and transposed, overlapping destinations applied in order) vs numpy."""
+    import ctypes as C
+    sbm, wl, capi = mods
+    rng = np.random.default_rng(9)
+    D = rng.standard_normal((90, 75))
+    A, B, Cm = rng.standard_normal((40, 33)), rng.standard_normal((33, 40)), rng.standard_normal((90, 75))
+    Dd, Ad, Bd, Cd = [torch.from_numpy(x.copy()).cuda() for x in (D, A, B, Cm)]
+    tasks = (capi.AxpyTask * 3)()
+    base = Dd.data_ptr()
+    def fill(t, dst_off, src, lds, nr, nc, tr, alpha):
+        t.dst, t.dst_base, t.src, t.ldd, t.lds, t.nr, t.nc, t.transposed, t.alpha = base + 8 * dst_off, base, src, 75, lds, nr, nc, tr, alpha
+    fill(tasks[0], 5 * 75 + 7, Ad.data_ptr(), 33, 40, 33, 0, 2.0)           # D[5:45, 7:40] += 2 A
+    fill(tasks[1], 5 * 75 + 7, Bd.data_ptr(), 40, 40, 33, 1, -0.5)          # D[5:45, 7:40] += -0.5 B^T (same destination)
+    fill(tasks[2], 0, Cd.data_ptr(), 75, 90, 75, 0, 1.0)                    # D += C (overlaps both)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    capi.check(capi.lib().dmrgx_cells_axpy(3, tasks, st))
+    torch.cuda.synchronize()
+    ref = D.copy()
+    ref[5:45, 7:40] += 2.0 * A - 0.5 * B.T
+    ref += Cm
+    assert np.abs(Dd.cpu().numpy() - ref).max() < 1e-14
