@@ -8,7 +8,10 @@ HIPFLAGS   := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude -I$(CSRC) -W
 HIP_SRCS   := $(CSRC)/lib.hip $(CSRC)/ggemm.hip $(CSRC)/kron_plan.hip $(CSRC)/eigs.hip $(CSRC)/rdm.hip $(CSRC)/rotate.hip
 HIP_OBJS   := $(HIP_SRCS:.hip=.o)
 
-all: $(PKG)/libdmrgx_hip.so oracle/liboracle_kron.so
+HOST       := $(PKG)/host
+HOST_HDRS  := $(wildcard $(HOST)/*.hpp) include/dmrgx.h
+
+all: $(PKG)/libdmrgx_hip.so $(PKG)/dmrgx-square-lattice oracle/liboracle_kron.so
 
 $(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/ggemm.h include/dmrgx.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
@@ -16,11 +19,19 @@ $(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/ggemm.h include/dmrgx.h
 $(PKG)/libdmrgx_hip.so: $(HIP_OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(HIP_OBJS) -o $@
 
+# host sweep engine (plain C++17 over the C ABI: no HIP headers needed)
+$(PKG)/dmrgx-square-lattice: $(HOST)/DMRG-SquareLattice.cpp $(HOST_HDRS) $(PKG)/libdmrgx_hip.so
+	g++ -std=c++17 -O2 -Wall -Wno-unused-variable -Iinclude -I$(HOST) $< -L$(PKG) -ldmrgx_hip -Wl,-rpath,'$$ORIGIN' -o $@
+
+# the reference's own driver source must compile against these headers (only where the reference tree is present)
+dropin-check:
+	g++ -std=c++17 -fsyntax-only -Iinclude -I$(HOST) /root/reference/src/DMRG-SquareLattice.cpp && echo "drop-in OK: reference src/DMRG-SquareLattice.cpp compiles against dmrg.x_amd/host headers"
+
 # x86-64-v3 (AVX2/FMA), not -march=native: the .so is built here and travels to the GPU host
 oracle/liboracle_kron.so: oracle/kron_ref.c
 	gcc -O3 -march=x86-64-v3 -fopenmp -shared -fPIC $< -o $@
 
 clean:
-	rm -f $(HIP_OBJS) $(PKG)/libdmrgx_hip.so oracle/liboracle_kron.so
+	rm -f $(HIP_OBJS) $(PKG)/libdmrgx_hip.so $(PKG)/dmrgx-square-lattice oracle/liboracle_kron.so
 
-.PHONY: all clean
+.PHONY: all clean dropin-check

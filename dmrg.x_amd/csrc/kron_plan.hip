@@ -424,35 +424,48 @@ extern "C" dmrgx_status dmrgx_kron_plan_create(const dmrgx_kron_desc* d, void* s
 
     // ---- task tables ---------------------------------------------------------------------------------------
     Builder B;
-    // stage 1:  T[:, cols] = X_src[:, krange] * cellT   for every transposed right cell of the block (IR -> IR')
+    // stage 1:  T[:, cols] = sum over the transposed right cells of block (IR -> IR') that reach those columns of
+    //           X_src[:, contraction range of the cell] * cellT.  A merged right operator may hold several cells with the
+    //           same output columns (e.g. O (x) 1 cell (2,2) and the new site's identity cell (2,1)), so groups are built
+    //           per output-column SEGMENT with a product list -- never one overwriting group per cell.
     auto stage1 = [&](const std::vector<PCell>& cellsT, int32_t sB, int32_t k, int32_t ksrc, int64_t toff) {
+        (void)sB;
         const int32_t ir = d->block_ir[k], cs = cb(k, me), ce = cb(k, me + 1), w = ce - cs;
         if (w <= 0) return;
         const int32_t M = nLk(ksrc);
+        std::set<int32_t> cuts = {cs, ce};
+        auto clampc = [&](int32_t v) { return std::min(std::max(v, cs), ce); };
         for (const PCell& c : cellsT) {
-            if (c.q != ir) continue;                         // cell of block (ir -> ir+sB), stored transposed:
-            const int32_t o0 = std::max(c.c0, cs), o1 = std::min(c.c0 + c.nc, ce);   // output columns (index in sector ir)
+            if (c.q != ir) continue;
+            cuts.insert(clampc(c.c0)); cuts.insert(clampc(c.c0 + c.nc));
+            if (c.kind == DMRGX_CELL_IDENT)        // a scaled copy must read ONE source panel: cut at panel borders too
+                for (int32_t p = 1; p < W; ++p) { const int32_t sc = cb(ksrc, p); if (sc > c.r0 && sc < c.r0 + c.nr) cuts.insert(clampc(c.c0 + (sc - c.r0))); }
+        }
+        std::vector<int32_t> cv(cuts.begin(), cuts.end());
+        for (size_t s = 0; s + 1 < cv.size(); ++s) {
+            const int32_t o0 = cv[s], o1 = cv[s + 1];
             if (o0 >= o1) continue;
-            (void)sB;
-            if (c.kind == DMRGX_CELL_DENSE) {
-                const int32_t g = B.open(BASE_ARENA, toff + (o0 - cs), w, M, o1 - o0, 0);
-                for (int32_t p = 0; p < W; ++p) {            // contraction index r' in [c.r0, c.r0+c.nr) split over source panels
-                    const int32_t k0 = std::max(c.r0, cb(ksrc, p)), k1 = std::min(c.r0 + c.nr, cb(ksrc, p + 1));
-                    if (k0 >= k1) continue;
-                    B.add_gemm(BASE_X, panel_off(ksrc, p) + (k0 - cb(ksrc, p)), panel_ld(ksrc, p),
-                               BASE_ARENA, c.off + (int64_t)(k0 - c.r0) * c.nc + (o0 - c.c0), c.nc, k1 - k0);
-                }
-                B.close(g, 1);
-            } else {                                         // identity cell: T[:, c] = scale * X_src[:, r0 + (c - c0)]
-                for (int32_t p = 0; p < W; ++p) {
-                    const int32_t s0 = std::max(c.r0 + (o0 - c.c0), cb(ksrc, p)), s1 = std::min(c.r0 + (o1 - c.c0), cb(ksrc, p + 1));
-                    if (s0 >= s1) continue;
-                    const int32_t oc = c.c0 + (s0 - c.r0);
-                    const int32_t g = B.open(BASE_ARENA, toff + (oc - cs), w, M, s1 - s0, 0);
+            bool any = false;
+            for (const PCell& c : cellsT) if (c.q == ir && c.c0 <= o0 && c.c0 + c.nc >= o1) { any = true; break; }
+            if (!any) continue;                                  // T is zero there (arena memset at plan creation)
+            const int32_t g = B.open(BASE_ARENA, toff + (o0 - cs), w, M, o1 - o0, 0);
+            for (const PCell& c : cellsT) {
+                if (c.q != ir || c.c0 > o0 || c.c0 + c.nc < o1) continue;
+                if (c.kind == DMRGX_CELL_DENSE) {
+                    for (int32_t p = 0; p < W; ++p) {            // contraction index r' in [c.r0, c.r0+c.nr) split over source panels
+                        const int32_t k0 = std::max(c.r0, cb(ksrc, p)), k1 = std::min(c.r0 + c.nr, cb(ksrc, p + 1));
+                        if (k0 >= k1) continue;
+                        B.add_gemm(BASE_X, panel_off(ksrc, p) + (k0 - cb(ksrc, p)), panel_ld(ksrc, p),
+                                   BASE_ARENA, c.off + (int64_t)(k0 - c.r0) * c.nc + (o0 - c.c0), c.nc, k1 - k0);
+                    }
+                } else {                                         // identity cell: T[:, o] += scale * X_src[:, c.r0 + (o - c.c0)]
+                    const int32_t s0 = c.r0 + (o0 - c.c0);
+                    int32_t p = 0;
+                    while (p + 1 < W && cb(ksrc, p + 1) <= s0) ++p;
                     B.add_axpy(BASE_X, panel_off(ksrc, p) + (s0 - cb(ksrc, p)), panel_ld(ksrc, p), c.scale);
-                    B.close(g, 1);
                 }
             }
+            B.close(g, 1);
         }
     };
     for (size_t g = 0; g < G.size(); ++g)

@@ -30,7 +30,13 @@ __global__ void __launch_bounds__(256) cells_axpy_kernel(const AxTile* __restric
     const AxTask k = tasks[t.task];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int i0 = t.ti * 32, j0 = t.tj * 32;
-    if (!k.tr) {
+    if (!k.src) {                       // identity source: dst += alpha * I
+        if (t.ti == t.tj)
+            for (int r = ty; r < 32; r += 8) {
+                const int i = i0 + r, j = j0 + tx;
+                if (i == j && i < k.nr && j < k.nc) k.dst[(size_t)i * k.ldd + j] += k.alpha;
+            }
+    } else if (!k.tr) {
         for (int r = ty; r < 32; r += 8) {
             const int i = i0 + r, j = j0 + tx;
             if (i < k.nr && j < k.nc) k.dst[(size_t)i * k.ldd + j] += k.alpha * k.src[(size_t)i * k.lds + j];
@@ -65,7 +71,7 @@ extern "C" dmrgx_status dmrgx_cells_axpy(int32_t n, const dmrgx_axpy_task* tasks
     int32_t max_round = 0;
     for (int32_t i = 0; i < n; ++i) {
         const dmrgx_axpy_task& t = tasks[i];
-        if (!t.dst || !t.src || t.nr <= 0 || t.nc <= 0 || t.ldd < t.nc || t.lds < (t.transposed ? t.nr : t.nc))
+        if (!t.dst || t.nr <= 0 || t.nc <= 0 || t.ldd < t.nc || (t.src && t.lds < (t.transposed ? t.nr : t.nc)) || (!t.src && t.nr != t.nc))
             DMRGX_FAIL(DMRGX_ERR_ARG, "cells_axpy: task %d malformed", i);
         ht[i] = AxTask{t.dst, t.src, t.ldd, t.lds, t.nr, t.nc, t.transposed ? 1 : 0, 0, t.alpha};
         // conservative overlap rule: tasks sharing a destination base pointer are serialised

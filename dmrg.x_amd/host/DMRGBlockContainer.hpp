@@ -1,0 +1,519 @@
+/** @file DMRGBlockContainer.hpp
+    DMRGBlockContainer<Block, Hamiltonian>: warm-up, sweeps and the single DMRG step, with the public interface, the
+    option names, the block-index schedule and the truncation rules of the reference orchestrator (reference
+    include/DMRGBlockContainer.hpp:166-2777) so that src/DMRG-SquareLattice.cpp compiles on top of it unchanged.
+    What a step does here:
+
+        enlarge   KronEye_Explicit            cell views + device H assembly              (host metadata, HBM data)
+        build H   KronBlocks.KronSumConstruct dmrgx_kron_plan_create                      (matrix-free, MFMA GEMMs)
+        solve     dmrgx_eigs_lowest           thick-restart Lanczos, psi stays in HBM     (replaces SLEPc EPSSolve)
+        truncate  GetTruncation               dmrgx_rdm_create (RDMs + block Jacobi), host sort / m-cut / sector re-sort
+        rotate    Block::RotateOperators      dmrgx_rotate_ops, all operators in one call
+
+    The eigensolver is configured with the reference's option prefix: -H_eps_tol, -H_eps_ncv, -H_eps_max_it.
+    DMRGSteps.json / Timings.json keep the reference's tabular schema (Timings.json gains a MatMults column). */
+#ifndef DMRGX_DMRGBLOCKCONTAINER_HPP
+#define DMRGX_DMRGBLOCKCONTAINER_HPP
+
+#include <algorithm>
+#include <cmath>
+#include <iomanip>
+#include <iostream>
+#include <map>
+#include <set>
+#include <string>
+#include <vector>
+#include "DMRGKron.hpp"
+
+/** One eigenpair of a reduced-density-matrix block */
+struct Eigen_t
+{
+    PetscScalar eigval;  /**< eigenvalue */
+    PetscInt    seqIdx;  /**< KronBlock the matrix belongs to */
+    PetscInt    epsIdx;  /**< rank inside that block's spectrum (0 = largest) */
+    PetscInt    blkIdx;  /**< sector index in the block's Magnetization */
+};
+inline bool greater_eigval(const Eigen_t& a, const Eigen_t& b) { return a.eigval > b.eigval; }
+inline bool less_blkIdx(const Eigen_t& a, const Eigen_t& b) { return a.blkIdx < b.blkIdx; }
+
+/** An operator of a measurement */
+struct Op {
+    Op_t     OpType;
+    PetscInt idx;
+    PetscErrorCode PrintInfo() const { std::cout << "  Op" << OpToStr(OpType) << idx << std::endl; return 0; }
+};
+
+template<class Block, class Hamiltonian> class DMRGBlockContainer
+{
+public:
+    /** Result of the truncation of one side */
+    struct BasisTransformation
+    {
+        Mat RotMatT;            /**< rotation matrix (sector-block rows of kept eigenvectors) */
+        QuantumNumbers QN;      /**< sectors of the truncated block */
+        PetscReal TruncErr = 0; /**< 1 - sum of kept (positive) eigenvalues */
+    };
+
+    explicit DMRGBlockContainer(const MPI_Comm& mpi_comm) : mpi_comm(mpi_comm) {}
+    ~DMRGBlockContainer() { PetscErrorCode ierr = Destroy(); CPP_CHKERR(ierr); }
+
+    PetscErrorCode Initialize()
+    {
+        if (init) SETERRQ(mpi_comm, 1, "DMRG object has already been initialized.");
+        PetscErrorCode ierr;
+        char path[PETSC_MAX_PATH_LEN];
+        ierr = MPI_Comm_size(mpi_comm, &mpi_size); CHKERRQ(ierr);
+        ierr = MPI_Comm_rank(mpi_comm, &mpi_rank); CHKERRQ(ierr);
+        ierr = Ham.SetFromOptions(); CHKERRQ(ierr);
+        ierr = SingleSite.Initialize(mpi_comm, 1, PETSC_DEFAULT); CHKERRQ(ierr);
+        num_sites = Ham.NumSites();
+        if (num_sites < 2) SETERRQ1(mpi_comm, 1, "There must be at least two total sites. Got %lld.", LLD(num_sites));
+        if (num_sites % 2) SETERRQ1(mpi_comm, 1, "Total number of sites must be even. Got %lld.", LLD(num_sites));
+        ierr = PetscOptionsGetBool(NULL, NULL, "-verbose", &verbose, NULL); CHKERRQ(ierr);
+        ierr = PetscOptionsGetBool(NULL, NULL, "-no_symm", &no_symm, NULL); CHKERRQ(ierr);
+        ierr = PetscOptionsGetBool(NULL, NULL, "-do_shell", &do_shell, NULL); CHKERRQ(ierr);
+        ierr = PetscOptionsGetBool(NULL, NULL, "-dry_run", &dry_run, NULL); CHKERRQ(ierr);
+        ierr = PetscOptionsGetReal(NULL, NULL, "-qn_sector", &qn_sector, NULL); CHKERRQ(ierr);
+        ierr = PetscOptionsGetReal(NULL, NULL, "-H_eps_tol", &eps_tol, NULL); CHKERRQ(ierr);
+        ierr = PetscOptionsGetInt(NULL, NULL, "-H_eps_ncv", &eps_ncv, NULL); CHKERRQ(ierr);
+        ierr = PetscOptionsGetInt(NULL, NULL, "-H_eps_max_it", &eps_max_it, NULL); CHKERRQ(ierr);
+        if (no_symm) SETERRQ(mpi_comm, PETSC_ERR_SUP, "Unsupported option: no_symm.");
+        ierr = PetscOptionsGetBool(NULL, NULL, "-debug_check_symmetry", &debug_symm, NULL); CHKERRQ(ierr);
+
+        PetscBool opt = PETSC_FALSE;
+        ierr = PetscOptionsGetString(NULL, NULL, "-scratch_dir", path, PETSC_MAX_PATH_LEN, &opt); CHKERRQ(ierr);
+        scratch_dir = opt ? std::string(path) : std::string("./scratch_dir/");
+        if (scratch_dir.back() != '/') scratch_dir += '/';
+        ierr = PetscOptionsGetString(NULL, NULL, "-data_dir", path, PETSC_MAX_PATH_LEN, &opt); CHKERRQ(ierr);
+        data_dir = opt ? std::string(path) : std::string("./data_dir/");
+        if (data_dir.back() != '/') data_dir += '/';
+        if (!mpi_rank) { ierr = Makedir(data_dir); CHKERRQ(ierr); }
+        ierr = PetscFOpen(mpi_comm, (data_dir + "DMRGSteps.json").c_str(), "w", &fp_step); CHKERRQ(ierr);
+        ierr = SaveStepHeaders(); CHKERRQ(ierr);
+        fprintf(fp_step, "[\n");
+        ierr = PetscFOpen(mpi_comm, (data_dir + "Timings.json").c_str(), "w", &fp_timings); CHKERRQ(ierr);
+        ierr = SaveTimingsHeaders(); CHKERRQ(ierr);
+        fprintf(fp_timings, "[\n");
+        ierr = PetscFOpen(mpi_comm, (data_dir + "EntanglementSpectra.json").c_str(), "w", &fp_entanglement); CHKERRQ(ierr);
+        fprintf(fp_entanglement, "[\n");
+        ierr = PetscFOpen(mpi_comm, (data_dir + "DMRGRun.json").c_str(), "w", &fp_data); CHKERRQ(ierr);
+        fprintf(fp_data, "{\n"); Ham.SaveOut(fp_data); fprintf(fp_data, ",\n  \"QNSector\": %g", qn_sector); fflush(fp_data);
+
+        if (!mpi_rank) {
+            printf("=========================================\nDENSITY MATRIX RENORMALIZATION GROUP (MI355X engine)\n-----------------------------------------\n");
+            Ham.PrintOut();
+            printf("-----------------------------------------\nDIRECTORIES\n  Data:    %s\n=========================================\n", data_dir.c_str());
+        }
+        {   /* sweep modes: -nsweeps | -msweeps [-maxnsweeps] */
+            PetscBool opt_mstates = PETSC_FALSE, opt_mwarmup = PETSC_FALSE, opt_nsweeps = PETSC_FALSE, opt_msweeps = PETSC_FALSE, opt_maxnsweeps = PETSC_FALSE;
+            PetscInt mstates = 0, num_msweeps = 1000, num_maxnsweeps = 1000;
+            msweeps.resize(num_msweeps); maxnsweeps.resize(num_maxnsweeps);
+            ierr = PetscOptionsGetInt(NULL, NULL, "-mstates", &mstates, &opt_mstates); CHKERRQ(ierr);
+            ierr = PetscOptionsGetInt(NULL, NULL, "-mwarmup", &mwarmup, &opt_mwarmup); CHKERRQ(ierr);
+            ierr = PetscOptionsGetInt(NULL, NULL, "-nsweeps", &nsweeps, &opt_nsweeps); CHKERRQ(ierr);
+            ierr = PetscOptionsGetIntArray(NULL, NULL, "-msweeps", msweeps.data(), &num_msweeps, &opt_msweeps); CHKERRQ(ierr);
+            msweeps.resize(num_msweeps);
+            ierr = PetscOptionsGetIntArray(NULL, NULL, "-maxnsweeps", maxnsweeps.data(), &num_maxnsweeps, &opt_maxnsweeps); CHKERRQ(ierr);
+            maxnsweeps.resize(num_maxnsweeps);
+            if (opt_mstates && !opt_mwarmup) mwarmup = mstates;
+            if (opt_nsweeps && opt_msweeps) SETERRQ(mpi_comm, 1, "-msweeps and -nsweeps cannot both be specified at the same time.");
+            if (opt_maxnsweeps && (num_maxnsweeps != num_msweeps))
+                SETERRQ2(mpi_comm, 1, "-msweeps and -maxnsweeps must have the same number of items. Got %lld and %lld, respectively.", LLD(num_msweeps), LLD(num_maxnsweeps));
+            if (opt_nsweeps && !opt_msweeps) sweep_mode = SWEEP_MODE_NSWEEPS;
+            else if (opt_msweeps && !opt_nsweeps) sweep_mode = opt_maxnsweeps ? SWEEP_MODE_TOLERANCE_TEST : SWEEP_MODE_MSWEEPS;
+            else sweep_mode = SWEEP_MODE_NULL;
+        }
+        init = PETSC_TRUE;
+        return 0;
+    }
+
+    /** Registers an n-point correlator (kept for the driver; measurements are SURVEY 8f N3). */
+    PetscErrorCode SetUpCorrelation(const std::vector<Op>& OpList, const std::string& name, const std::string& desc)
+    {
+        if (!init) SETERRQ(mpi_comm, 1, "Initialize() must be called first.");
+        for (const Op& o : OpList) if (o.idx < 0 || o.idx >= num_sites) SETERRQ2(mpi_comm, 1, "Operator index %lld out of range [0,%lld).", LLD(o.idx), LLD(num_sites));
+        corr_names.push_back(name); corr_descs.push_back(desc); corr_ops.push_back(OpList);
+        return 0;
+    }
+
+    /** Grows the system block from one site to half the lattice, using as environment the largest stored block that
+        completes whole columns (Liang-Pang style cluster growth). */
+    PetscErrorCode Warmup()
+    {
+        if (!init) SETERRQ(mpi_comm, 1, "Initialize() must be called first.");
+        if (dry_run) return 0;
+        if (mwarmup == 0) { if (!mpi_rank) std::cout << "WARNING: Nothing left to do since mwarmup is zero." << std::endl; return 0; }
+        PetscErrorCode ierr;
+        ierr = PetscTime(&t0abs); CHKERRQ(ierr);
+        if (warmed_up) SETERRQ(mpi_comm, 1, "Warmup has already been called, and it can only be called once.");
+        if (!mpi_rank) printf("WARMUP\n");
+        num_sys_blocks = num_sites - 1;
+        sys_blocks.resize((size_t)num_sys_blocks);
+        ierr = sys_blocks[sys_ninit++].Initialize(mpi_comm, 1, PETSC_DEFAULT); CHKERRQ(ierr);
+        if (AddSite().NumSites() != 1) SETERRQ1(mpi_comm, 1, "Routine assumes an additional site of 1. Got %lld.", LLD(AddSite().NumSites()));
+        PetscInt nsites_cluster = Ham.NumEnvSites();
+        if (nsites_cluster % 2) nsites_cluster *= 2;
+        if (!mpi_rank) printf(" Preparing initial blocks.\n");
+        while (sys_ninit < nsites_cluster) {          /* exact blocks, no truncation */
+            const PetscInt ntot = sys_blocks[sys_ninit - 1].NumSites() + AddSite().NumSites();
+            ierr = KronEye_Explicit(sys_blocks[sys_ninit - 1], AddSite(), Ham.H(ntot), sys_blocks[sys_ninit]); CHKERRQ(ierr);
+            ++sys_ninit;
+        }
+        if (sys_ninit >= num_sites / 2)
+            SETERRQ(mpi_comm, 1, "No DMRG Steps were performed since all site operators were created exactly.  Please change the system dimensions.");
+        LoopType = WarmupStep; StepIdx = 0;
+        while (sys_ninit < num_sites / 2) {
+            PetscInt full_cluster = (((sys_ninit + 2) / nsites_cluster) + 1) * nsites_cluster;
+            PetscInt env_numsites = full_cluster - sys_ninit - 2;
+            const PetscInt env_add = ((sys_ninit - env_numsites) / nsites_cluster) * nsites_cluster;
+            env_numsites += env_add; full_cluster += env_add;
+            if (env_numsites < 1 || env_numsites > sys_ninit) SETERRQ1(mpi_comm, 1, "Incorrect number of sites. Got %lld.", LLD(env_numsites));
+            if (!mpi_rank) { printf(" %s  %lld/%lld/%lld\n", "WARMUP", LLD(LoopIdx), LLD(StepIdx), LLD(GlobIdx)); PrintBlocks(sys_ninit, env_numsites); }
+            ierr = SingleDMRGStep(sys_blocks[sys_ninit - 1], sys_blocks[env_numsites - 1], mwarmup,
+                                  sys_blocks[sys_ninit], sys_blocks[env_numsites], PetscBool(sys_ninit + 1 == num_sites / 2)); CHKERRQ(ierr);
+            ++sys_ninit;
+        }
+        if (sys_ninit != num_sites / 2) SETERRQ2(mpi_comm, 1, "Expected sys_ninit = num_sites/2 = %lld. Got %lld.", LLD(num_sites / 2), LLD(sys_ninit));
+        warmed_up = PETSC_TRUE;
+        ++LoopIdx;
+        return 0;
+    }
+
+    PetscErrorCode Sweeps()
+    {
+        if (dry_run || mwarmup == 0) return 0;
+        PetscErrorCode ierr;
+        if (sweep_mode == SWEEP_MODE_NSWEEPS) { for (msweep_idx = 0; msweep_idx < nsweeps; ++msweep_idx) { ierr = SingleSweep(mwarmup); CHKERRQ(ierr); } }
+        else if (sweep_mode == SWEEP_MODE_MSWEEPS) { for (msweep_idx = 0; msweep_idx < (PetscInt)msweeps.size(); ++msweep_idx) { ierr = SingleSweep(msweeps.at(msweep_idx)); CHKERRQ(ierr); } }
+        else if (sweep_mode == SWEEP_MODE_TOLERANCE_TEST) {
+            for (msweep_idx = 0; msweep_idx < (PetscInt)msweeps.size(); ++msweep_idx) {
+                const PetscInt mstates = msweeps.at(msweep_idx), max_iter = maxnsweeps.at(msweep_idx);
+                if (max_iter == 0) continue;
+                PetscInt iter = 0; bool cont;
+                do {    /* sweep again while the energy still moves by more than the largest truncation error */
+                    const PetscScalar prev_gse = gse;
+                    ierr = SingleSweep(mstates); CHKERRQ(ierr);
+                    const PetscReal diff_gse = PetscAbsScalar(gse - prev_gse);
+                    const PetscReal max_trn = std::max(*std::max_element(trunc_err.begin(), trunc_err.end()), 0.0);
+                    ++iter;
+                    cont = (iter < max_iter) && (diff_gse > max_trn);
+                    if (!mpi_rank) std::cout << "SWEEP_MODE_TOLERANCE_TEST\n  Iterations / Max Iterations:       " << iter << "/" << max_iter
+                        << "\n  Difference in ground state energy: " << diff_gse << "\n  Largest truncation error:          " << max_trn
+                        << "\n  " << (cont ? "CONTINUE" : "BREAK") << std::endl;
+                } while (cont);
+            }
+        }
+        else if (sweep_mode == SWEEP_MODE_NULL) {}
+        else SETERRQ(mpi_comm, 1, "Invalid sweep mode.");
+        return 0;
+    }
+
+    /** One sweep: centre -> right edge, then (by reflection symmetry) from the right edge's mirror back to the centre:
+        N-4 steps. */
+    PetscErrorCode SingleSweep(const PetscInt& MStates, const PetscInt& MinBlock = PETSC_DEFAULT)
+    {
+        if (!init) SETERRQ(mpi_comm, 1, "Initialize() must be called first.");
+        PetscErrorCode ierr;
+        if (!warmed_up) SETERRQ(mpi_comm, 1, "Warmup must be called first before performing sweeps.");
+        if (!mpi_rank) printf("SWEEP MStates=%lld\n", LLD(MStates));
+        trunc_err.clear();
+        const PetscInt min_block = MinBlock == PETSC_DEFAULT ? 1 : MinBlock;
+        if (min_block < 1) SETERRQ1(mpi_comm, 1, "MinBlock must at least be 1. Got %lld.", LLD(min_block));
+        PetscLogDouble ts0, ts1;
+        ierr = PetscTime(&ts0); CHKERRQ(ierr);
+        const PetscInt steps0 = GlobIdx, mm0 = total_matmults;
+        LoopType = SweepStep; StepIdx = 0;
+        for (PetscInt iblock = num_sites / 2; iblock < num_sites - min_block - 2; ++iblock) {
+            const PetscInt insys = iblock - 1, inenv = num_sites - iblock - 3, outsys = iblock, outenv = num_sites - iblock - 2;
+            if (!mpi_rank) { printf(" %s  %lld/%lld/%lld\n", "SWEEP", LLD(LoopIdx), LLD(StepIdx), LLD(GlobIdx)); PrintBlocks(insys + 1, inenv + 1); }
+            ierr = SingleDMRGStep(sys_blocks[insys], sys_blocks[inenv], MStates, sys_blocks[outsys], sys_blocks[outenv]); CHKERRQ(ierr);
+        }
+        for (PetscInt iblock = min_block; iblock < num_sites / 2; ++iblock) {
+            const PetscInt insys = num_sites - iblock - 3, inenv = iblock - 1, outsys = num_sites - iblock - 2, outenv = iblock;
+            if (!mpi_rank) { printf(" %s  %lld/%lld/%lld\n", "SWEEP", LLD(LoopIdx), LLD(StepIdx), LLD(GlobIdx)); PrintBlocks(insys + 1, inenv + 1); }
+            ierr = SingleDMRGStep(sys_blocks[insys], sys_blocks[inenv], MStates, sys_blocks[outsys], sys_blocks[outenv], PetscBool(outsys == outenv)); CHKERRQ(ierr);
+        }
+        sweeps_mstates.push_back(MStates);
+        ierr = PetscTime(&ts1); CHKERRQ(ierr);
+        if (!mpi_rank) printf("SWEEP DONE  steps=%lld  time=%.6f s  sites/s=%.3f  MatMults=%lld  E=%.12g\n", LLD(GlobIdx - steps0), ts1 - ts0,
+                              (GlobIdx - steps0) / (ts1 - ts0), LLD(total_matmults - mm0), gse);
+        last_sweep_seconds = ts1 - ts0; last_sweep_steps = GlobIdx - steps0; last_sweep_matmults = total_matmults - mm0;
+        ++LoopIdx;
+        return 0;
+    }
+
+    PetscErrorCode Destroy()
+    {
+        if (!init) return 0;
+        for (Block& b : sys_blocks) { PetscErrorCode ierr = b.Destroy(); CHKERRQ(ierr); }
+        PetscErrorCode ierr = SingleSite.Destroy(); CHKERRQ(ierr);
+        if (fp_step) { fprintf(fp_step, "\n  ]\n}\n"); fclose(fp_step); fp_step = NULL; }
+        if (fp_timings) { fprintf(fp_timings, "\n  ]\n}\n"); fclose(fp_timings); fp_timings = NULL; }
+        if (fp_entanglement) { fprintf(fp_entanglement, "\n]\n"); fclose(fp_entanglement); fp_entanglement = NULL; }
+        if (fp_data) {
+            fprintf(fp_data, ",\n  \"Sweeps\": [");
+            for (size_t i = 0; i < sweeps_mstates.size(); ++i) fprintf(fp_data, "%s%lld", i ? ", " : "", LLD(sweeps_mstates[i]));
+            fprintf(fp_data, "],\n  \"GSEnergy\": %.16g,\n  \"MatMults\": %lld,\n  \"LastSweepSeconds\": %.9g,\n  \"LastSweepSteps\": %lld,\n  \"LastSweepMatMults\": %lld,\n  \"EigensolveSeconds\": %.9g\n}\n",
+                    gse, LLD(total_matmults), last_sweep_seconds, LLD(last_sweep_steps), LLD(last_sweep_matmults), total_eigs_seconds);
+            fclose(fp_data); fp_data = NULL;
+        }
+        init = PETSC_FALSE;
+        return 0;
+    }
+
+    const Block& SysBlock(const PetscInt& BlockIdx) const { if (BlockIdx >= sys_ninit) throw std::runtime_error("Attempted to access uninitialized system block."); return sys_blocks[BlockIdx]; }
+    const Block& EnvBlock() const { return sys_blocks[0]; }
+    PetscInt NumSites() const { return num_sites; }
+    const Hamiltonian& HamiltonianRef() const { return Ham; }
+    PetscBool Verbose() const { return verbose; }
+    PetscScalar GSEnergy() const { return gse; }
+    PetscInt TotalMatMults() const { return total_matmults; }
+
+    /** One DMRG step: enlarge both blocks by a site, solve the superblock ground state in the target sector, truncate
+        to at most MStates states per block and rotate every operator into the new bases. */
+    PetscErrorCode SingleDMRGStep(Block& SysBlock, Block& EnvBlock, const PetscInt& MStates, Block& SysBlockOut, Block& EnvBlockOut,
+                                  PetscBool do_measurements = PETSC_FALSE)
+    {
+        PetscErrorCode ierr;
+        PetscLogDouble t0 = t0abs, tenlr, tkron, tdiag, trdms, trotb;
+        TimingsData timings;
+        StepData step;
+        step.NumSites_Sys = SysBlock.NumSites(); step.NumSites_Env = EnvBlock.NumSites();
+        step.NumStates_Sys = SysBlock.NumStates(); step.NumStates_Env = EnvBlock.NumStates();
+        const PetscBool same = PetscBool(&SysBlock == &EnvBlock);
+
+        Block SysBlockEnl, EnvBlockEnl;
+        ierr = KronEye_Explicit(SysBlock, AddSite(), Ham.H(SysBlock.NumSites() + AddSite().NumSites()), SysBlockEnl); CHKERRQ(ierr);
+        if (!same) { ierr = KronEye_Explicit(EnvBlock, AddSite(), Ham.H(EnvBlock.NumSites() + AddSite().NumSites()), EnvBlockEnl); CHKERRQ(ierr); }
+        else EnvBlockEnl = SysBlockEnl;                                   /* shallow copy: same operator handles */
+        ierr = PetscTime(&tenlr); CHKERRQ(ierr);
+        timings.tEnlr = tenlr - t0;
+        step.NumSites_SysEnl = SysBlockEnl.NumSites(); step.NumSites_EnvEnl = EnvBlockEnl.NumSites();
+        step.NumStates_SysEnl = SysBlockEnl.NumStates(); step.NumStates_EnvEnl = EnvBlockEnl.NumStates();
+
+        const PetscInt NumSitesTotal = SysBlockEnl.NumSites() + EnvBlockEnl.NumSites();
+        const std::vector<Hamiltonians::Term> Terms = Ham.H(NumSitesTotal);
+        KronBlocks_t KronBlocks(SysBlockEnl, EnvBlockEnl, {qn_sector}, NULL, GlobIdx);
+        step.NumStates_H = KronBlocks.NumStates();
+        if (KronBlocks.NumStates() == 0) SETERRQ1(mpi_comm, 1, "The target sector %g is empty.", qn_sector);
+        Mat H = nullptr;
+        ierr = KronBlocks.KronSumSetRedistribute(PETSC_TRUE); CHKERRQ(ierr);
+        ierr = KronBlocks.KronSumSetToleranceFromOptions(); CHKERRQ(ierr);
+        ierr = KronBlocks.KronSumSetShellMatrix(do_shell); CHKERRQ(ierr);
+        ierr = KronBlocks.KronSumConstruct(Terms, H); CHKERRQ(ierr);
+        if (!H) SETERRQ(mpi_comm, 1, "H is null.");
+        ierr = PetscTime(&tkron); CHKERRQ(ierr);
+        timings.tKron = tkron - tenlr;
+
+        if (debug_symm) {   /* -debug_check_symmetry: <u,Hv> == <Hu,v> on random vectors (the reference's H is symmetric) */
+            Vec u, v, Hu, Hv;
+            MatCreateVecs(H, &u, &v); MatCreateVecs(H, &Hu, &Hv);
+            double* uh = u->buf->host(); double* vh = v->buf->host();
+            uint64_t z = 88172645463325252ull;
+            for (PetscInt i = 0; i < u->n; ++i) { z ^= z << 13; z ^= z >> 7; z ^= z << 17; uh[i] = (double)(z % 2001) / 1000.0 - 1.0; z ^= z << 13; z ^= z >> 7; z ^= z << 17; vh[i] = (double)(z % 2001) / 1000.0 - 1.0; }
+            ierr = MatMult(H, u, Hu); CHKERRQ(ierr); ierr = MatMult(H, v, Hv); CHKERRQ(ierr);
+            const double *a = u->buf->host_ro(), *b = v->buf->host_ro(), *ha = Hu->buf->host_ro(), *hb = Hv->buf->host_ro();
+            double uHv = 0, Huv = 0, nu = 0;
+            for (PetscInt i = 0; i < u->n; ++i) { uHv += a[i] * hb[i]; Huv += ha[i] * b[i]; nu += ha[i] * ha[i]; }
+            printf("  [debug] symmetry: <u,Hv>=%.12g <Hu,v>=%.12g |Hu|=%.6g  N=%lld\n", uHv, Huv, std::sqrt(nu), LLD(u->n));
+        }
+        /* ground state: lowest eigenpair, random start vector (the reference passes no initial space either) */
+        Vec gsv_r;
+        ierr = MatCreateVecs(H, &gsv_r, nullptr); CHKERRQ(ierr);
+        PetscScalar gse_r = 0.0;
+        {
+            dmrgx_eigs_opts o;
+            memset(&o, 0, sizeof(o));
+            o.ncv = (int32_t)eps_ncv; o.max_it = (int32_t)eps_max_it; o.tol = eps_tol; o.seed = 0x9E3779B9u + (uint64_t)GlobIdx;
+            dmrgx_eigs_stats st;
+            memset(&st, 0, sizeof(st));
+            if (dmrgx_eigs_lowest(H->plan, &o, &gse_r, gsv_r->buf->dev_uninitialised(), &st, nullptr))
+                SETERRQ1(mpi_comm, 1, "dmrgx_eigs_lowest: %s", dmrgx_last_error());
+            timings.nMatMult = st.n_matvec; total_matmults += st.n_matvec; total_eigs_seconds += st.seconds;
+        }
+        step.GSEnergy = gse_r;
+        ierr = MatDestroy_KronSumShell(&H); CHKERRQ(ierr);
+        ierr = MatDestroy(&H); CHKERRQ(ierr);
+        ierr = PetscTime(&tdiag); CHKERRQ(ierr);
+        timings.tDiag = tdiag - tkron;
+
+        BasisTransformation BT_L, BT_R;
+        ierr = GetTruncation(KronBlocks, gsv_r, MStates, BT_L, BT_R); CHKERRQ(ierr);
+        (void)do_measurements;                                            /* correlators: SURVEY 8f N3 */
+        ierr = VecDestroy(&gsv_r); CHKERRQ(ierr);
+        ierr = SysBlockOut.Destroy(); CHKERRQ(ierr);
+        ierr = EnvBlockOut.Destroy(); CHKERRQ(ierr);
+        ierr = PetscTime(&trdms); CHKERRQ(ierr);
+        timings.tRdms = trdms - tdiag;
+
+        ierr = SysBlockOut.Initialize(SysBlockEnl.NumSites(), BT_L.QN); CHKERRQ(ierr);
+        ierr = SysBlockOut.RotateOperators(SysBlockEnl, BT_L.RotMatT); CHKERRQ(ierr);
+        if (!same) {
+            ierr = EnvBlockOut.Initialize(EnvBlockEnl.NumSites(), BT_R.QN); CHKERRQ(ierr);
+            ierr = EnvBlockOut.RotateOperators(EnvBlockEnl, BT_R.RotMatT); CHKERRQ(ierr);
+        }
+        step.NumStates_SysRot = SysBlockOut.NumStates(); step.NumStates_EnvRot = EnvBlockOut.NumStates();
+        step.TruncErr_Sys = BT_L.TruncErr; step.TruncErr_Env = BT_R.TruncErr;
+        ierr = PetscTime(&trotb); CHKERRQ(ierr);
+        timings.tRotb = trotb - trdms;
+        timings.Total = trotb - t0;
+        ierr = PetscTime(&t0abs); CHKERRQ(ierr);
+        if (!mpi_rank && verbose) {
+            printf("  Superblock: NumStates %lld  NumSites %lld  QNSector %g  Energy %.12g  Energy/site %.12g\n", LLD(KronBlocks.NumStates()), LLD(NumSitesTotal), qn_sector, gse_r, gse_r / PetscReal(NumSitesTotal));
+            printf("  Sys out: NumStates %lld TruncErr %g | Env out: NumStates %lld TruncErr %g | MatMults %lld\n", LLD(BT_L.QN.NumStates()), BT_L.TruncErr, LLD(BT_R.QN.NumStates()), BT_R.TruncErr, LLD(timings.nMatMult));
+            printf("  Total %.6f s: enlarge %.6f  build H %.6f  solve %.6f  rdm %.6f  rotate %.6f\n", timings.Total, timings.tEnlr, timings.tKron, timings.tDiag, timings.tRdms, timings.tRotb);
+        }
+        gse = gse_r;
+        trunc_err.push_back(BT_L.TruncErr);
+        ierr = SaveStepData(step); CHKERRQ(ierr);
+        ierr = SaveTimingsData(timings); CHKERRQ(ierr);
+        ++GlobIdx; ++StepIdx;
+        return 0;
+    }
+
+    /** Reduced density matrices of both sides, their full spectra (device), the global cut to MStates states and the
+        rotation matrices.  The ordering rules are the reference's: concatenate the spectra KronBlock by KronBlock,
+        stable-sort by decreasing eigenvalue, keep the first min(MStates, #), stable-sort the survivors by sector. */
+    PetscErrorCode GetTruncation(const KronBlocks_t& KronBlocks, const Vec& gsv_r, const PetscInt& MStates, BasisTransformation& BT_L, BasisTransformation& BT_R)
+    {
+        PetscErrorCode ierr;
+        if (gsv_r->n != KronBlocks.NumStates()) SETERRQ2(PETSC_COMM_SELF, 1, "Incorrect vector length. Expected %lld. Got %lld.", LLD(KronBlocks.NumStates()), LLD(gsv_r->n));
+        const QuantumNumbers* M[2] = {&KronBlocks.LeftBlockRef().Magnetization, &KronBlocks.RightBlockRef().Magnetization};
+        const std::vector<int32_t> ls = M[0]->Sizes32(), rs = M[1]->Sizes32();
+        const PetscInt nb = KronBlocks.size();
+        std::vector<int32_t> bil, bir;
+        for (PetscInt k = 0; k < nb; ++k) {
+            bil.push_back((int32_t)KronBlocks.LeftIdx(k)); bir.push_back((int32_t)KronBlocks.RightIdx(k));
+            if (KronBlocks.Offsets(k + 1) - KronBlocks.Offsets(k) != (PetscInt)ls[bil[k]] * rs[bir[k]]) SETERRQ(PETSC_COMM_SELF, 1, "Incorrect segment length.");
+        }
+        dmrgx_sectors sl{(int32_t)ls.size(), ls.data()}, sr{(int32_t)rs.size(), rs.data()};
+        dmrgx_rdm* rdm = nullptr;
+        if (dmrgx_rdm_create(&sl, &sr, (int32_t)nb, bil.data(), bir.data(), gsv_r->buf->dev_ro(), nullptr, &rdm)) SETERRQ1(mpi_comm, 1, "dmrgx_rdm_create: %s", dmrgx_last_error());
+        BasisTransformation* BT[2] = {&BT_L, &BT_R};
+        for (int side = 0; side < 2; ++side) {
+            std::vector<Eigen_t> eigen;
+            for (PetscInt k = 0; k < nb; ++k) {
+                const PetscInt blk = side == 0 ? bil[k] : bir[k], n = M[side]->Sizes(blk);
+                std::vector<double> w((size_t)n);
+                if (dmrgx_rdm_eigenvalues(rdm, side, (int32_t)k, w.data())) { dmrgx_rdm_destroy(rdm); SETERRQ1(mpi_comm, 1, "dmrgx_rdm_eigenvalues: %s", dmrgx_last_error()); }
+                for (PetscInt e = 0; e < n; ++e) eigen.push_back({w[(size_t)e], k, e, blk});
+            }
+            ierr = SaveEntanglementSpectrum(side, eigen, *M[side]); CHKERRQ(ierr);
+            std::stable_sort(eigen.begin(), eigen.end(), greater_eigval);
+            const PetscInt m = PetscMin(MStates, (PetscInt)eigen.size());
+            eigen.resize((size_t)m);
+            std::stable_sort(eigen.begin(), eigen.end(), less_blkIdx);
+            PetscReal trunc = 1.0;
+            for (const Eigen_t& e : eigen) trunc -= (e.eigval > 0) * e.eigval;
+            BT[side]->TruncErr = trunc;
+            /* kept states per sector are the top ones of that sector's spectrum, in decreasing order */
+            std::map<PetscInt, std::pair<PetscInt, PetscInt>> per;       /* blkIdx -> (KronBlock, count) */
+            for (const Eigen_t& e : eigen) { auto& p = per[e.blkIdx]; p.first = e.seqIdx; p.second += 1; }
+            auto rot = std::make_shared<dmrgx_host::BasisRotation>();
+            rot->old_sizes = M[side]->Sizes32();
+            std::vector<PetscReal> qn_list; std::vector<PetscInt> qn_size;
+            for (const auto& kv : per) {
+                const PetscInt blk = kv.first, k = kv.second.first, cnt = kv.second.second, n = M[side]->Sizes(blk);
+                rot->old_sector.push_back((int32_t)blk); rot->kept.push_back((int32_t)cnt);
+                auto buf = std::make_shared<dmrgx_host::DevBuffer>((size_t)cnt * n);
+                if (dmrgx_rdm_eigenvectors(rdm, side, (int32_t)k, (int32_t)cnt, buf->dev_uninitialised(), n, nullptr)) { dmrgx_rdm_destroy(rdm); SETERRQ1(mpi_comm, 1, "dmrgx_rdm_eigenvectors: %s", dmrgx_last_error()); }
+                rot->rt.push_back(buf);
+                qn_list.push_back(M[side]->List(blk)); qn_size.push_back(cnt);
+            }
+            BT[side]->RotMatT = std::make_shared<dmrgx_host::SectorMat>();
+            BT[side]->RotMatT->rot = rot;
+            ierr = BT[side]->QN.Initialize(mpi_comm, qn_list, qn_size); CHKERRQ(ierr);
+        }
+        dmrgx_stream_sync(nullptr);
+        dmrgx_rdm_destroy(rdm);
+        return 0;
+    }
+
+private:
+    struct StepData {
+        PetscInt NumSites_Sys = 0, NumSites_Env = 0, NumSites_SysEnl = 0, NumSites_EnvEnl = 0;
+        PetscInt NumStates_Sys = 0, NumStates_Env = 0, NumStates_SysEnl = 0, NumStates_EnvEnl = 0, NumStates_SysRot = 0, NumStates_EnvRot = 0, NumStates_H = 0;
+        PetscScalar GSEnergy = 0; PetscReal TruncErr_Sys = 0, TruncErr_Env = 0;
+    };
+    struct TimingsData { PetscLogDouble tEnlr = 0, tKron = 0, tDiag = 0, tRdms = 0, tRotb = 0, Total = 0; PetscInt nMatMult = 0; };
+    typedef enum { WarmupStep = 0, SweepStep = 1, NullStep = -1 } Step_t;
+    typedef enum { SWEEP_MODE_NULL, SWEEP_MODE_NSWEEPS, SWEEP_MODE_MSWEEPS, SWEEP_MODE_TOLERANCE_TEST } SweepMode_t;
+
+    Block& AddSite() { return SingleSite; }
+
+    void PrintBlocks(const PetscInt& nsys, const PetscInt& nenv) const { printf("  [%lld]-* *-[%lld]\n", LLD(nsys), LLD(nenv)); }
+
+    PetscErrorCode SaveStepHeaders()
+    {
+        fprintf(fp_step, "{\n  \"headers\" : [\"GlobIdx\", \"LoopType\", \"LoopIdx\", \"StepIdx\", \"NSites_Sys\", \"NSites_Env\", \"NSites_SysEnl\", \"NSites_EnvEnl\", "
+                         "\"NStates_Sys\", \"NStates_Env\", \"NStates_SysEnl\", \"NStates_EnvEnl\", \"NStates_SysRot\", \"NStates_EnvRot\", \"NumStates_H\", "
+                         "\"TruncErr_Sys\", \"TruncErr_Env\", \"GSEnergy\"  ],\n  \"table\" : ");
+        return 0;
+    }
+    PetscErrorCode SaveStepData(const StepData& d)
+    {
+        fprintf(fp_step, "%s    [ %lld, %s, %lld, %lld, %lld, %lld, %lld, %lld, %lld, %lld, %lld, %lld, %lld, %lld, %lld, %.12g, %.12g, %.12g]", GlobIdx ? ",\n" : "",
+                LLD(GlobIdx), LoopType ? "\"Sweep\"" : "\"Warmup\"", LLD(LoopIdx), LLD(StepIdx), LLD(d.NumSites_Sys), LLD(d.NumSites_Env), LLD(d.NumSites_SysEnl), LLD(d.NumSites_EnvEnl),
+                LLD(d.NumStates_Sys), LLD(d.NumStates_Env), LLD(d.NumStates_SysEnl), LLD(d.NumStates_EnvEnl), LLD(d.NumStates_SysRot), LLD(d.NumStates_EnvRot), LLD(d.NumStates_H),
+                d.TruncErr_Sys, d.TruncErr_Env, d.GSEnergy);
+        fflush(fp_step);
+        return 0;
+    }
+    PetscErrorCode SaveTimingsHeaders()
+    {
+        fprintf(fp_timings, "{\n  \"headers\" : [\"GlobIdx\", \"Total\", \"Enlr\", \"Kron\", \"Diag\", \"Rdms\", \"Rotb\", \"MatMults\" ],\n  \"table\" : ");
+        return 0;
+    }
+    PetscErrorCode SaveTimingsData(const TimingsData& d)
+    {
+        fprintf(fp_timings, "%s    [ %lld, %.9g, %.9g, %.9g, %.9g, %.9g, %.9g, %lld ]", GlobIdx ? ",\n" : "", LLD(GlobIdx), d.Total, d.tEnlr, d.tKron, d.tDiag, d.tRdms, d.tRotb, LLD(d.nMatMult));
+        fflush(fp_timings);
+        return 0;
+    }
+    /** Per-sector RDM eigenvalues of one side, in the reference's EntanglementSpectra.json layout. */
+    PetscErrorCode SaveEntanglementSpectrum(int side, const std::vector<Eigen_t>& eigen, const QuantumNumbers& qn)
+    {
+        if (side == 0) fprintf(fp_entanglement, "%s  {\n    \"GlobIdx\": %lld,\n", GlobIdx ? ",\n" : "", LLD(GlobIdx));
+        fprintf(fp_entanglement, "    \"%s\": [\n", side == 0 ? "Sys" : "Env");
+        PetscInt prev = -1; bool first_sector = true;
+        for (const Eigen_t& e : eigen) {
+            if (e.blkIdx != prev) {
+                if (!first_sector) fprintf(fp_entanglement, "] },\n");
+                fprintf(fp_entanglement, "      {\"sector\": %g, \"vals\": [ %g", qn.List(e.blkIdx), e.eigval);
+                prev = e.blkIdx; first_sector = false;
+            } else fprintf(fp_entanglement, ", %g", e.eigval);
+        }
+        if (!first_sector) fprintf(fp_entanglement, "] }\n");
+        fprintf(fp_entanglement, side == 0 ? "    ],\n" : "    ]\n  }");
+        fflush(fp_entanglement);
+        return 0;
+    }
+
+    MPI_Comm mpi_comm;
+    PetscMPIInt mpi_rank = 0, mpi_size = 1;
+    PetscBool debug_symm = PETSC_FALSE;
+    PetscBool init = PETSC_FALSE, verbose = PETSC_FALSE, no_symm = PETSC_FALSE, do_shell = PETSC_TRUE, dry_run = PETSC_FALSE, warmed_up = PETSC_FALSE;
+    PetscReal qn_sector = 0.0;
+    PetscReal eps_tol = 1.0e-8;     /* SLEPc's default relative residual tolerance */
+    PetscInt eps_ncv = 16, eps_max_it = 1000;
+    std::string scratch_dir, data_dir;
+    FILE *fp_step = NULL, *fp_timings = NULL, *fp_entanglement = NULL, *fp_data = NULL;
+    PetscInt mwarmup = 0, nsweeps = 0, msweep_idx = 0;
+    std::vector<PetscInt> msweeps, maxnsweeps, sweeps_mstates;
+    SweepMode_t sweep_mode = SWEEP_MODE_NULL;
+    Hamiltonian Ham;
+    Block SingleSite;
+    PetscInt num_sites = 0, num_sys_blocks = 0, sys_ninit = 0;
+    std::vector<Block> sys_blocks;
+    Step_t LoopType = NullStep;
+    PetscInt GlobIdx = 0, LoopIdx = 0, StepIdx = 0;
+    PetscScalar gse = 0.0;
+    std::vector<PetscReal> trunc_err;
+    PetscLogDouble t0abs = 0.0;
+    PetscInt total_matmults = 0, last_sweep_steps = 0, last_sweep_matmults = 0;
+    double total_eigs_seconds = 0.0, last_sweep_seconds = 0.0;
+    std::vector<std::string> corr_names, corr_descs;
+    std::vector<std::vector<Op>> corr_ops;
+};
+
+#endif

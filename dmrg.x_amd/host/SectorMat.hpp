@@ -1,0 +1,197 @@
+/** @file SectorMat.hpp
+    The engine's `Mat` and `Vec`: handles to sector-blocked operator cells / superblock vectors whose storage lives in
+    HBM behind the C ABI (include/dmrgx.h).  They take the place of PETSc's Mat/Vec in the DMRG.x operator API
+    (reference include/DMRGBlock.hpp:79-434).  An operator is a list of dense or scaled-identity cells inside its
+    (sector q -> sector q+shift) blocks -- exactly the dmrgx_cell description the kernels consume, so building a
+    superblock plan or a rotation needs no conversion.  A host mirror exists only on demand (fixtures, single-site
+    operators, tests); all arithmetic happens on the device. */
+#ifndef DMRGX_SECTORMAT_HPP
+#define DMRGX_SECTORMAT_HPP
+
+#include <memory>
+#include <vector>
+#include <algorithm>
+#include "petsc_compat.hpp"
+#include "dmrgx.h"
+
+namespace dmrgx_host {
+
+/** f64 buffer with a lazily synchronised host mirror. */
+class DevBuffer {
+public:
+    explicit DevBuffer(size_t n) : n_(n), h_(n, 0.0), where_(HOST) {}
+    DevBuffer(const DevBuffer&) = delete;
+    DevBuffer& operator=(const DevBuffer&) = delete;
+    ~DevBuffer() { if (d_) dmrgx_free(d_); }
+    size_t size() const { return n_; }
+    /** host pointer for reading and writing (device copy becomes stale) */
+    double* host() { sync_host(); where_ = HOST; return h_.data(); }
+    const double* host_ro() { sync_host(); return h_.data(); }
+    /** device pointer for reading and writing (host copy becomes stale); throws without a GPU */
+    double* dev() { sync_dev(); where_ = DEVICE; return d_; }
+    const double* dev_ro() { sync_dev(); return d_; }
+    /** device pointer without uploading the (all-zero / don't-care) host content */
+    double* dev_uninitialised() {
+        if (!d_) alloc_dev();
+        where_ = DEVICE;
+        return d_;
+    }
+private:
+    enum Where { HOST, DEVICE, BOTH };
+    void alloc_dev() {
+        void* p = nullptr;
+        if (dmrgx_malloc(&p, std::max<size_t>(n_, 1) * sizeof(double))) throw std::runtime_error(std::string("dmrgx_malloc: ") + dmrgx_last_error());
+        d_ = static_cast<double*>(p);
+    }
+    void sync_dev() {
+        if (!d_) alloc_dev();
+        if (where_ == HOST) {
+            if (n_ && dmrgx_memcpy_h2d(d_, h_.data(), n_ * sizeof(double), nullptr)) throw std::runtime_error(dmrgx_last_error());
+            if (dmrgx_stream_sync(nullptr)) throw std::runtime_error(dmrgx_last_error());
+            where_ = BOTH;
+        }
+    }
+    void sync_host() {
+        if (where_ == DEVICE) {
+            if (h_.size() != n_) h_.assign(n_, 0.0);
+            if (n_ && dmrgx_memcpy_d2h(h_.data(), d_, n_ * sizeof(double), nullptr)) throw std::runtime_error(dmrgx_last_error());
+            where_ = BOTH;
+        }
+    }
+    size_t n_;
+    std::vector<double> h_;
+    double* d_ = nullptr;
+    Where where_;
+};
+
+struct MatCell {
+    int32_t q = 0, r0 = 0, c0 = 0, nr = 0, nc = 0;
+    int32_t kind = DMRGX_CELL_DENSE;
+    double scale = 0.0;
+    std::shared_ptr<DevBuffer> buf;   /**< DENSE: storage (possibly shared with the block this one was enlarged from) */
+    int64_t off = 0, ld = 0;          /**< element (r0,c0) is buf[off], row stride ld */
+};
+
+/** Truncation as a sector-block rotation (the engine's RotMatT): new sector a keeps kept[a] states of old sector
+    old_sector[a]; rt[a] holds those kept[a] eigenvectors as rows (kept[a] x n_old, row-major) -- the non-zero
+    blocks of the reference's RotMatT (include/DMRGBlockContainer.hpp:2032-2054). */
+struct BasisRotation {
+    std::vector<int32_t> old_sizes;
+    std::vector<int32_t> old_sector, kept;
+    std::vector<std::shared_ptr<DevBuffer>> rt;
+};
+
+/** Sector-blocked square operator (or, when `plan` is set, a matrix-free superblock Hamiltonian; or, when `rot` is
+    set, a rotation matrix RotMatT). */
+class SectorMat {
+public:
+    std::shared_ptr<SectorMat> transpose_of;   /**< set for Sm(i): a transposed view of Sp(i), never materialised */
+    std::shared_ptr<BasisRotation> rot;        /**< set for RotMatT */
+    int32_t shift = 0;
+    std::vector<int32_t> sizes;       /**< sector sizes of the block basis */
+    std::vector<MatCell> cells;
+    dmrgx_kron_plan* plan = nullptr;  /**< shell matrix: the HIP plan that applies it */
+    PetscInt shell_n = 0;
+
+    PetscInt N() const { if (plan) return shell_n; PetscInt n = 0; for (int32_t s : sizes) n += s; return n; }
+    std::vector<PetscInt> offsets() const { std::vector<PetscInt> o(sizes.size() + 1, 0); for (size_t i = 0; i < sizes.size(); ++i) o[i + 1] = o[i] + sizes[i]; return o; }
+
+    /** One zero-initialised dense cell per existing sector block: the form block initialisers hand out
+        (InitSingleSiteOperator + preallocation in the reference, src/DMRGBlock.cpp:140-147). */
+    static std::shared_ptr<SectorMat> Dense(int32_t shift, const std::vector<int32_t>& sizes) {
+        auto m = std::make_shared<SectorMat>();
+        m->shift = shift; m->sizes = sizes;
+        const int32_t ns = (int32_t)sizes.size();
+        for (int32_t q = 0; q < ns; ++q) {
+            const int32_t qc = q + shift;
+            if (qc < 0 || qc >= ns) continue;
+            MatCell c;
+            c.q = q; c.nr = sizes[q]; c.nc = sizes[qc]; c.ld = c.nc;
+            c.buf = std::make_shared<DevBuffer>((size_t)c.nr * c.nc);
+            m->cells.push_back(c);
+        }
+        return m;
+    }
+
+    /** Locate global (row, col): sector indices and in-block coordinates; false if outside the shift's blocks. */
+    bool locate(PetscInt row, PetscInt col, int32_t& q, int32_t& i, int32_t& j) const {
+        const auto o = offsets();
+        const int32_t ns = (int32_t)sizes.size();
+        q = -1;
+        for (int32_t s = 0; s < ns; ++s) if (row >= o[s] && row < o[s + 1]) q = s;
+        if (q < 0) return false;
+        const int32_t qc = q + shift;
+        if (qc < 0 || qc >= ns || col < o[qc] || col >= o[qc + 1]) return false;
+        i = (int32_t)(row - o[q]); j = (int32_t)(col - o[qc]);
+        return true;
+    }
+    /** Host-side element access (fixtures / tests).  set() needs a dense cell covering the entry. */
+    double get(PetscInt row, PetscInt col) const {
+        int32_t q, i, j;
+        if (!locate(row, col, q, i, j)) return 0.0;
+        double v = 0.0;
+        for (const MatCell& c : cells) {
+            if (c.q != q || i < c.r0 || i >= c.r0 + c.nr || j < c.c0 || j >= c.c0 + c.nc) continue;
+            if (c.kind == DMRGX_CELL_DENSE) v += c.buf->host_ro()[c.off + (int64_t)(i - c.r0) * c.ld + (j - c.c0)];
+            else if (i - c.r0 == j - c.c0) v += c.scale;
+        }
+        return v;
+    }
+    PetscErrorCode set(PetscInt row, PetscInt col, double v) {
+        int32_t q, i, j;
+        if (!locate(row, col, q, i, j)) return PETSC_ERR_ARG_OUTOFRANGE;      /* entry outside the operator's sector blocks */
+        for (MatCell& c : cells) {
+            if (c.q != q || c.kind != DMRGX_CELL_DENSE || i < c.r0 || i >= c.r0 + c.nr || j < c.c0 || j >= c.c0 + c.nc) continue;
+            c.buf->host()[c.off + (int64_t)(i - c.r0) * c.ld + (j - c.c0)] = v;
+            return 0;
+        }
+        return PETSC_ERR_ARG_OUTOFRANGE;
+    }
+    std::vector<double> dense_row(PetscInt row) const {
+        const PetscInt n = N();
+        std::vector<double> r((size_t)n, 0.0);
+        const auto o = offsets();
+        int32_t q = -1;
+        for (size_t s = 0; s < sizes.size(); ++s) if (row >= o[s] && row < o[s + 1]) q = (int32_t)s;
+        const int32_t qc = q + shift;
+        if (q < 0 || qc < 0 || qc >= (int32_t)sizes.size()) return r;
+        for (PetscInt col = o[qc]; col < o[qc + 1]; ++col) r[(size_t)col] = get(row, col);
+        return r;
+    }
+    /** dmrgx_secop view of this operator (device pointers; uploads host-resident cells). */
+    void to_secop(dmrgx_secop& op, std::vector<dmrgx_cell>& storage, bool transposed = false, int32_t shift_as_used = 0) {
+        storage.clear();
+        for (MatCell& c : cells) {
+            dmrgx_cell d;
+            d.row_sector = c.q; d.r0 = c.r0; d.c0 = c.c0; d.nr = c.nr; d.nc = c.nc; d.kind = c.kind; d.scale = c.scale;
+            d.data = (c.kind == DMRGX_CELL_DENSE) ? c.buf->dev_ro() + c.off : nullptr;
+            d.ld = c.ld;
+            storage.push_back(d);
+        }
+        op.shift = transposed ? shift_as_used : shift;
+        op.transposed = transposed ? 1 : 0;
+        op.ncells = (int32_t)storage.size();
+        op.cells = storage.data();
+    }
+    void release() { cells.clear(); }
+};
+
+typedef std::shared_ptr<SectorMat> Mat;
+
+/** Superblock vector (device). */
+struct VecImpl { std::shared_ptr<DevBuffer> buf; PetscInt n = 0; };
+typedef std::shared_ptr<VecImpl> Vec;
+
+inline PetscErrorCode MatDestroy(Mat* m) { if (m && *m) { (*m)->release(); m->reset(); } return 0; }
+inline PetscErrorCode VecDestroy(Vec* v) { if (v) v->reset(); return 0; }
+inline PetscErrorCode MatGetSize(const Mat& m, PetscInt* M, PetscInt* N) { if (!m) return PETSC_ERR_ARG_CORRUPT; *M = *N = m->N(); return 0; }
+
+}  // namespace dmrgx_host
+
+using dmrgx_host::Mat;
+using dmrgx_host::Vec;
+using dmrgx_host::MatDestroy;
+using dmrgx_host::VecDestroy;
+using dmrgx_host::MatGetSize;
+
+#endif

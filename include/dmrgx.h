@@ -203,7 +203,8 @@ dmrgx_status dmrgx_rdm_destroy(dmrgx_rdm* rdm);
 /* ---- K6: operator rotation + dense-cell accumulate ------------------------------------------------------------ */
 /* dst[i*ldd + j] += alpha * src(i,j), src(i,j) = src[i*lds + j] or (transposed) src[j*lds + i]; nr x nc is the shape of
  * the DESTINATION rectangle.  Tasks whose destinations may overlap must carry the same dst_base (e.g. the owning
- * sector block): they are then applied in submission order; dst_base == NULL means "no overlap with other tasks". */
+ * sector block): they are then applied in submission order; dst_base == NULL means "no overlap with other tasks".
+ * src == NULL adds alpha to the diagonal of a square destination (scaled-identity source cell). */
 typedef struct {
     double* dst; const double* dst_base; const double* src;
     int64_t ldd, lds; int32_t nr, nc; int32_t transposed; double alpha;

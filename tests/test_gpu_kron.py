@@ -289,3 +289,37 @@ def test_cells_axpy_vs_numpy(mods):
     ref[5:45, 7:40] += 2.0 * A - 0.5 * B.T
     ref += Cm
     assert np.abs(Dd.cpu().numpy() - ref).max() < 1e-14
+
+
+@pytest.mark.parametrize("mode", ["few_left", "few_right"])
+def test_apply_when_one_side_has_fewer_distinct_operators(mods, mode):
+    """Both merge directions of the plan (terms grouped by the side with fewer distinct operators, the other side's
+    operators pre-summed): a mid-column cut where one site couples to every site of the other block, so the MERGED
+    operator holds several cells with the same output range (O (x) 1 cell + new-site identity cell)."""
+    sbm, wl, _ = mods
+    sb = wl.synthetic_superblock("cfg2", m=48, Ly=3, seed=77)
+    terms = []
+    for j in range(3):
+        for i in ([2] if mode == "few_left" else [0, 1, 2]):
+            jj = [j] if mode == "few_left" else [2]
+            for r in jj:
+                terms += [(0.7 + 0.1 * j, wl.OpSp, i, wl.OpSm, r), (0.7 + 0.1 * j, wl.OpSm, i, wl.OpSp, r), (0.3, wl.OpSz, i, wl.OpSz, r)]
+    sb.terms = terms
+    plan = sbm.KronPlan(sb)
+    ref = ShellApplyC(oracle_shell_from_superblock(sb))
+    x = np.random.default_rng(3).standard_normal(sb.n_states)
+    y, y_ref = _apply(plan, x), ref.apply(x)
+    assert np.abs(y - y_ref).max() <= RTOL * np.abs(y_ref).max()
+    for W in (2,):
+        plans = [sbm.KronPlan(sb, world_size=W, rank=r) for r in range(W)]
+        info = plans[0].info
+        xs = torch.zeros(info.vec_len, dtype=torch.float64, device="cuda")
+        plans[0].to_striped(torch.from_numpy(x).cuda(), xs)
+        ys = torch.zeros_like(xs)
+        for p in plans:
+            p.apply(xs, ys[p.info.local_offset:p.info.local_offset + p.info.local_len])
+        yd = torch.zeros(sb.n_states, dtype=torch.float64, device="cuda")
+        plans[0].from_striped(ys, yd)
+        torch.cuda.synchronize()
+        assert np.abs(yd.cpu().numpy() - y_ref).max() <= RTOL * np.abs(y_ref).max()
+    plan.destroy()
