@@ -58,6 +58,9 @@ def GetTruncation(kb, psi, MStates):
         spectra = [(e[3], e[0]) for e in eigen[side]]
         lst = sorted(eigen[side], key=lambda e: -e[0])       # stable_sort(greater_eigval) :1795
         m = min(MStates, len(lst))                            # :1819-1820
+        # test aid (not in the reference): the eigenvalues on both sides of the cut -- a parity comparison of the kept
+        # subspace is only well-defined when lam_kept_min is above round-off and separated from lam_dropped_max
+        cut = (lst[m - 1][0] if m > 0 else 0.0, lst[m][0] if m < len(lst) else 0.0)
         lst = lst[:m]
         lst = sorted(lst, key=lambda e: e[3])                 # stable_sort(less_blkIdx) :1852
         NStates = q.NumStates()
@@ -76,7 +79,7 @@ def GetTruncation(kb, psi, MStates):
             counts[e[3]] = counts.get(e[3], 0) + 1
         blks = sorted(counts)
         QN = QuantumNumbers([q.qn_list[b] for b in blks], [counts[b] for b in blks])
-        out.append(dict(RotMatT=RotMatT, QN=QN, TruncErr=trunc, spectra=spectra, kept=lst))
+        out.append(dict(RotMatT=RotMatT, QN=QN, TruncErr=trunc, spectra=spectra, kept=lst, cut=cut))
     return out[0], out[1]
 
 
@@ -130,7 +133,7 @@ class DMRGOracle:
                          NStates_SysRot=SysOut.NumStates(), NStates_EnvRot=EnvOut.NumStates(),
                          sectors_SysEnl=(SysEnl.Magnetization.qn_list, SysEnl.Magnetization.qn_size),
                          sectors_EnvEnl=(EnvEnl.Magnetization.qn_list, EnvEnl.Magnetization.qn_size),
-                         nterms=len(Terms))
+                         nterms=len(Terms), cut_Sys=BT_L["cut"], cut_Env=BT_R["cut"])
         if self.verbose:
             print(f"  [{loop} {self.GlobIdx}] sys {SysBlock.NumSites()} env {EnvBlock.NumSites()} "
                   f"N_sb {kb.NumStates()} E {gse:.12f} trunc {BT_L['TruncErr']:.3e}")
