@@ -4,7 +4,7 @@
 // KronBlock k, Psi = n_L x n_R row-major slice of psi (:1731), rho_L = Psi Psi^T, rho_R = Psi^T Psi (:1733-1734),
 // then EigRDM_BlockDiag = all eigenpairs of each block by LAPACK (:1962-2003).  Here all 2*nblocks matrices are
 // built by ONE launch of the grouped MFMA-f64 GEMM and diagonalised TOGETHER on the device by a batched two-sided
-// block-Jacobi method (block size 32): per round every matrix contributes nb/2 disjoint block pairs; a 64 x 64
+// block-Jacobi method (block size JB = 16): per round every matrix contributes nb/2 disjoint block pairs; a 32 x 32
 // sub-problem is solved by scalar Jacobi in LDS, then the rotation is applied to the block columns of A and V
 // and to the block rows of A.  Sorting, the global m-cut and the stable re-sort by sector (:1795,1850-1853) stay
 // on the host (caller), which fetches spectra with dmrgx_rdm_eigenvalues and asks for the kept eigenvectors with
@@ -18,12 +18,13 @@
 namespace dmrgx {
 namespace {
 
-constexpr int JB = 32, JS = 2 * JB;          // block size, sub-problem size
+constexpr int JB = 16, JS = 2 * JB;          // block size, sub-problem size (32 x 32 in LDS: ~12x cheaper per solve
+                                             // than 64 x 64 for 2x the rounds; the solve is LDS-instruction bound)
+constexpr int JT = JS / 16;                  // outputs per thread and dimension in the 16 x 16-thread LDS matmul
 constexpr int JLD = JS + 1;
 
 struct MatDesc { int64_t a_off, v_off; int32_t n, npad, nb, pad; };
 struct PairRef { int32_t mat, j; };
-struct TileRef { int32_t pair, tile; };
 
 __device__ __forceinline__ void pair_blocks(int nb, int r, int j, int& I, int& J)
 {
@@ -64,7 +65,7 @@ __global__ void __launch_bounds__(256) transpose_kernel(const TrTile* __restrict
     }
 }
 
-// Solve the 64 x 64 symmetric sub-problem of block pair (I,J) by cyclic Jacobi in LDS; R (row-major 64x64) such
+// Solve the JS x JS symmetric sub-problem of block pair (I,J) by cyclic Jacobi in LDS; R (row-major JS x JS) such
 // that R^T S R is diagonal is written to rbuf[pair].
 __global__ void __launch_bounds__(256)
 jacobi_sub_kernel(const MatDesc* __restrict__ mats, const PairRef* __restrict__ pairs, double* __restrict__ buf, double* __restrict__ rbuf, int round)
@@ -86,8 +87,8 @@ jacobi_sub_kernel(const MatDesc* __restrict__ mats, const PairRef* __restrict__ 
         R[i * JLD + j] = (i == j) ? 1.0 : 0.0;
     }
     __syncthreads();
-    for (int sweep = 0; sweep < 12; ++sweep) {
-        // convergence: off-diagonal mass relative to the diagonal (wave-uniform decision)
+    for (int sweep = 0; sweep < 8; ++sweep) {
+        // convergence: off-diagonal mass relative to the diagonal (wave-uniform decision); the outer sweeps finish the job
         double off = 0.0, dg = 0.0;
         for (int e = tid; e < JS * JS; e += 256) {
             const int i = e / JS, j = e % JS;
@@ -99,7 +100,7 @@ jacobi_sub_kernel(const MatDesc* __restrict__ mats, const PairRef* __restrict__ 
         __syncthreads();
         const double offt = red0[0] + red0[1] + red0[2] + red0[3], dgt = red1[0] + red1[1] + red1[2] + red1[3];
         __syncthreads();
-        if (offt <= 1e-32 * dgt) break;
+        if (offt <= 1e-26 * dgt) break;
         for (int rr = 0; rr < JS - 1; ++rr) {
             if (tid < JB) {
                 int p, q;
@@ -143,77 +144,81 @@ jacobi_sub_kernel(const MatDesc* __restrict__ mats, const PairRef* __restrict__ 
     for (int e = tid; e < JS * JS; e += 256) Rout[e] = R[(e / JS) * JLD + (e % JS)];
 }
 
-// out(64x64) = L(64x64) * M(64x64), all in LDS; thread computes a 4x4 block
-__device__ __forceinline__ void lds_mm64(const double* L, const double* M, double acc[4][4], int ty, int tx)
+// out(JS x JS) = L * M, all in LDS; 16 x 16 threads, each a JT x JT block
+__device__ __forceinline__ void lds_mm(const double* L, const double* M, double acc[JT][JT], int ty, int tx)
 {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < JT; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+        for (int j = 0; j < JT; ++j) acc[i][j] = 0.0;
     for (int k = 0; k < JS; ++k) {
-        double a[4], b[4];
+        double a[JT], b[JT];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) a[i] = L[(4 * ty + i) * JLD + k];
+        for (int i = 0; i < JT; ++i) a[i] = L[(JT * ty + i) * JLD + k];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) b[j] = M[k * JLD + 4 * tx + j];
+        for (int j = 0; j < JT; ++j) b[j] = M[k * JLD + JT * tx + j];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < JT; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] += a[i] * b[j];
+            for (int j = 0; j < JT; ++j) acc[i][j] += a[i] * b[j];
     }
 }
 
-// mode 0: X[rows of tile, cols(I,J)] <- X * R   for X = A and X = V     (grid.y = 2 selects A / V)
-// mode 1: A[rows(I,J), cols of tile] <- R^T * A
+// One launch per round applies all rotations of the round:
+//   kind 0 (A, two-sided): block (P,Q) of the pair-block partition:  A[P,Q] <- R_P^T . A[P,Q] . R_Q   -- every JS x JS block
+//                          of A is read and written by exactly one workgroup, so the column and the row update of the
+//                          textbook formulation fuse into one pass over A (half the launches, half the traffic);
+//   kind 1 (V, one-sided): rows [JS*t, JS*t+JS) x pair-block Q:      V[t,Q] <- V[t,Q] . R_Q
+struct UpdTask { int32_t mat, p, q, kind; };     // p: pair index (kind 0) or row tile (kind 1); q: pair index (both local to mat)
 __global__ void __launch_bounds__(256)
-jacobi_update_kernel(const MatDesc* __restrict__ mats, const PairRef* __restrict__ pairs, const TileRef* __restrict__ tiles,
-                     double* __restrict__ buf, const double* __restrict__ rbuf, int round, int mode)
+jacobi_update_kernel(const MatDesc* __restrict__ mats, const int32_t* __restrict__ pair_start, const UpdTask* __restrict__ tasks,
+                     double* __restrict__ buf, const double* __restrict__ rbuf, int round)
 {
-    __shared__ double L[JS * JLD], M[JS * JLD];
-    const TileRef tr = tiles[blockIdx.x];
-    const PairRef pr = pairs[tr.pair];
-    const MatDesc m = mats[pr.mat];
-    int I, J;
-    pair_blocks(m.nb, round, pr.j, I, J);
+    __shared__ double X[JS * JLD], RQ[JS * JLD], RP[JS * JLD];
+    const UpdTask t = tasks[blockIdx.x];
+    const MatDesc m = mats[t.mat];
     const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
-    const double* Rg = rbuf + (int64_t)tr.pair * JS * JS;
-    double* X = buf + ((mode == 0 && blockIdx.y == 1) ? m.v_off : m.a_off);
-    const int t0 = tr.tile * JS;
-    auto gidx = [&](int i) { return i < JB ? I * JB + i : J * JB + i - JB; };
-    if (mode == 0) {
-        for (int e = tid; e < JS * JS; e += 256) {
-            const int i = e / JS, j = e % JS;
-            L[i * JLD + j] = X[(int64_t)(t0 + i) * m.npad + gidx(j)];
-            M[i * JLD + j] = Rg[e];
-        }
-    } else {
-        for (int e = tid; e < JS * JS; e += 256) {
-            const int i = e / JS, j = e % JS;
-            L[j * JLD + i] = Rg[e];                                   // L = R^T
-            M[i * JLD + j] = X[(int64_t)gidx(i) * m.npad + t0 + j];
-        }
+    int IQ, JQ, IP = 0, JP = 0;
+    pair_blocks(m.nb, round, t.q, IQ, JQ);
+    if (t.kind == 0) pair_blocks(m.nb, round, t.p, IP, JP);
+    const double* Rq = rbuf + (int64_t)(pair_start[t.mat] + t.q) * JS * JS;
+    const double* Rp = rbuf + (int64_t)(pair_start[t.mat] + t.p) * JS * JS;
+    double* M = buf + (t.kind == 0 ? m.a_off : m.v_off);
+    auto cq = [&](int j) { return j < JB ? IQ * JB + j : JQ * JB + j - JB; };
+    auto rp = [&](int i) { return t.kind == 0 ? (i < JB ? IP * JB + i : JP * JB + i - JB) : t.p * JS + i; };
+    for (int e = tid; e < JS * JS; e += 256) {
+        const int i = e / JS, j = e % JS;
+        X[i * JLD + j] = M[(int64_t)rp(i) * m.npad + cq(j)];
+        RQ[i * JLD + j] = Rq[e];
+        if (t.kind == 0) RP[j * JLD + i] = Rp[e];                 // RP = R_P^T
     }
     __syncthreads();
-    double acc[4][4];
-    lds_mm64(L, M, acc, ty, tx);
+    double acc[JT][JT];
+    lds_mm(X, RQ, acc, ty, tx);                                   // X . R_Q
+    if (t.kind == 0) {
+        __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < JT; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int r = 4 * ty + i, c = 4 * tx + j;
-            if (mode == 0) X[(int64_t)(t0 + r) * m.npad + gidx(c)] = acc[i][j];
-            else X[(int64_t)gidx(r) * m.npad + t0 + c] = acc[i][j];
-        }
+            for (int j = 0; j < JT; ++j) X[(JT * ty + i) * JLD + JT * tx + j] = acc[i][j];
+        __syncthreads();
+        lds_mm(RP, X, acc, ty, tx);                               // R_P^T . (X . R_Q)
+    }
+#pragma unroll
+    for (int i = 0; i < JT; ++i)
+#pragma unroll
+        for (int j = 0; j < JT; ++j) M[(int64_t)rp(JT * ty + i) * m.npad + cq(JT * tx + j)] = acc[i][j];
 }
 
-// per matrix: out[2*mat] = sum of squares off the diagonal, out[2*mat+1] = on the diagonal
+// per matrix and block of the grid: out[(mat*NORM_BLOCKS + b)*2] = partial sum of squares off the diagonal, [..+1] = on it
+constexpr int NORM_BLOCKS = 32;
 __global__ void __launch_bounds__(256) offnorm_kernel(const MatDesc* __restrict__ mats, const double* __restrict__ buf, double* __restrict__ out)
 {
     __shared__ double r0[4], r1[4];
-    const MatDesc m = mats[blockIdx.x];
+    const MatDesc m = mats[blockIdx.y];
     double off = 0.0, dg = 0.0;
     const int64_t tot = (int64_t)m.npad * m.npad;
-    for (int64_t e = threadIdx.x; e < tot; e += 256) {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < tot; e += 256 * NORM_BLOCKS) {
         const int i = (int)(e / m.npad), j = (int)(e % m.npad);
         const double v = buf[m.a_off + e];
         if (i == j) dg += v * v; else off += v * v;
@@ -221,7 +226,10 @@ __global__ void __launch_bounds__(256) offnorm_kernel(const MatDesc* __restrict_
     for (int o = 32; o > 0; o >>= 1) { off += __shfl_down(off, o, 64); dg += __shfl_down(dg, o, 64); }
     if ((threadIdx.x & 63) == 0) { r0[threadIdx.x >> 6] = off; r1[threadIdx.x >> 6] = dg; }
     __syncthreads();
-    if (threadIdx.x == 0) { out[2 * blockIdx.x] = r0[0] + r0[1] + r0[2] + r0[3]; out[2 * blockIdx.x + 1] = r1[0] + r1[1] + r1[2] + r1[3]; }
+    if (threadIdx.x == 0) {
+        out[(blockIdx.y * NORM_BLOCKS + blockIdx.x) * 2] = r0[0] + r0[1] + r0[2] + r0[3];
+        out[(blockIdx.y * NORM_BLOCKS + blockIdx.x) * 2 + 1] = r1[0] + r1[1] + r1[2] + r1[3];
+    }
 }
 
 __global__ void diag_kernel(const MatDesc* __restrict__ mats, const double* buf, double* out, const int64_t* __restrict__ out_off)
@@ -241,12 +249,12 @@ __global__ void __launch_bounds__(256) normalize_columns_kernel(const MatDesc* _
     const int col = c0 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
     double* V = buf + m.v_off;
     double s = 0.0;
-    for (int i = rg; i < m.npad; i += 4) { const double v = V[(int64_t)i * m.npad + col]; s += v * v; }
+    if (col < m.npad) for (int i = rg; i < m.npad; i += 4) { const double v = V[(int64_t)i * m.npad + col]; s += v * v; }
     part[rg][threadIdx.x & 63] = s;
     __syncthreads();
     const double tot = part[0][threadIdx.x & 63] + part[1][threadIdx.x & 63] + part[2][threadIdx.x & 63] + part[3][threadIdx.x & 63];
     const double inv = tot > 0.0 ? 1.0 / sqrt(tot) : 0.0;
-    for (int i = rg; i < m.npad; i += 4) V[(int64_t)i * m.npad + col] *= inv;
+    if (col < m.npad) for (int i = rg; i < m.npad; i += 4) V[(int64_t)i * m.npad + col] *= inv;
 }
 
 // out[c] = sum_i W[i*ld + c]^2 for c < ncols  (Rayleigh quotients: lambda_c = |Psi^T u_c|^2)
@@ -322,18 +330,20 @@ extern "C" dmrgx_status dmrgx_rdm_create(const dmrgx_sectors* left, const dmrgx_
     const int64_t psiT_off = total; total += N;
     const int nm = (int)P->mats.size();
     std::vector<PairRef> pairs;
-    std::vector<TileRef> tiles;
+    std::vector<UpdTask> tiles;
+    std::vector<int32_t> pair_start(nm);
     int max_nb = 2;
     for (int mi = 0; mi < nm; ++mi) {
         const MatDesc& m = P->mats[mi];
         max_nb = std::max(max_nb, m.nb);
-        for (int j = 0; j < m.nb / 2; ++j) {
-            pairs.push_back(PairRef{mi, j});
-            for (int t = 0; t < m.npad / JS; ++t) tiles.push_back(TileRef{(int32_t)pairs.size() - 1, t});
-        }
+        pair_start[mi] = (int32_t)pairs.size();
+        const int np = m.nb / 2;
+        for (int j = 0; j < np; ++j) pairs.push_back(PairRef{mi, j});
+        for (int p = 0; p < np; ++p) for (int q = 0; q < np; ++q) tiles.push_back(UpdTask{mi, p, q, 0});
+        for (int t = 0; t < m.npad / JS; ++t) for (int q = 0; q < np; ++q) tiles.push_back(UpdTask{mi, t, q, 1});
     }
     const int64_t rbuf_off = total; total += (int64_t)pairs.size() * JS * JS;
-    const int64_t norm_off = total; total += 2 * nm;
+    const int64_t norm_off = total; total += 2 * nm * NORM_BLOCKS;
     std::vector<int64_t> diag_off(nm);
     int64_t dtot = 0;
     for (int mi = 0; mi < nm; ++mi) { diag_off[mi] = dtot; dtot += P->mats[mi].npad; }
@@ -342,10 +352,11 @@ extern "C" dmrgx_status dmrgx_rdm_create(const dmrgx_sectors* left, const dmrgx_
     const int64_t w_base = total; total += 2 * N;            // W = Psi^T V_L (n_R x n_L) and Psi V_R (n_L x n_R) per block
     DMRGX_CHK(P->buf.alloc((size_t)total * sizeof(double)));
     double* buf = P->buf.as<double>();
-    DevBuf d_pairs, d_tiles, d_doff;
+    DevBuf d_pairs, d_tiles, d_doff, d_pstart;
     DMRGX_CHK(upload(P->d_mats, P->mats, st));
     DMRGX_CHK(upload(d_pairs, pairs, st));
     DMRGX_CHK(upload(d_tiles, tiles, st));
+    DMRGX_CHK(upload(d_pstart, pair_start, st));
     for (auto& v : diag_off) v += diag_base;
     DMRGX_CHK(upload(d_doff, diag_off, st));
     const MatDesc* dm = P->d_mats.as<MatDesc>();
@@ -390,21 +401,26 @@ extern "C" dmrgx_status dmrgx_rdm_create(const dmrgx_sectors* left, const dmrgx_
     }
 
     // ---- batched block Jacobi ------------------------------------------------------------------------------------
-    std::vector<double> norms(2 * nm);
+    std::vector<double> norms((size_t)2 * nm * NORM_BLOCKS);
     const int rounds = std::max(1, max_nb - 1);
     int sweep = 0;
     for (; sweep < 30; ++sweep) {
-        hipLaunchKernelGGL(offnorm_kernel, dim3(nm), dim3(256), 0, st, dm, buf, buf + norm_off);
+        hipLaunchKernelGGL(offnorm_kernel, dim3(NORM_BLOCKS, nm), dim3(256), 0, st, dm, buf, buf + norm_off);
         DMRGX_HIP(hipGetLastError());
         DMRGX_HIP(hipMemcpyAsync(norms.data(), buf + norm_off, norms.size() * sizeof(double), hipMemcpyDeviceToHost, st));
         DMRGX_HIP(hipStreamSynchronize(st));
         bool conv = true;
-        for (int mi = 0; mi < nm; ++mi) if (norms[2 * mi] > 1e-30 * (norms[2 * mi] + norms[2 * mi + 1])) conv = false;
+        // off <= 1e-12 ||A||_F: V is a product of rotations (orthogonal to round-off whatever the convergence) and the
+        // eigenvalues are re-evaluated as Rayleigh quotients below, whose error is O(off^2)
+        for (int mi = 0; mi < nm; ++mi) {
+            double off2 = 0.0, dg2 = 0.0;
+            for (int b = 0; b < NORM_BLOCKS; ++b) { off2 += norms[(size_t)(mi * NORM_BLOCKS + b) * 2]; dg2 += norms[(size_t)(mi * NORM_BLOCKS + b) * 2 + 1]; }
+            if (off2 > 1e-24 * (off2 + dg2)) conv = false;
+        }
         if (conv) break;
         for (int r = 0; r < rounds; ++r) {
             hipLaunchKernelGGL(jacobi_sub_kernel, dim3((unsigned)pairs.size()), dim3(256), 0, st, dm, d_pairs.as<PairRef>(), buf, buf + rbuf_off, r);
-            hipLaunchKernelGGL(jacobi_update_kernel, dim3((unsigned)tiles.size(), 2), dim3(256), 0, st, dm, d_pairs.as<PairRef>(), d_tiles.as<TileRef>(), buf, buf + rbuf_off, r, 0);
-            hipLaunchKernelGGL(jacobi_update_kernel, dim3((unsigned)tiles.size(), 1), dim3(256), 0, st, dm, d_pairs.as<PairRef>(), d_tiles.as<TileRef>(), buf, buf + rbuf_off, r, 1);
+            hipLaunchKernelGGL(jacobi_update_kernel, dim3((unsigned)tiles.size()), dim3(256), 0, st, dm, d_pstart.as<int32_t>(), d_tiles.as<UpdTask>(), buf, buf + rbuf_off, r);
             DMRGX_HIP(hipGetLastError());
         }
     }
@@ -414,7 +430,7 @@ extern "C" dmrgx_status dmrgx_rdm_create(const dmrgx_sectors* left, const dmrgx_
     {
         int max_npad = JS;
         for (auto& m : P->mats) max_npad = std::max(max_npad, m.npad);
-        hipLaunchKernelGGL(normalize_columns_kernel, dim3(max_npad / 64, nm), dim3(256), 0, st, dm, buf);
+        hipLaunchKernelGGL(normalize_columns_kernel, dim3((max_npad + 63) / 64, nm), dim3(256), 0, st, dm, buf);
         DMRGX_HIP(hipGetLastError());
     }
     // ---- eigenvalues as Rayleigh quotients of the renormalised eigenvectors: lambda = |Psi^T u|^2 (rho_L) / |Psi v|^2

@@ -190,7 +190,9 @@ def test_rdm_spectra_and_eigenvectors_vs_lapack(mods, sizes):
             n = rho.shape[0]
             U = rdm.eigenvectors(side, k, n).cpu().numpy()          # rows = eigenvectors
             assert np.abs(U @ U.T - np.eye(n)).max() < 1e-13
-            assert np.abs(U @ rho @ U.T - np.diag(w)).max() < 3e-15 * n * np.abs(w).max() + 1e-16
+            # design tolerance of the block-Jacobi stop: off-diagonal <= 1e-12 ||rho||_F (eigenvalues are Rayleigh quotients,
+            # second order in that; V stays orthogonal to round-off)
+            assert np.abs(U @ rho @ U.T - np.diag(w)).max() < 1e-11 * np.linalg.norm(rho) + 1e-16
             tot[side] += w.sum()
     assert abs(tot[0] - 1.0) < 1e-13 and abs(tot[1] - 1.0) < 1e-13      # Tr rho = <psi|psi>
     rdm.destroy()
