@@ -20,6 +20,8 @@ namespace {
 
 constexpr int JB = 16, JS = 2 * JB;          // block size, sub-problem size (32 x 32 in LDS: ~12x cheaper per solve
                                              // than 64 x 64 for 2x the rounds; the solve is LDS-instruction bound)
+constexpr int JACOBI_INNER_SWEEPS = 1;       // partial sub-solves: the serial LDS Jacobi is the round's critical path, and
+                                             // two cyclic sweeps per visit cost fewer total microseconds than full solves
 constexpr int JT = JS / 16;                  // outputs per thread and dimension in the 16 x 16-thread LDS matmul
 constexpr int JLD = JS + 1;
 
@@ -87,7 +89,7 @@ jacobi_sub_kernel(const MatDesc* __restrict__ mats, const PairRef* __restrict__ 
         R[i * JLD + j] = (i == j) ? 1.0 : 0.0;
     }
     __syncthreads();
-    for (int sweep = 0; sweep < 8; ++sweep) {
+    for (int sweep = 0; sweep < JACOBI_INNER_SWEEPS; ++sweep) {
         // convergence: off-diagonal mass relative to the diagonal (wave-uniform decision); the outer sweeps finish the job
         double off = 0.0, dg = 0.0;
         for (int e = tid; e < JS * JS; e += 256) {

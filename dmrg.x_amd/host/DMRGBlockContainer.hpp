@@ -388,7 +388,11 @@ public:
         }
         dmrgx_sectors sl{(int32_t)ls.size(), ls.data()}, sr{(int32_t)rs.size(), rs.data()};
         dmrgx_rdm* rdm = nullptr;
+        PetscLogDouble tr0, tr1;
+        PetscTime(&tr0);
         if (dmrgx_rdm_create(&sl, &sr, (int32_t)nb, bil.data(), bir.data(), gsv_r->buf->dev_ro(), nullptr, &rdm)) SETERRQ1(mpi_comm, 1, "dmrgx_rdm_create: %s", dmrgx_last_error());
+        PetscTime(&tr1);
+        if (!mpi_rank && verbose) { int32_t nsw = 0; dmrgx_rdm_info(rdm, &nsw); printf("  RDM: %lld KronBlocks, block-Jacobi sweeps %d, create %.6f s\n", LLD(nb), nsw, tr1 - tr0); }
         BasisTransformation* BT[2] = {&BT_L, &BT_R};
         for (int side = 0; side < 2; ++side) {
             std::vector<Eigen_t> eigen;
