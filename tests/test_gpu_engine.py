@@ -69,8 +69,11 @@ def test_step_by_step_parity_with_oracle_under_truncation(tmp_path):
         for key in ("NSites_Sys", "NSites_Env", "NStates_SysEnl", "NStates_EnvEnl", "NumStates_H", "NStates_SysRot", "NStates_EnvRot"):
             assert r[key] == o[key], (r["GlobIdx"], key)
         assert abs(r["GSEnergy"] - o["GSEnergy"]) <= 1e-10 * abs(o["GSEnergy"]), r["GlobIdx"]
+        # TruncErr = 1 - (sum of kept eigenvalues) is first-order sensitive to the ground-state vector: the engine's Lanczos
+        # stops at ||r|| <= 1e-13 |E| while the oracle diagonalises densely, so |d psi| ~ 1e-12 moves TruncErr by
+        # ~ |d psi| sqrt(TruncErr) ~ 1e-13 in absolute terms, on top of the 1e-10 relative bar
         for side in ("TruncErr_Sys", "TruncErr_Env"):
-            assert abs(r[side] - o[side]) <= 1e-10 * abs(o[side]) + 1e-14, (r["GlobIdx"], side, r[side], o[side])
+            assert abs(r[side] - o[side]) <= 1e-10 * abs(o[side]) + 1e-13, (r["GlobIdx"], side, r[side], o[side])
     assert max(o["TruncErr_Sys"] for o in orc.steps) > 1e-4               # the truncation was real
     assert run["MatMults"] > 0 and timings["headers"][-1] == "MatMults"
 
