@@ -38,7 +38,8 @@ __device__ __forceinline__ void pair_blocks(int nb, int r, int j, int& I, int& J
     if (I > J) { const int t = I; I = J; J = t; }
 }
 
-// A <- 0 with -1 on the padding diagonal; V <- identity
+// A <- 0 on the padding (it stays exactly decoupled: rotations with a_pq == 0 are skipped, so the real eigenvectors are
+// the columns [0,n) of V and the convergence norms only see the real matrix); V <- identity
 __global__ void rdm_init_kernel(const MatDesc* __restrict__ mats, double* __restrict__ buf)
 {
     const MatDesc m = mats[blockIdx.y];
@@ -46,7 +47,7 @@ __global__ void rdm_init_kernel(const MatDesc* __restrict__ mats, double* __rest
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (int64_t)gridDim.x * blockDim.x) {
         const int i = (int)(e / m.npad), j = (int)(e % m.npad);
         buf[m.v_off + e] = (i == j) ? 1.0 : 0.0;
-        if (i >= m.n || j >= m.n) buf[m.a_off + e] = (i == j) ? -1.0 : 0.0;
+        if (i >= m.n || j >= m.n) buf[m.a_off + e] = 0.0;
     }
 }
 
