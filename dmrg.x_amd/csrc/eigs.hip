@@ -10,8 +10,8 @@
 //   multi_axpy: w -= V c ; ||w||^2                   (reads j+2 vectors, writes w)
 // repeated once (CGS2).  Nothing is copied to the host inside a restart cycle: the normalisation reads beta^2
 // from device memory, and the host fetches the projected matrix once per cycle (ncv/2 MatMults).
-// world_size > 1: vectors are this rank's stripe segment; the three reductions per pass go through one
-// stream-ordered all-reduce hook, and the Krylov vector is all-gathered before every MatMult.
+// world_size > 1: vectors are this rank's stripe segment; per Lanczos step there are exactly two fused all-reduces (of
+// j+2 doubles each) and one all-gather of the Krylov vector before the MatMult.
 #include "common.h"
 #include <algorithm>
 #include <chrono>
@@ -97,6 +97,13 @@ multi_axpy_kernel(const double* __restrict__ V, int64_t ldv, int nv, const doubl
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = nrm;
     __syncthreads();
     if (threadIdx.x == 0) { double t = 0.0; for (int k = 0; k < DOT_THREADS / 64; ++k) t += red[k]; partial[blockIdx.x] = t; }
+}
+
+// ||w - V c||^2 = w.w - |c|^2 for orthonormal V and c = V^T w (c is the tiny refinement coefficient vector of the second
+// Gram-Schmidt pass, so there is no cancellation): saves a reduction pass and, distributed, one all-reduce per step.
+__global__ void norm_after_projection_kernel(const double* __restrict__ c, int nv, double* __restrict__ nrm2)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) { double s = c[nv]; for (int i = 0; i < nv; ++i) s -= c[i] * c[i]; *nrm2 = s > 0.0 ? s : 0.0; }
 }
 
 // dst = src * (nrm2 > tiny ? 1/sqrt(nrm2) : 0)
@@ -241,12 +248,12 @@ extern "C" dmrgx_status dmrgx_eigs_lowest(dmrgx_kron_plan* plan, const dmrgx_eig
         DMRGX_HIP(hipGetLastError());
         return allreduce(c1, nv + 1);
     };
-    auto multi_axpy = [&](int nv, double* hacc) -> dmrgx_status {
+    // final == false: only subtract.  final == true: also set nrm = ||w_new||^2 from the dots just reduced.
+    auto multi_axpy = [&](int nv, double* hacc, bool final) -> dmrgx_status {
+        if (final) { hipLaunchKernelGGL(norm_after_projection_kernel, dim3(1), dim3(64), 0, st, c1, nv, nrm); DMRGX_HIP(hipGetLastError()); }
         hipLaunchKernelGGL(multi_axpy_kernel, dim3(DOT_BLOCKS), dim3(DOT_THREADS), 0, st, V, n, nv, c1, w, n, dPartial.as<double>(), hacc);
         DMRGX_HIP(hipGetLastError());
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(DOT_THREADS), 0, st, dPartial.as<double>(), nrm, 1);
-        DMRGX_HIP(hipGetLastError());
-        return allreduce(nrm, 1);
+        return DMRGX_OK;
     };
     auto normalise_into = [&](double* dst) -> dmrgx_status {
         hipLaunchKernelGGL(scale_copy_kernel, dim3(1024), dim3(256), 0, st, w, dst, n, nrm);
@@ -292,10 +299,10 @@ extern "C" dmrgx_status dmrgx_eigs_lowest(dmrgx_kron_plan* plan, const dmrgx_eig
         for (int j = k; j < jend; ++j) {
             DMRGX_CHK(matvec(vec(j), w));
             ++n_matvec;
-            DMRGX_CHK(multi_dot(j + 1));                      // pass 1
-            DMRGX_CHK(multi_axpy(j + 1, Hrow(j)));
-            DMRGX_CHK(multi_dot(j + 1));                      // pass 2 (refinement)
-            DMRGX_CHK(multi_axpy(j + 1, Hrow(j)));
+            DMRGX_CHK(multi_dot(j + 1));                      // pass 1: c = V^T w                (one fused all-reduce)
+            DMRGX_CHK(multi_axpy(j + 1, Hrow(j), false));
+            DMRGX_CHK(multi_dot(j + 1));                      // pass 2: refinement, c2 = V^T w', w'.w' (one fused all-reduce)
+            DMRGX_CHK(multi_axpy(j + 1, Hrow(j), true));     //         beta^2 = w'.w' - |c2|^2
             DMRGX_HIP(hipMemcpyAsync(Hrow(j) + m + 1, nrm, sizeof(double), hipMemcpyDeviceToDevice, st));
             DMRGX_CHK(normalise_into(vec(j + 1)));
         }

@@ -81,3 +81,14 @@ def test_step_by_step_parity_with_oracle_under_truncation(tmp_path):
 def test_driver_fails_loudly_on_bad_options(tmp_path):
     out = subprocess.run([EXE, "-Lx", "3", "-Ly", "1", "-mwarmup", "8", "-data_dir", str(tmp_path) + "/"], capture_output=True, text=True, timeout=60)
     assert out.returncode != 0 and "must be even" in out.stderr
+
+
+def test_two_rank_eigensolve_on_one_gpu():
+    """N>1 path end to end on one GPU: two processes, striped plans (world_size 2), host-staged gloo collectives."""
+    import sys
+    script = os.path.join(ROOT, "tests", "dist_eigs_worker.py")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29641", PYTHONPATH=ROOT)
+    procs = [subprocess.Popen([sys.executable, script, str(r), "2"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)[-3000:]
+    assert "two-rank eigensolve ok" in outs[0]
