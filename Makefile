@@ -11,7 +11,7 @@ HIP_OBJS   := $(HIP_SRCS:.hip=.o)
 HOST       := $(PKG)/host
 HOST_HDRS  := $(wildcard $(HOST)/*.hpp) include/dmrgx.h
 
-all: $(PKG)/libdmrgx_hip.so $(PKG)/dmrgx-square-lattice oracle/liboracle_kron.so
+all: $(PKG)/libdmrgx_hip.so $(PKG)/dmrgx-square-lattice $(PKG)/dmrgx-host-tool oracle/liboracle_kron.so
 
 $(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/ggemm.h include/dmrgx.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
@@ -23,6 +23,10 @@ $(PKG)/libdmrgx_hip.so: $(HIP_OBJS)
 $(PKG)/dmrgx-square-lattice: $(HOST)/DMRG-SquareLattice.cpp $(HOST_HDRS) $(PKG)/libdmrgx_hip.so
 	g++ -std=c++17 -O2 -Wall -Wno-unused-variable -Iinclude -I$(HOST) $< -L$(PKG) -ldmrgx_hip -Wl,-rpath,'$$ORIGIN' -o $@
 
+# host-logic test harness (runs without a GPU)
+$(PKG)/dmrgx-host-tool: $(HOST)/host_tool.cpp $(HOST_HDRS) $(PKG)/libdmrgx_hip.so
+	g++ -std=c++17 -O1 -Wall -Wno-unused-variable -Iinclude -I$(HOST) $< -L$(PKG) -ldmrgx_hip -Wl,-rpath,'$$ORIGIN' -o $@
+
 # the reference's own driver source must compile against these headers (only where the reference tree is present)
 dropin-check:
 	g++ -std=c++17 -fsyntax-only -Iinclude -I$(HOST) /root/reference/src/DMRG-SquareLattice.cpp && echo "drop-in OK: reference src/DMRG-SquareLattice.cpp compiles against dmrg.x_amd/host headers"
@@ -32,6 +36,6 @@ oracle/liboracle_kron.so: oracle/kron_ref.c
 	gcc -O3 -march=x86-64-v3 -fopenmp -shared -fPIC $< -o $@
 
 clean:
-	rm -f $(HIP_OBJS) $(PKG)/libdmrgx_hip.so $(PKG)/dmrgx-square-lattice oracle/liboracle_kron.so
+	rm -f $(HIP_OBJS) $(PKG)/libdmrgx_hip.so $(PKG)/dmrgx-square-lattice $(PKG)/dmrgx-host-tool oracle/liboracle_kron.so
 
 .PHONY: all clean dropin-check

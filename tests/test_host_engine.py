@@ -1,0 +1,109 @@
+"""CPU suite: host logic of the C++ engine (dmrg.x_amd/host/*.hpp) replayed through dmrgx-host-tool -- no GPU involved.
+The reference's known-answer tables are applied to the ENGINE here (tests/test_oracle_golden.py applies them to the oracle)."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle.hamiltonian import J1J2XXZModel_SquareLattice
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOOL = os.path.join(ROOT, "dmrg.x_amd", "dmrgx-host-tool")
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def tool(lines):
+    out = subprocess.run([TOOL], input="\n".join(lines) + "\n", capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return out.stdout.splitlines()
+
+
+def block_lines(name, d):
+    L = [f"block {name} {d['nsites']} {len(d['qn_list'])} " + " ".join(map(str, d["qn_list"])) + " " + " ".join(map(str, d["qn_size"]))]
+    for op in ("Sz", "Sp"):
+        for site, rows in d[op].items():
+            for row, cols in rows.items():
+                for c in cols:
+                    L.append(f"set {name} {op} {site} {row} {c} {float(c)}")      # SetRow: value == column index
+    return L
+
+
+def parse_dump(lines):
+    ops, cur = {}, None
+    for ln in lines:
+        t = ln.split()
+        if t[0] == "op":
+            cur = (t[1], int(t[2]))
+            ops[cur] = {}
+        elif t[0] == "row" and cur:
+            ops[cur][int(t[1])] = {int(a.split(":")[0]): float(a.split(":")[1]) for a in t[2:]}
+    return ops
+
+
+def test_engine_kroneye_matches_reference_table():
+    """tests/UnitTests_DMRGKron.cpp:39-252 on the engine's KronEye_Explicit (sector merging + index formula)."""
+    g = json.load(open(os.path.join(GOLD, "testkron01.json")))
+    out = tool(block_lines("L", g["left"]) + block_lines("R", g["right"]) + ["kroneye L R O", "check O", "dump O"])
+    rcs = [ln for ln in out if ln.startswith("rc ")]
+    assert all(ln == "rc 0" for ln in rcs), rcs
+    sect = next(ln for ln in out if ln.startswith("sectors")).split()
+    assert sect[1:] == ["4", "1.5", "0.5", "-0.5", "-1.5", "2", "5", "4", "1"]
+    ops = parse_dump(out)
+    n = 0
+    for opname in ("Sz", "Sp"):
+        for site, rows in g["expected"][opname].items():
+            for row, exp in rows.items():
+                want = {c: v for c, v in zip(exp["cols"], exp["vals"]) if v != 0.0}     # dense cells carry no structural zeros
+                assert ops[(opname, int(site))].get(int(row), {}) == want, (opname, site, row)
+                n += 1
+    assert n == 120
+
+
+def test_engine_block_checks_and_planted_error():
+    """tests/UnitTests_DMRGBlock.cpp:76-131: valid patterns pass; an entry outside its sector block is refused with
+    PETSC_ERR_ARG_OUTOFRANGE (63) -- in the engine at insertion time, since cells cannot hold such an entry."""
+    f = json.load(open(os.path.join(GOLD, "block_fixture.json")))
+    d = dict(nsites=f["nsites"], qn_list=f["qn_list"], qn_size=f["qn_size"], Sz={"0": f["valid"]["SetSz0"], "1": f["valid"]["SetSz1"]},
+             Sp={"0": f["valid"]["SetSp0"], "1": f["valid"]["SetSp1"]})
+    out = tool(block_lines("B", d) + ["check B"])
+    assert all(ln == "rc 0" for ln in out if ln.startswith("rc "))
+    bad = f["planted_bad"]
+    out = tool([f"block B {f['nsites']} 4 " + " ".join(map(str, f["qn_list"])) + " " + " ".join(map(str, f["qn_size"])),
+                f"set B Sz {bad['site']} {bad['row']} 1 1.0", "set B Sz 1 7 7 7.0", "qnrange B 3 1", "qnrange B 1 1"])
+    assert out[1] == f"rc {bad['expect_code']}" and out[2] == "rc 0"
+    assert out[3].split()[-1] == "0" and out[4] == "rc 0 5 7 1"
+
+
+def test_engine_single_site_and_kronblocks_order():
+    # (enlarging blocks that carry a Hamiltonian needs the device: covered by tests/test_gpu_engine.py)
+    out = tool(["single A", "single B", "dump A", "kronblocks A B", "kronblocks A B 0",
+                "block P 2 2 0.5 -0.5 1 1", "block Q 2 2 0.5 -0.5 1 1", "kroneye P Q C", "dump C"])
+    ops = parse_dump(out)
+    assert ops[("Sz", 0)] == {0: {0: 0.5}, 1: {1: -0.5}} and ops[("Sp", 0)] == {0: {1: 1.0}, 1: {}}
+    kb_all = next(ln for ln in out if ln.startswith("kronblocks 4"))
+    assert kb_all.split()[3:] == ["0,0,1,0", "0,1,1,1", "1,0,1,2", "1,1,1,3"]          # stable sort by descending Sz
+    kb0 = [ln for ln in out if ln.startswith("kronblocks 2")][0]
+    assert kb0.split()[3:] == ["0,1,1,0", "1,0,1,1"]                                    # target Sz=0: nested IL-then-IR order
+    sect = [ln for ln in out if ln.startswith("sectors")][-1].split()
+    assert sect[1:] == ["3", "1", "0", "-1", "1", "2", "1"]
+
+
+@pytest.mark.parametrize("opts", [dict(Lx=16, Ly=1, heisenberg=1.0), dict(Lx=4, Ly=2, heisenberg=1.0), dict(Lx=4, Ly=4, J1=1, Jz1=1, J2=0.5, Jz2=0.5),
+                                  dict(Lx=4, Ly=4), dict(Lx=6, Ly=3, J1=1, Jz1=0.3, J2=0.5, Jz2=0.2, BCperiodic=True), dict(Lx=5, Ly=4, J1=1, Jz1=1, J2=1, Jz2=1, BCopen=True)])
+def test_engine_hamiltonian_terms_match_oracle(opts):
+    """Hamiltonians::J1J2XXZModel_SquareLattice::H(n) of the engine == the oracle's restatement of
+    src/Hamiltonians.cpp:70-122, term by term and in order, for full and partial lattices."""
+    H = J1J2XXZModel_SquareLattice(**opts)
+    args = []
+    for k, v in opts.items():
+        args += [f"-{k}", "_" if v is True else str(v)]
+    ns = H.NumSites()
+    out = tool(["ham " + " ".join(args), "terms -1", f"terms {ns // 2}", f"terms {ns - 3}", "snake"])
+    for ln, n in zip(out[1:4], (None, ns // 2, ns - 3)):
+        got = [tuple(float(x) if i == 0 else int(x) for i, x in enumerate(t.split(","))) for t in ln.split()[2:]]
+        want = [(t.a, t.Iop, t.Isite, t.Jop, t.Jsite) for t in H.H(n)]
+        assert got == want
+    snake = [tuple(int(x) for x in t.split(",")) for t in out[4].split()[1:]]
+    assert all(H.To2D(i) == (ix, jy) and idx == i for i, (ix, jy, idx) in enumerate(snake))
