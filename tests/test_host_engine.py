@@ -80,7 +80,7 @@ def test_engine_single_site_and_kronblocks_order():
     # (enlarging blocks that carry a Hamiltonian needs the device: covered by tests/test_gpu_engine.py)
     out = tool(["single A", "single B", "dump A", "kronblocks A B", "kronblocks A B 0",
                 "block P 2 2 0.5 -0.5 1 1", "block Q 2 2 0.5 -0.5 1 1", "kroneye P Q C", "dump C"])
-    ops = parse_dump(out)
+    ops = parse_dump(out[:out.index("end") + 1])                 # the dump of A (the dump of C follows later)
     assert ops[("Sz", 0)] == {0: {0: 0.5}, 1: {1: -0.5}} and ops[("Sp", 0)] == {0: {1: 1.0}, 1: {}}
     kb_all = next(ln for ln in out if ln.startswith("kronblocks 4"))
     assert kb_all.split()[3:] == ["0,0,1,0", "0,1,1,1", "1,0,1,2", "1,1,1,3"]          # stable sort by descending Sz
