@@ -6,6 +6,7 @@
 // MatMult (both stages), the reduced-density-matrix build and the rotation GEMMs.
 #pragma once
 #include "common.h"
+#include <algorithm>
 
 namespace dmrgx {
 
@@ -37,30 +38,38 @@ constexpr int GG_BM = 64, GG_BN = 64, GG_BK = 16, GG_THREADS = 256;
 // (coordinates still in 64-units), else 64 x 64.
 dmrgx_status ggemm_launch(const GTile* d_tiles, const GGroup* d_groups, const GProd* d_prods, int32_t ntiles, hipStream_t st, int big = 0);
 
-// Host-side helper: append the tiles of group `g` (M x N) to a tile list; `cost` (k-steps of the group's product
-// list) is stored in GTile::pad for the scheduler.
+// Host-side helper: append the tiles of group `g` (M x N) to a tile list in 4 x 4 clusters (tiles of a cluster share
+// A row-panels and B column-panels; the scheduler keeps a cluster on one XCD so they meet in its L2); `cost` (k-steps of
+// the group's product list) is stored in GTile::pad for the scheduler.
+constexpr int GG_CLUSTER = 4;
 inline void ggemm_append_tiles(std::vector<GTile>& tiles, int32_t g, int32_t M, int32_t N, int32_t cost = 1) {
-    for (int32_t tm = 0; tm < (M + GG_BM - 1) / GG_BM; ++tm)
-        for (int32_t tn = 0; tn < (N + GG_BN - 1) / GG_BN; ++tn) tiles.push_back(GTile{g, tm, tn, cost});
+    const int32_t TM = (M + GG_BM - 1) / GG_BM, TN = (N + GG_BN - 1) / GG_BN;
+    for (int32_t bm = 0; bm < TM; bm += GG_CLUSTER)
+        for (int32_t bn = 0; bn < TN; bn += GG_CLUSTER)
+            for (int32_t tm = bm; tm < std::min(TM, bm + GG_CLUSTER); ++tm)
+                for (int32_t tn = bn; tn < std::min(TN, bn + GG_CLUSTER); ++tn) tiles.push_back(GTile{g, tm, tn, cost});
 }
 
-// Mixed tiling: the [0, 128*floor(M/128)) x [0, 128*floor(N/128)) core of a group goes to the 128 x 128 kernel,
-// the right and bottom remainders (< 128 wide) to the 64 x 64 kernel, so padding waste stays that of 64-tiles.
 // DMRGX_TILES=64 (environment) disables the 128 x 128 kernel, DMRGX_TILES=mixed enables it for the superblock plan.
 bool ggemm_use_big_tiles();
 inline void ggemm_append_tiles_mixed(std::vector<GTile>& big, std::vector<GTile>& small, int32_t g, int32_t M, int32_t N, int32_t cost = 1, bool allow_big = true) {
     const int32_t mb = allow_big ? (M / 128) * 2 : 0, nb = allow_big ? (N / 128) * 2 : 0;   // core extent in 64-units
-    for (int32_t tm = 0; tm < mb; tm += 2)
-        for (int32_t tn = 0; tn < nb; tn += 2) big.push_back(GTile{g, tm, tn, 4 * cost});
-    for (int32_t tm = 0; tm < (M + GG_BM - 1) / GG_BM; ++tm)
-        for (int32_t tn = 0; tn < (N + GG_BN - 1) / GG_BN; ++tn)
-            if (tm >= mb || tn >= nb) small.push_back(GTile{g, tm, tn, cost});
+    for (int32_t bm = 0; bm < mb; bm += 2 * GG_CLUSTER)
+        for (int32_t bn = 0; bn < nb; bn += 2 * GG_CLUSTER)
+            for (int32_t tm = bm; tm < std::min(mb, bm + 2 * GG_CLUSTER); tm += 2)
+                for (int32_t tn = bn; tn < std::min(nb, bn + 2 * GG_CLUSTER); tn += 2) big.push_back(GTile{g, tm, tn, 4 * cost});
+    const int32_t TM = (M + GG_BM - 1) / GG_BM, TN = (N + GG_BN - 1) / GG_BN;
+    for (int32_t bm = 0; bm < TM; bm += GG_CLUSTER)
+        for (int32_t bn = 0; bn < TN; bn += GG_CLUSTER)
+            for (int32_t tm = bm; tm < std::min(TM, bm + GG_CLUSTER); ++tm)
+                for (int32_t tn = bn; tn < std::min(TN, bn + GG_CLUSTER); ++tn)
+                    if (tm >= mb || tn >= nb) small.push_back(GTile{g, tm, tn, cost});
 }
 
 // XCD-aware, cost-balanced launch order.  Blocks b, b+8, b+16.. run on one XCD (each XCD has its own L2), so the
 // list is rebuilt as 8 interleaved per-XCD lists: clusters of tiles that share an A row-panel (same group and
 // tile row) stay on one XCD for L2 reuse, clusters are dealt longest-first to the least-loaded XCD (LPT), and each
 // XCD runs its longest clusters first so the tail is made of short tiles.  Lists are padded with group = -1.
-void ggemm_schedule(std::vector<GTile>& tiles);
+void ggemm_schedule(std::vector<GTile>& tiles, int unit = 1);   // unit = 2 for lists of 128 x 128 tiles
 
 }  // namespace dmrgx

@@ -50,16 +50,19 @@ ggemm_kernel(const GTile* __restrict__ tiles, const GGroup* __restrict__ groups,
     __shared__ double As[2][BM * AS_LD];
     __shared__ double Bs[2][BK * BS_LD];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index in an SGPR
     const GTile tile = tiles[blockIdx.x];
     if (tile.group < 0) return;
     const GGroup g = groups[tile.group];
     const int m0 = tile.tm * GG_BM, n0 = tile.tn * GG_BN;        // tile coordinates are in 64-units for both shapes
     const int mrem = min(BM, g.M - m0), nrem = min(BN, g.N - n0);
-    const bool full_mn = (mrem == BM) && (nrem == BN);
     const int wr = wave / WC, wc = wave % WC;
     const int l15 = lane & 15, l4 = lane >> 4;
     const int wrow = wr * 16 * TR, wcol = wc * 16 * TC;           // wave sub-tile origin
+    // 16 x 16 accumulator blocks of this wave that intersect the output (edge tiles): blocks outside are never
+    // multiplied, so ragged sector sizes cost MFMA time at 16-granularity, not at tile granularity (wave-uniform).
+    const int tr_eff = min(TR, max(0, (mrem - wrow + 15) >> 4)), tc_eff = min(TC, max(0, (nrem - wcol + 15) >> 4));
+    const bool wave_full = (tr_eff == TR) && (tc_eff == TC);
 
     d4 acc[TR][TC];
 #pragma unroll
@@ -84,8 +87,18 @@ ggemm_kernel(const GTile* __restrict__ tiles, const GGroup* __restrict__ groups,
     }
 
     // ---- GEMM stream ------------------------------------------------------------------------------------
+    // The MFMA pipe and the ordinary VALU do not co-issue on a SIMD (SQ_VALU_MFMA_COEXEC_CYCLES = 0 on gfx950), so every
+    // vector integer instruction in the k-step loop is MFMA time lost.  The steady-state k-step therefore contains no
+    // VALU work besides the MFMAs: per-thread byte offsets are computed once per product (aoff/boff), the wave-uniform
+    // base advances in SGPRs, and the LDS buffer index is a compile-time constant (loop unrolled by two) so that all LDS
+    // addresses are loop invariants.
     const int a_r = tid >> 4, a_k = tid & 15;      // A loader: rows a_r + AROWS s, column a_k (128 B per 16 lanes)
     const int b_k = tid / BN, b_j = tid % BN;      // B loader: rows b_k + BROWS s, column b_j (512 B per wave)
+    // Ragged M / N edges need no masking: a row of A beyond mrem only feeds rows of C beyond mrem, a column of B beyond
+    // nrem only columns beyond nrem, and the epilogue never stores those -- the loaders just clamp to the last valid
+    // row / column so that every address is in bounds.  Only the K edge is zeroed (last k-step of a product).
+    const int bcol = min(b_j, nrem - 1);
+    unsigned aoff[NA], boff[NB];                   // per-thread byte offsets inside the current product's panels
     double ra[NA], rb[NB];
     const int pend = g.prod_end;
     int k0 = 0;
@@ -93,30 +106,29 @@ ggemm_kernel(const GTile* __restrict__ tiles, const GGroup* __restrict__ groups,
     int clda = 0, cldb = 0, cK = 0;
 
 // Operand pointers come out of the task table, so the compiler would treat them as generic and emit flat_load
-// (+ lgkmcnt waits that serialise against LDS); they are global by construction -> explicit address space.
-// Interior k-steps (full tile, full BK) take a uniform fast path with plain loads; edge k-steps load from clamped,
-// always-valid addresses and zero the out-of-range elements by a 0/1 multiply (a select would let the compiler sink
-// each load under its own exec-mask branch and wait on it individually).
+// (+ lgkmcnt waits that serialise against LDS); they are global by construction -> explicit address space, and the
+// loads are "uniform base + 32-bit per-thread offset".
+#define GG_PRODUCT(P)                                                                         \
+    {                                                                                         \
+        cA = prods[P].A; cB = prods[P].B; clda = prods[P].lda; cldb = prods[P].ldb; cK = prods[P].K; \
+        _Pragma("unroll") for (int s = 0; s < NA; ++s) aoff[s] = ((unsigned)min(a_r + AROWS * s, mrem - 1) * (unsigned)clda + (unsigned)a_k) * 8u; \
+        _Pragma("unroll") for (int s = 0; s < NB; ++s) boff[s] = ((unsigned)(b_k + BROWS * s) * (unsigned)cldb + (unsigned)bcol) * 8u; \
+    }
 #define GG_GLOAD(KK0)                                                                         \
     {                                                                                         \
-        gbptr A_ = (gbptr)(cA + (size_t)m0 * clda + (KK0));    /* wave-uniform byte bases: saddr + 32-bit voffset loads */ \
+        gbptr A_ = (gbptr)(cA + (size_t)m0 * clda + (KK0));                                   \
         gbptr B_ = (gbptr)(cB + (size_t)(KK0) * cldb + n0);                                   \
         const int klast_ = cK - 1 - (KK0);                                                    \
-        if (full_mn && klast_ >= BK - 1) {                                                    \
-            unsigned ao_ = ((unsigned)a_r * (unsigned)clda + (unsigned)a_k) * 8u, bo_ = ((unsigned)b_k * (unsigned)cldb + (unsigned)b_j) * 8u; \
-            const unsigned as_ = (unsigned)(8 * AROWS) * (unsigned)clda, bs_ = (unsigned)(8 * BROWS) * (unsigned)cldb; \
-            _Pragma("unroll") for (int s = 0; s < NA; ++s) { ra[s] = *(gptr)(A_ + ao_); ao_ += as_; } \
-            _Pragma("unroll") for (int s = 0; s < NB; ++s) { rb[s] = *(gptr)(B_ + bo_); bo_ += bs_; } \
+        if (klast_ >= BK - 1) {                                                               \
+            _Pragma("unroll") for (int s = 0; s < NA; ++s) ra[s] = *(gptr)(A_ + aoff[s]);     \
+            _Pragma("unroll") for (int s = 0; s < NB; ++s) rb[s] = *(gptr)(B_ + boff[s]);     \
         } else {                                                                              \
-            const double ak_ = a_k <= klast_ ? 1.0 : 0.0, bj_ = b_j < nrem ? 1.0 : 0.0;       \
-            const unsigned acol_ = (unsigned)min(a_k, klast_), bcol_ = (unsigned)min(b_j, nrem - 1); \
-            _Pragma("unroll") for (int s = 0; s < NA; ++s) {                                  \
-                const int row_ = a_r + AROWS * s;                                             \
-                ra[s] = *(gptr)(A_ + ((unsigned)min(row_, mrem - 1) * (unsigned)clda + acol_) * 8u) * (row_ < mrem ? ak_ : 0.0); \
-            }                                                                                 \
+            const double ak_ = a_k <= klast_ ? 1.0 : 0.0;                                     \
+            const unsigned aback_ = (unsigned)max(a_k - klast_, 0) * 8u;                      \
+            _Pragma("unroll") for (int s = 0; s < NA; ++s) ra[s] = *(gptr)(A_ + (aoff[s] - aback_)) * ak_; \
             _Pragma("unroll") for (int s = 0; s < NB; ++s) {                                  \
                 const int k_ = b_k + BROWS * s;                                               \
-                rb[s] = *(gptr)(B_ + ((unsigned)min(k_, klast_) * (unsigned)cldb + bcol_) * 8u) * (k_ <= klast_ ? bj_ : 0.0); \
+                rb[s] = *(gptr)(B_ + ((unsigned)min(k_, klast_) * (unsigned)cldb + (unsigned)bcol) * 8u) * (k_ <= klast_ ? 1.0 : 0.0); \
             }                                                                                 \
         }                                                                                     \
     }
@@ -126,41 +138,105 @@ ggemm_kernel(const GTile* __restrict__ tiles, const GGroup* __restrict__ groups,
         _Pragma("unroll") for (int s = 0; s < NB; ++s) Bs[BUF][(b_k + BROWS * s) * BS_LD + b_j] = rb[s]; \
     }
 
+// MFMA fragments come from LDS through explicit ds_read_b64 with immediate offsets off two per-tile base registers
+// (left to itself the compiler rematerialises a v_add_u32 per fragment address inside the loop).  GG_FRAG_WAIT is the
+// matching s_waitcnt, tied to the fragment registers so that the MFMAs cannot be scheduled above it.
+    const unsigned lds_a = (unsigned)(size_t)&As[0][(wrow + l15) * AS_LD + l4];
+    const unsigned lds_b = (unsigned)(size_t)&Bs[0][l4 * BS_LD + wcol + l15];
+    double fa[2][TR], fb[2][TC];
+#define GG_FRAG(SET, BUF, KK)                                                                 \
+    {                                                                                         \
+        _Pragma("unroll") for (int mi = 0; mi < TR; ++mi)                                     \
+            asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(fa[SET][mi]) : "v"(lds_a), "i"(8 * ((BUF) * BM * AS_LD + 16 * AS_LD * mi + (KK))) : "memory"); \
+        _Pragma("unroll") for (int ni = 0; ni < TC; ++ni)                                     \
+            asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(fb[SET][ni]) : "v"(lds_b), "i"(8 * ((BUF) * BK * BS_LD + (KK) * BS_LD + 16 * ni)) : "memory"); \
+    }
+#define GG_FRAG_WAIT(SET)                                                                     \
+    {                                                                                         \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                    \
+        _Pragma("unroll") for (int mi = 0; mi < TR; ++mi) asm volatile("" : "+v"(fa[SET][mi])); \
+        _Pragma("unroll") for (int ni = 0; ni < TC; ++ni) asm volatile("" : "+v"(fb[SET][ni])); \
+    }
+#define GG_MFMA(SET, GUARD, I0, I1)      /* MFMAs number I0 .. I1-1 (row-major over the TR x TC blocks) of one k-group */ \
+    {                                                                                         \
+        _Pragma("unroll") for (int q = (I0); q < (I1); ++q) {                                 \
+            const int mi = q / TC, ni = q % TC;                                               \
+            if (GUARD) acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[SET][mi], fb[SET][ni], acc[mi][ni], 0, 0, 0); \
+        }                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+    }
+
     bool have = p < pend;
     if (have) {
-        cA = prods[p].A; cB = prods[p].B; clda = prods[p].lda; cldb = prods[p].ldb; cK = prods[p].K;
+        GG_PRODUCT(p);
         GG_GLOAD(0);
         GG_LSTORE(0);
     }
     __syncthreads();
-    int buf = 0;
-    while (have) {
-        int pn = p, kn = k0 + BK;
-        if (kn >= cK) { pn = p + 1; kn = 0; }
-        const bool have_next = pn < pend;
-        if (have_next) {
-            if (pn != p) { cA = prods[pn].A; cB = prods[pn].B; clda = prods[pn].lda; cldb = prods[pn].ldb; cK = prods[pn].K; }
-            GG_GLOAD(kn);
-        }
-        const double* as = &As[buf][(wrow + l15) * AS_LD + l4];
-        const double* bs = &Bs[buf][l4 * BS_LD + wcol + l15];
-#pragma unroll
-        for (int kk = 0; kk < BK; kk += 4) {
-            double a[TR], b[TC];
-#pragma unroll
-            for (int mi = 0; mi < TR; ++mi) a[mi] = as[mi * 16 * AS_LD + kk];
-#pragma unroll
-            for (int ni = 0; ni < TC; ++ni) b[ni] = bs[kk * BS_LD + ni * 16];
-#pragma unroll
-            for (int mi = 0; mi < TR; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < TC; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
-        }
-        if (have_next) GG_LSTORE(buf ^ 1);
-        __syncthreads();
-        buf ^= 1; p = pn; k0 = kn; have = have_next;
+    if (have) GG_FRAG(0, 0, 0);
+// One k-step (4 k-groups of 4) on LDS buffer BUF.  The waves of a SIMD advance in lockstep (the MFMA arbiter is fair:
+// with n waves each gets the pipe every n-th MFMA), so a wave has about (n-1) x 64 cycles of slack after each of its
+// MFMAs, and whatever it does between two MFMAs beyond that slack is MFMA time lost on the whole SIMD.  The step is
+// therefore laid out by hand, with the non-MFMA work cut into pieces that sit between individual MFMAs:
+//   k-group 0: bookkeeping for the next k-step | its global loads (-> registers) | fragment reads of group 1
+//   k-group 1: fragment reads of group 2
+//   k-group 2: park the prefetched registers in buffer BUF^1 | fragment reads of group 3 | barrier | first fragments of
+//              the next k-step (from BUF^1)
+//   k-group 3: nothing but MFMAs
+// Every fragment read of buffer BUF is issued and waited for before the barrier, so a fast wave that goes on to
+// refill BUF one step later cannot overtake a reader.  sched_barrier pins the order against the compiler's scheduler.
+#define GG_STEP(BUF, GUARD)                                                                   \
+    {                                                                                         \
+        constexpr int NM = TR * TC;                                                           \
+        GG_FRAG_WAIT(0);                                                                      \
+        GG_MFMA(0, GUARD, 0, 1);                                                              \
+        int pn = p, kn = k0 + BK;                                                             \
+        if (kn >= cK) { pn = p + 1; kn = 0; }                                                 \
+        const bool have_next = pn < pend;                                                     \
+        if (have_next && pn != p) GG_PRODUCT(pn);                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        GG_MFMA(0, GUARD, 1, 2);                                                              \
+        if (have_next) GG_GLOAD(kn);                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        GG_MFMA(0, GUARD, 2, NM - 1);                                                         \
+        GG_FRAG(1, BUF, 4);                                                                   \
+        GG_MFMA(0, GUARD, NM - 1, NM);                                                        \
+        GG_FRAG_WAIT(1);                                                                      \
+        GG_MFMA(1, GUARD, 0, NM - 1);                                                         \
+        GG_FRAG(0, BUF, 8);                                                                   \
+        GG_MFMA(1, GUARD, NM - 1, NM);                                                        \
+        GG_FRAG_WAIT(0);                                                                      \
+        GG_MFMA(0, GUARD, 0, 1);                                                              \
+        if (have_next) GG_LSTORE((BUF) ^ 1);                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        GG_MFMA(0, GUARD, 1, NM - 1);                                                         \
+        GG_FRAG(1, BUF, 12);                                                                  \
+        GG_MFMA(0, GUARD, NM - 1, NM);                                                        \
+        GG_FRAG_WAIT(1);                                                                      \
+        __syncthreads();                                                                      \
+        if (have_next) GG_FRAG(0, (BUF) ^ 1, 0);                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        GG_MFMA(1, GUARD, 0, NM);                                                             \
+        p = pn; k0 = kn; have = have_next;                                                    \
     }
+// The k-step stream, instantiated twice: interior waves run it with every MFMA unconditional; waves on a ragged tile
+// edge run a copy whose MFMAs are guarded by wave-uniform block bounds (blocks outside the output are never multiplied).
+// Both copies execute the same barriers, so the waves of one workgroup may take different copies.  (One loop with a
+// per-k-step choice makes the compiler merge the accumulators with v_mov copies that wait on the MFMA results.)
+#define GG_STREAM(GUARD)                                                                      \
+    while (have) {                                                                            \
+        GG_STEP(0, GUARD);                                                                    \
+        if (!have) break;                                                                     \
+        GG_STEP(1, GUARD);                                                                    \
+    }
+    if (TR * TC > 4 || wave_full) { GG_STREAM(true) }     // (the 128 x 128 kernel only ever gets interior tiles)
+    else { GG_STREAM(mi < tr_eff && ni < tc_eff) }
+#undef GG_STREAM
+#undef GG_STEP
+#undef GG_FRAG
+#undef GG_FRAG_WAIT
+#undef GG_MFMA
+#undef GG_PRODUCT
 #undef GG_GLOAD
 #undef GG_LSTORE
 
@@ -186,16 +262,18 @@ bool ggemm_use_big_tiles()
     return e && std::string(e) == "mixed";   // the plan's ragged task tables currently balance better on 64 x 64 tiles only
 }
 
-void ggemm_schedule(std::vector<GTile>& tiles)
+void ggemm_schedule(std::vector<GTile>& tiles, int unit)
 {
-    constexpr int NX = 8, CLUSTER = 8;
+    constexpr int NX = 8;
     if (tiles.empty()) return;
     struct Cl { size_t begin, end; int64_t cost; };
     std::vector<Cl> cl;
     for (size_t i = 0; i < tiles.size();) {
         size_t j = i;
         int64_t c = 0;
-        while (j < tiles.size() && j - i < (size_t)CLUSTER && tiles[j].group == tiles[i].group && tiles[j].tm == tiles[i].tm) { c += tiles[j].pad + 2; ++j; }
+        // a cluster = the consecutive tiles of one group inside one GG_CLUSTER x GG_CLUSTER block of its tile grid
+        const int W = GG_CLUSTER * unit, cm = tiles[i].tm / W, cn = tiles[i].tn / W;
+        while (j < tiles.size() && tiles[j].group == tiles[i].group && tiles[j].tm / W == cm && tiles[j].tn / W == cn && j - i < 64) { c += tiles[j].pad + 2; ++j; }
         cl.push_back(Cl{i, j, c});
         i = j;
     }

@@ -95,13 +95,26 @@ __global__ void layout_copy_kernel(const LayoutSeg* __restrict__ segs, const dou
     }
 }
 
-// y[e] += slab_0[e] + slab_1[e] + ...  (fixed order: bit-reproducible split-K)
-__global__ void slab_reduce_kernel(double* __restrict__ y, const double* __restrict__ slabs, int64_t ylen, int nslab)
+// Split-K fix-up: for every split output block, y_block += slab_0 + slab_1 + ... in fixed order (bit-reproducible,
+// no atomics).  Slabs are compact M x N copies (ld = N) stored back to back in the arena.
+struct RedTask { int64_t dst_off, slab_off; int32_t ldc, M, N, nslab; };
+struct RedTile { int32_t task, chunk; };
+constexpr int RED_CHUNK = 2048;
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const RedTile* __restrict__ tiles, const RedTask* __restrict__ tasks,
+                                                          double* __restrict__ y, const double* __restrict__ arena)
 {
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < ylen; e += (int64_t)gridDim.x * blockDim.x) {
-        double v = y[e];
-        for (int s = 0; s < nslab; ++s) v += slabs[(int64_t)s * ylen + e];
-        y[e] = v;
+    const RedTile t = tiles[blockIdx.x];
+    const RedTask k = tasks[t.task];
+    const int64_t mn = (int64_t)k.M * k.N;
+    const double* sl = arena + k.slab_off;
+    for (int i = threadIdx.x; i < RED_CHUNK; i += 256) {
+        const int64_t e = (int64_t)t.chunk * RED_CHUNK + i;
+        if (e >= mn) break;
+        const int32_t row = (int32_t)(e / k.N), col = (int32_t)(e - (int64_t)row * k.N);
+        double* d = y + k.dst_off + (int64_t)row * k.ldc + col;
+        double v = *d;
+        for (int s = 0; s < k.nslab; ++s) v += sl[(int64_t)s * mn + e];
+        *d = v;
     }
 }
 
@@ -153,8 +166,8 @@ struct dmrgx_kron_plan {
     int32_t nprods = 0, ngroups = 0, ntiles1 = 0, ntiles2 = 0, ntiles1b = 0, ntiles2b = 0;
     DevBuf d_layout;
     int32_t nlayout = 0;
-    int64_t slab_off = 0, ylen = 0;     // split-K partial-sum slabs inside the arena
-    int32_t nslab = 0;
+    DevBuf d_red_tasks, d_red_tiles;    // split-K fix-up tables
+    int32_t n_red_tiles = 0;
     const double* last_x = nullptr;     // tables are re-patched only when the (x,y) pair changes
     double* last_y = nullptr;
     bool timing = false;                // per-stage HIP-event timing (dmrgx_kron_plan_timing)
@@ -208,25 +221,34 @@ struct Builder {
     }
 
     // Stage-2 output tiles carry the whole operator list of a KronBlock (K ~ 10^4 at m = 2048) and there are fewer
-    // of them than workgroup slots, so long product lists are cut into up to 8 contiguous segments ("split-K").
-    // Segment 0 writes y, segment s >= 1 writes slab s-1 (same layout as y, in the arena); a fixed-order reduce
-    // kernel adds the slabs into y afterwards, so the result stays bit-reproducible (no atomics).
-    void finalize_stage2(int64_t slab_base, int64_t ylen) {
+    // of them than workgroup slots, so long product lists are cut on product boundaries into contiguous segments of
+    // about equal length ("split-K"): enough (tile, segment) units that the scheduler can balance the XCDs, long enough
+    // that the 32 KB partial-tile write is amortised.  Segment 0 writes y, segment s >= 1 writes a compact slab in the
+    // arena; slab_reduce_kernel adds them in fixed order, so the result stays bit-reproducible (no atomics).
+    std::vector<RedTask> red_tasks;
+    std::vector<RedTile> red_tiles;
+    int64_t slab_elems = 0;
+    void finalize_stage2(int64_t slab_base) {
         double total = 0;
         for (int32_t g : stage2_groups) {
             const RelGroup& G = groups[g];
             total += (double)ksteps(g) * ((G.M + GG_BM - 1) / GG_BM) * ((G.N + GG_BN - 1) / GG_BN);
         }
-        const double seg_target = std::max(total / 2048.0, 8.0);
+        static const double units = getenv("DMRGX_SPLIT_UNITS") ? atof(getenv("DMRGX_SPLIT_UNITS")) : 8192.0;
+        static const double min_seg = getenv("DMRGX_SPLIT_MIN") ? atof(getenv("DMRGX_SPLIT_MIN")) : 16.0;
+        const double seg_target = std::max(total / units, min_seg);
         const size_t ng = stage2_groups.size();
         for (size_t gi = 0; gi < ng; ++gi) {
             const int32_t g = stage2_groups[gi];
             const int32_t cost = ksteps(g);
             const int32_t gemm_begin = groups[g].prod_begin + groups[g].n_axpy, gemm_end = groups[g].prod_end;
-            int32_t S = (int32_t)std::min<double>(8.0, std::max(1.0, std::ceil(cost / seg_target)));
+            int32_t S = (int32_t)std::min<double>(64.0, std::max(1.0, std::floor(cost / seg_target + 0.5)));
             S = std::max(1, std::min(S, gemm_end - gemm_begin));
             if (S == 1) { ggemm_append_tiles_mixed(tiles2b, tiles2, g, groups[g].M, groups[g].N, cost, big); continue; }
             max_split = std::max(max_split, S);
+            const int64_t mn = (int64_t)groups[g].M * groups[g].N;
+            red_tasks.push_back(RedTask{groups[g].c_off, slab_base + slab_elems, groups[g].ldc, groups[g].M, groups[g].N, S - 1});
+            for (int64_t c = 0; c * RED_CHUNK < mn; ++c) red_tiles.push_back(RedTile{(int32_t)red_tasks.size() - 1, (int32_t)c});
             int32_t gcost = 0;
             for (int32_t p = gemm_begin; p < gemm_end; ++p) gcost += (prods[p].K + GG_BK - 1) / GG_BK;
             int32_t p = gemm_begin, done = 0;
@@ -242,12 +264,14 @@ struct Builder {
                 } else {
                     RelGroup ng2 = groups[g];
                     ng2.c_base = BASE_ARENA;
-                    ng2.c_off = slab_base + (int64_t)(sidx - 1) * ylen + groups[g].c_off;
+                    ng2.c_off = slab_base + slab_elems + (int64_t)(sidx - 1) * mn;
+                    ng2.ldc = ng2.N;
                     ng2.prod_begin = b; ng2.prod_end = p; ng2.n_axpy = 0; ng2.accumulate = 0;
                     groups.push_back(ng2);
                     ggemm_append_tiles_mixed(tiles2b, tiles2, (int32_t)groups.size() - 1, ng2.M, ng2.N, c, big);
                 }
             }
+            slab_elems += (int64_t)(S - 1) * mn;
         }
     }
 
@@ -273,8 +297,9 @@ struct Builder {
             if (prods[p].kind == GPROD_AXPY) { G.n_axpy++; flops_alg += 2.0 * mn; }
             else {
                 flops_alg += 2.0 * mn * prods[p].K;
-                const double tm = (G.M + GG_BM - 1) / GG_BM, tn = (G.N + GG_BN - 1) / GG_BN;
-                flops_exec += 2.0 * tm * tn * GG_BM * GG_BN * (double)(((prods[p].K + GG_BK - 1) / GG_BK) * GG_BK);
+                // MFMA work actually issued: 16 x 16 accumulator blocks that intersect the output, k in units of 4
+                const double tm = (G.M + 15) / 16, tn = (G.N + 15) / 16;
+                flops_exec += 2.0 * tm * tn * 256.0 * (double)(((prods[p].K + 3) / 4) * 4);
                 if (big) flops_alg_big += 2.0 * (double)((G.M / 128) * 128) * (double)((G.N / 128) * 128) * prods[p].K;
             }
         }
@@ -508,12 +533,26 @@ extern "C" dmrgx_status dmrgx_kron_plan_create(const dmrgx_kron_desc* d, void* s
 
     const int64_t ylen = (W == 1) ? N : seg_stride;
     const int64_t slab_base = arena_ops + arena_T;
-    B.finalize_stage2(slab_base, ylen);
-    const int64_t arena_slabs = (int64_t)(B.max_split - 1) * ylen;
+    B.finalize_stage2(slab_base);
+    const int64_t arena_slabs = B.slab_elems;
     ggemm_schedule(B.tiles1);
     ggemm_schedule(B.tiles2);
-    ggemm_schedule(B.tiles1b);
-    ggemm_schedule(B.tiles2b);
+    ggemm_schedule(B.tiles1b, 2);
+    ggemm_schedule(B.tiles2b, 2);
+    if (const char* dump = getenv("DMRGX_PLAN_DUMP")) {   // developer aid: scheduled tile lists, one line per tile
+        if (FILE* f = fopen(dump, "w")) {
+            auto put = [&](const char* name, const std::vector<GTile>& tl) {
+                for (size_t i = 0; i < tl.size(); ++i) {
+                    const GTile& t = tl[i];
+                    if (t.group < 0) { fprintf(f, "%s %zu -1 0 0 0 0 0 0\n", name, i); continue; }
+                    const RelGroup& G2 = B.groups[t.group];
+                    fprintf(f, "%s %zu %d %d %d %d %d %d %d\n", name, i, t.group, t.tm, t.tn, G2.M, G2.N, t.pad, G2.prod_end - G2.prod_begin);
+                }
+            };
+            put("s1", B.tiles1); put("s2", B.tiles2); put("s1b", B.tiles1b); put("s2b", B.tiles2b);
+            fclose(f);
+        }
+    }
 
     // ---- device objects ------------------------------------------------------------------------------------
     dmrgx_kron_plan* P = new (std::nothrow) dmrgx_kron_plan();
@@ -521,7 +560,7 @@ extern "C" dmrgx_status dmrgx_kron_plan_create(const dmrgx_kron_desc* d, void* s
     std::unique_ptr<dmrgx_kron_plan> guard(P);
     P->world = W; P->rank = me;
     DMRGX_CHK(P->arena.alloc((size_t)std::max<int64_t>(arena_ops + arena_T + arena_slabs, 1) * sizeof(double)));
-    P->slab_off = slab_base; P->ylen = ylen; P->nslab = B.max_split - 1;
+    P->n_red_tiles = (int32_t)B.red_tiles.size();
     DMRGX_HIP(hipMemsetAsync(P->arena.p, 0, P->arena.bytes, st));
     {   // operator copies, one launch per accumulation round
         int32_t max_round = -1;
@@ -551,6 +590,8 @@ extern "C" dmrgx_status dmrgx_kron_plan_create(const dmrgx_kron_desc* d, void* s
     DMRGX_CHK(upload(P->d_tiles2, B.tiles2, st));
     DMRGX_CHK(upload(P->d_tiles1b, B.tiles1b, st));
     DMRGX_CHK(upload(P->d_tiles2b, B.tiles2b, st));
+    DMRGX_CHK(upload(P->d_red_tasks, B.red_tasks, st));
+    DMRGX_CHK(upload(P->d_red_tiles, B.red_tiles, st));
     DMRGX_CHK(P->d_prods.alloc(std::max<size_t>(B.prods.size(), 1) * sizeof(GProd)));
     DMRGX_CHK(P->d_groups.alloc(std::max<size_t>(B.groups.size(), 1) * sizeof(GGroup)));
     {   // layout conversion table (reference order <-> rank-major stripes)
@@ -573,7 +614,7 @@ extern "C" dmrgx_status dmrgx_kron_plan_create(const dmrgx_kron_desc* d, void* s
     for (auto& g : G) { cellbytes(g.left); cellbytes(g.rightT); }
     cellbytes(PHL); cellbytes(PHRT);
     I.bytes_alg = opbytes + 8.0 * ((double)N + (double)seg_off[me][nb]);
-    I.bytes_workspace = 16.0 * (double)arena_T + 8.0 * (double)ylen * (2.0 * (B.max_split - 1) + (B.max_split > 1 ? 2.0 : 0.0));
+    I.bytes_workspace = 16.0 * (double)arena_T + 16.0 * (double)B.slab_elems;
     I.n_groups = (int32_t)G.size(); I.n_tiles_stage1 = P->ntiles1 + P->ntiles1b; I.n_tiles_stage2 = P->ntiles2 + P->ntiles2b;
     I.n_tiles_big = P->ntiles1b + P->ntiles2b; I.flops_alg_big = B.flops_alg_big;
     (void)n_groups_stage1;
@@ -619,8 +660,8 @@ extern "C" dmrgx_status dmrgx_kron_apply(dmrgx_kron_plan* P, const double* x_ful
     if (e) DMRGX_HIP(hipEventRecord(e[3], st));
     DMRGX_CHK(ggemm_launch(P->d_tiles2.as<GTile>(), P->d_groups.as<GGroup>(), P->d_prods.as<GProd>(), P->ntiles2, st, 0));
     if (e) DMRGX_HIP(hipEventRecord(e[4], st));
-    if (P->nslab > 0) {
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3(2048), dim3(256), 0, st, y_local, P->arena.as<double>() + P->slab_off, P->ylen, P->nslab);
+    if (P->n_red_tiles > 0) {
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)P->n_red_tiles), dim3(256), 0, st, P->d_red_tiles.as<RedTile>(), P->d_red_tasks.as<RedTask>(), y_local, P->arena.as<double>());
         DMRGX_HIP(hipGetLastError());
     }
     return DMRGX_OK;

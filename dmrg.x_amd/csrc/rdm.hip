@@ -395,7 +395,7 @@ extern "C" dmrgx_status dmrgx_rdm_create(const dmrgx_sectors* left, const dmrgx_
             groups.push_back(GGroup{buf + mR.a_off, mR.npad, nr, nr, (int32_t)prods.size() - 1, (int32_t)prods.size(), 0, 0});
             ggemm_append_tiles_mixed(gb, gt, (int32_t)groups.size() - 1, nr, nr, (nl + GG_BK - 1) / GG_BK);
         }
-        ggemm_schedule(gt); ggemm_schedule(gb);
+        ggemm_schedule(gt); ggemm_schedule(gb, 2);
         DevBuf dp, dg, dt, db;
         DMRGX_CHK(upload(dp, prods, st)); DMRGX_CHK(upload(dg, groups, st)); DMRGX_CHK(upload(dt, gt, st)); DMRGX_CHK(upload(db, gb, st));
         DMRGX_CHK(ggemm_launch(db.as<GTile>(), dg.as<GGroup>(), dp.as<GProd>(), (int32_t)gb.size(), st, 1));
@@ -462,7 +462,7 @@ extern "C" dmrgx_status dmrgx_rdm_create(const dmrgx_sectors* left, const dmrgx_
             ggemm_append_tiles_mixed(gb, gt, (int32_t)groups.size() - 1, nl, nr, (nr + GG_BK - 1) / GG_BK);
             cn.push_back(ColNormTask{w_base + 2 * off[k] + (int64_t)nl * nr, rq_base + (diag_off[2 * k + 1] - diag_base), nl, nr, nr, 0});
         }
-        ggemm_schedule(gt); ggemm_schedule(gb);
+        ggemm_schedule(gt); ggemm_schedule(gb, 2);
         DevBuf dp, dg, dt, db, dc;
         DMRGX_CHK(upload(dp, prods, st)); DMRGX_CHK(upload(dg, groups, st)); DMRGX_CHK(upload(dt, gt, st)); DMRGX_CHK(upload(db, gb, st));
         DMRGX_CHK(upload(dc, cn, st));

@@ -183,7 +183,7 @@ extern "C" dmrgx_status dmrgx_rotate_ops(const dmrgx_sectors* old_sectors, const
         groups.push_back(GGroup{dst_blocks[o][a], mp, m, mp, pb, (int32_t)prods.size(), 0, 0});
         ggemm_append_tiles_mixed(tBb, tB, (int32_t)groups.size() - 1, m, mp, cost);
     }
-    ggemm_schedule(tA); ggemm_schedule(tAb); ggemm_schedule(tB); ggemm_schedule(tBb);
+    ggemm_schedule(tA); ggemm_schedule(tAb, 2); ggemm_schedule(tB); ggemm_schedule(tBb, 2);
     DevBuf dp, dg, d1, d2, d3, d4;
     DMRGX_CHK(upload(dp, prods, st)); DMRGX_CHK(upload(dg, groups, st));
     DMRGX_CHK(upload(d1, tAb, st)); DMRGX_CHK(upload(d2, tA, st)); DMRGX_CHK(upload(d3, tBb, st)); DMRGX_CHK(upload(d4, tB, st));
