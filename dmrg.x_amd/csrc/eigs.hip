@@ -5,10 +5,10 @@
 // EPS_SMALLEST_REAL, nev = 1; SLEPc's defaults for that call: Krylov-Schur, ncv = 16, relative residual
 // tol = 1e-8 -- third-party, not in the reference tree).  One "superblock MatMult" == one dmrgx_kron_apply.
 //
-// Per Lanczos step the vector work is two fused HBM-bound passes instead of BLAS-1 calls:
-//   multi_dot : c[0..j] = V[0..j]^T w  and  w.w     (reads j+2 vectors once)
-//   multi_axpy: w -= V c ; ||w||^2                   (reads j+2 vectors, writes w)
-// repeated once (CGS2).  Nothing is copied to the host inside a restart cycle: the normalisation reads beta^2
+// Per Lanczos step the vector work is three fused HBM-bound passes over the basis instead of BLAS-1 calls (CGS2):
+//   multi_dot       : c = V^T w                                  (reads j+2 vectors)
+//   axpy_dot        : w' = w - V c ; c2 = V^T w' , w'.w'         (reads j+2 vectors, writes w')
+//   axpy_normalise  : v_{j+1} = (w' - V c2) / sqrt(w'.w' - |c2|^2)   (reads j+2 vectors, writes v_{j+1})  Nothing is copied to the host inside a restart cycle: the normalisation reads beta^2
 // from device memory, and the host fetches the projected matrix once per cycle (ncv/2 MatMults).
 // world_size > 1: vectors are this rank's stripe segment; per Lanczos step there are exactly two fused all-reduces (of
 // j+2 doubles each) and one all-gather of the Krylov vector before the MatMult.
@@ -20,7 +20,7 @@
 namespace dmrgx {
 namespace {
 
-constexpr int DOT_BLOCKS = 512, DOT_THREADS = 256, DOT_CHUNK = 8, MAX_NCV = 64;
+constexpr int DOT_BLOCKS = 1024, DOT_THREADS = 256, DOT_CHUNK = 8, MAX_NCV = 64, FUSE_NV = 24;
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -97,6 +97,69 @@ multi_axpy_kernel(const double* __restrict__ V, int64_t ldv, int nv, const doubl
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = nrm;
     __syncthreads();
     if (threadIdx.x == 0) { double t = 0.0; for (int k = 0; k < DOT_THREADS / 64; ++k) t += red[k]; partial[blockIdx.x] = t; }
+}
+
+// First Gram-Schmidt pass fused with the dots of the second: w' = w - V c is formed per element and immediately
+// multiplied into this thread's partial sums of V^T w' and w'.w' (V's values are still in registers), so the basis is
+// read from HBM once for both.  nv <= FUSE_NV (the default ncv = 16 gives nv <= 17).
+// partial[i * DOT_BLOCKS + block], i < nv: V_i . w' ; i == nv: w'.w'
+__global__ void __launch_bounds__(DOT_THREADS)
+axpy_dot_kernel(const double* __restrict__ V, int64_t ldv, int nv, const double* __restrict__ c, double* __restrict__ w, int64_t n,
+                double* __restrict__ partial, double* __restrict__ hacc)
+{
+    __shared__ double cs[FUSE_NV];
+    __shared__ double red[DOT_THREADS / 64][FUSE_NV + 1];
+    if (threadIdx.x < nv) cs[threadIdx.x] = c[threadIdx.x];
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x < nv && hacc) hacc[threadIdx.x] += cs[threadIdx.x];
+    double acc[FUSE_NV + 1];
+#pragma unroll
+    for (int i = 0; i <= FUSE_NV; ++i) acc[i] = 0.0;
+    for (int64_t e = (int64_t)blockIdx.x * DOT_THREADS + threadIdx.x; e < n; e += (int64_t)DOT_BLOCKS * DOT_THREADS) {
+        double v[FUSE_NV];
+#pragma unroll
+        for (int i = 0; i < FUSE_NV; ++i) v[i] = i < nv ? V[(int64_t)i * ldv + e] : 0.0;
+        double x = w[e];
+#pragma unroll
+        for (int i = 0; i < FUSE_NV; ++i) if (i < nv) x -= cs[i] * v[i];
+        w[e] = x;
+#pragma unroll
+        for (int i = 0; i < FUSE_NV; ++i) if (i < nv) acc[i] += v[i] * x;
+        acc[FUSE_NV] += x * x;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i <= FUSE_NV; ++i) {
+        if (i < nv || i == FUSE_NV) {
+            const double s2 = wave_sum(acc[i]);
+            if (lane == 0) red[wave][i] = s2;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x <= nv) {
+        const int src = threadIdx.x < nv ? threadIdx.x : FUSE_NV;
+        double s2 = 0.0;
+        for (int wv = 0; wv < DOT_THREADS / 64; ++wv) s2 += red[wv][src];
+        partial[(int64_t)threadIdx.x * DOT_BLOCKS + blockIdx.x] = s2;
+    }
+}
+
+// Second Gram-Schmidt pass fused with the normalisation: dst = (w - V c) * (nrm2 > tiny ? 1/sqrt(nrm2) : 0)
+__global__ void __launch_bounds__(DOT_THREADS)
+axpy_normalise_kernel(const double* __restrict__ V, int64_t ldv, int nv, const double* __restrict__ c, const double* __restrict__ w,
+                      double* __restrict__ dst, int64_t n, const double* __restrict__ nrm2, double* __restrict__ hacc)
+{
+    __shared__ double cs[MAX_NCV + 1];
+    if (threadIdx.x < nv) cs[threadIdx.x] = c[threadIdx.x];
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x < nv && hacc) hacc[threadIdx.x] += cs[threadIdx.x];
+    const double s2 = *nrm2;
+    const double inv = s2 > 1e-290 ? 1.0 / sqrt(s2) : 0.0;
+    for (int64_t e = (int64_t)blockIdx.x * DOT_THREADS + threadIdx.x; e < n; e += (int64_t)DOT_BLOCKS * DOT_THREADS) {
+        double x = w[e];
+        for (int i = 0; i < nv; ++i) x -= cs[i] * V[(int64_t)i * ldv + e];
+        dst[e] = x * inv;
+    }
 }
 
 // ||w - V c||^2 = w.w - |c|^2 for orthonormal V and c = V^T w (c is the tiny refinement coefficient vector of the second
@@ -223,12 +286,13 @@ extern "C" dmrgx_status dmrgx_eigs_lowest(dmrgx_kron_plan* plan, const dmrgx_eig
     DMRGX_CHK(dPartial.alloc((size_t)(MAX_NCV + DOT_CHUNK + 1) * DOT_BLOCKS * sizeof(double)));
     // scalars: per step j a row of (m+2) doubles: h_j[0..m] accumulated coefficients, slot m+1: beta_j^2 ; + scratch c[]
     const int row = m + 2;
-    DMRGX_CHK(dScal.alloc((size_t)((m + 1) * row + 2 * (MAX_NCV + 2)) * sizeof(double)));
+    DMRGX_CHK(dScal.alloc((size_t)((m + 1) * row + 3 * (MAX_NCV + 2)) * sizeof(double)));
     DMRGX_CHK(dQ.alloc((size_t)MAX_NCV * MAX_NCV * sizeof(double)));
     double* V = dV.as<double>();
     double* w = dW.as<double>();
     double* c1 = dScal.as<double>() + (size_t)(m + 1) * row;      // [nv+1]: V^T w, w.w
-    double* nrm = c1 + (MAX_NCV + 2);                             // [1]
+    double* c2 = c1 + (MAX_NCV + 2);                              // [nv+1]: V^T w', w'.w' (second pass)
+    double* nrm = c2 + (MAX_NCV + 2);                             // [1]
     auto Hrow = [&](int j) { return dScal.as<double>() + (size_t)j * row; };
     auto vec = [&](int j) { return V + (size_t)j * n; };
     DMRGX_HIP(hipMemsetAsync(dV.p, 0, dV.bytes, st));
@@ -299,12 +363,26 @@ extern "C" dmrgx_status dmrgx_eigs_lowest(dmrgx_kron_plan* plan, const dmrgx_eig
         for (int j = k; j < jend; ++j) {
             DMRGX_CHK(matvec(vec(j), w));
             ++n_matvec;
-            DMRGX_CHK(multi_dot(j + 1));                      // pass 1: c = V^T w                (one fused all-reduce)
-            DMRGX_CHK(multi_axpy(j + 1, Hrow(j), false));
-            DMRGX_CHK(multi_dot(j + 1));                      // pass 2: refinement, c2 = V^T w', w'.w' (one fused all-reduce)
-            DMRGX_CHK(multi_axpy(j + 1, Hrow(j), true));     //         beta^2 = w'.w' - |c2|^2
+            const int nv = j + 1;
+            DMRGX_CHK(multi_dot(nv));                         // pass 1: c1 = V^T w                (one fused all-reduce)
+            if (nv <= FUSE_NV) {
+                // w' = w - V c1 fused with pass 2's dots: c2 = V^T w', w'.w'            (one fused all-reduce)
+                hipLaunchKernelGGL(axpy_dot_kernel, dim3(DOT_BLOCKS), dim3(DOT_THREADS), 0, st, V, n, nv, c1, w, n, dPartial.as<double>(), Hrow(j));
+                DMRGX_HIP(hipGetLastError());
+                hipLaunchKernelGGL(reduce_partials_kernel, dim3(nv + 1), dim3(DOT_THREADS), 0, st, dPartial.as<double>(), c2, nv + 1);
+                DMRGX_HIP(hipGetLastError());
+                DMRGX_CHK(allreduce(c2, nv + 1));
+            } else {
+                DMRGX_CHK(multi_axpy(nv, Hrow(j), false));
+                DMRGX_CHK(multi_dot(nv));
+                DMRGX_HIP(hipMemcpyAsync(c2, c1, (size_t)(nv + 1) * sizeof(double), hipMemcpyDeviceToDevice, st));
+            }
+            // beta^2 = w'.w' - |c2|^2 ; v_{j+1} = (w' - V c2) / beta
+            hipLaunchKernelGGL(norm_after_projection_kernel, dim3(1), dim3(64), 0, st, c2, nv, nrm);
+            DMRGX_HIP(hipGetLastError());
+            hipLaunchKernelGGL(axpy_normalise_kernel, dim3(DOT_BLOCKS), dim3(DOT_THREADS), 0, st, V, n, nv, c2, w, vec(j + 1), n, nrm, Hrow(j));
+            DMRGX_HIP(hipGetLastError());
             DMRGX_HIP(hipMemcpyAsync(Hrow(j) + m + 1, nrm, sizeof(double), hipMemcpyDeviceToDevice, st));
-            DMRGX_CHK(normalise_into(vec(j + 1)));
         }
         DMRGX_HIP(hipMemcpyAsync(hbuf.data(), dScal.p, (size_t)(m + 1) * row * sizeof(double), hipMemcpyDeviceToHost, st));
         DMRGX_HIP(hipStreamSynchronize(st));

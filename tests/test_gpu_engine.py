@@ -92,3 +92,13 @@ def test_two_rank_eigensolve_on_one_gpu():
     outs = [p.communicate(timeout=600)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)[-3000:]
     assert "two-rank eigensolve ok" in outs[0]
+
+
+def test_rccl_hooks_single_rank():
+    """The RCCL hook implementations bench.py installs for N > 1 (collectives.torch_hooks), on a one-rank nccl group."""
+    import sys
+    script = os.path.join(ROOT, "tests", "nccl_hooks_worker.py")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29643", PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, script], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    out = p.stdout.decode()
+    assert p.returncode == 0 and "rccl hooks ok" in out, out[-3000:]
