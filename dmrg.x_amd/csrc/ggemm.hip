@@ -3,8 +3,9 @@
 //
 // Operand staging (HBM -> registers -> LDS, one barrier per 16-deep k-step, register prefetch of the next
 // k-step while the current one is multiplied):
-//   A tile 64 x 16, stored [i][k] with row stride 17 doubles  -> the MFMA A fragment (lane: i=l&15, k=l>>4)
-//                                                                 reads all 64 LDS banks exactly once
+//   A tile 64 x 16, stored [i][k] with row stride 18 doubles  -> the MFMA A fragment (lane: i=l&15, k=l>>4)
+//                                                                 reads all 64 LDS banks exactly once per
+//                                                                 32-lane ds_read_b64 pass
 //   B tile 16 x 64, stored [k][j] with row stride 80 doubles  -> same for the B fragment (k=l>>4, j=l&15)
 // C/D fragment of the f64 MFMA: col = lane&15, row = (lane>>4) + 4*reg  (verified on hardware,
 // profiles/r01_mfma_f64_probe.txt).
@@ -23,9 +24,9 @@ typedef const double __attribute__((address_space(1)))* gptr;   // global-memory
 typedef double __attribute__((address_space(1)))* gwptr;
 typedef const char __attribute__((address_space(1)))* gbptr;    // byte pointer for base + 32-bit offset addressing
 
-// LDS strides are derived inside the kernel template: A rows 17 doubles apart (34 dwords: the 16 rows of a fragment
-// hit 16 distinct 2-bank slots under ds_read_b64's 64 banks and under the ds_read2_b64 the compiler fuses k-steps into:
-// 32 banks, 16-lane groups; 18 was 2-way conflicted there), B rows BN+16 doubles apart.
+// LDS strides are derived inside the kernel template: A rows 18 doubles apart (the fragments are read with explicit
+// ds_read_b64: within a 32-lane pass the addresses i*18 + {k, k+1}, i < 16, cover every 8-byte bank pair once; an odd
+// stride always collides for one (i, i') pair, measured 20 % conflict cycles at 17), B rows BN+16 doubles apart.
 
 // Workgroup -> tile: tiles[blockIdx.x].  The host (ggemm_schedule) lays the list out so that entries b, b+8,
 // b+16, ... -- the blocks the dispatcher deals to one XCD -- form that XCD's cost-balanced, locality-clustered
@@ -41,7 +42,7 @@ ggemm_kernel(const GTile* __restrict__ tiles, const GGroup* __restrict__ groups,
 {
     constexpr int THREADS = 64 * WR * WC;
     constexpr int BM = 16 * TR * WR, BN = 16 * TC * WC, BK = GG_BK;
-    constexpr int AS_LD = BK + 1;        // 17: see header comment (conflict-free under ds_read_b64 and ds_read2_b64)
+    constexpr int AS_LD = BK + 2;        // 18: the 32 lanes of a ds_read_b64 pass (i < 16, k and k+1) hit 32 distinct bank pairs
     constexpr int BS_LD = BN + 16;       // == 32 dwords (mod 64): rows k and k+1 use disjoint bank halves
     constexpr int AROWS = THREADS / 16;  // A rows covered per pass
     constexpr int NA = BM / AROWS;       // A elements per thread per k-step

@@ -19,5 +19,5 @@ for f in sorted(glob.glob(os.path.join(out, "pmc_*", "**", "*counter_collection.
         cnt[k][c] += 1
     print(f"== PMC ({os.path.relpath(f, out)}) : per-dispatch averages ==")
     for k in acc:
-        if "ggemm" in k or "multi_" in k:
+        if "ggemm" in k or "multi_" in k or "axpy_" in k or "slab_" in k:
             print("  " + k + ": " + ", ".join(f"{c}={acc[k][c] / cnt[k][c]:.4g} (n={cnt[k][c]})" for c in sorted(acc[k])))
