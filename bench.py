@@ -64,6 +64,39 @@ def cpu_baseline(sb, budget_s=15.0):
                       f"({total_flops / 1e9:.0f} GF per MatMult)"}
 
 
+def engine_run(opts, timeout=300):
+    """Run the drop-in sweep engine (dmrg.x_amd/dmrgx-square-lattice, the host C++ driver over the same C ABI) in a child
+    process and return its DMRGRun.json.  Child process: it owns its own HIP context, nothing is exec'd from this one."""
+    import subprocess
+    import tempfile
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dmrg.x_amd", "dmrgx-square-lattice")
+    with tempfile.TemporaryDirectory(prefix="dmrgx_bench_") as d:
+        r = subprocess.run([exe, *[str(o) for o in opts], "-data_dir", d + "/"], capture_output=True, text=True, timeout=timeout)
+        if r.returncode != 0:
+            raise RuntimeError("sweep engine failed: " + (r.stdout + r.stderr)[-1000:])
+        return json.load(open(os.path.join(d, "DMRGRun.json")))
+
+
+def sweep_legs():
+    """The other two parts of BASELINE.json's metric, measured on the real engine (real Hamiltonian, real sweeps):
+    sites/sec per sweep on configs[1] (J1-J2 8x4 cylinder, J2 = 0.5, m = 512) and the E0 relative error on configs[0]
+    (Heisenberg 16x1 chain, m = 64, 2 sweeps) against exact diagonalisation."""
+    out = {}
+    run = engine_run(["-Lx", 8, "-Ly", 4, "-J1", 1, "-Jz1", 1, "-J2", 0.5, "-Jz2", 0.5, "-mwarmup", 512, "-nsweeps", 1])
+    out["sites_per_s"] = run["LastSweepSteps"] / run["LastSweepSeconds"]
+    out["config"] = "configs[1]: J1-J2 8x4 cylinder, J2=0.5, m=512, one finite-system sweep after warm-up (real engine run)"
+    out["sweep_steps"] = run["LastSweepSteps"]
+    out["sweep_seconds"] = run["LastSweepSeconds"]
+    out["sweep_matmults"] = run["LastSweepMatMults"]
+    out["matmults_per_s_in_sweep"] = run["LastSweepMatMults"] / run["LastSweepSeconds"]
+    out["gs_energy"] = run["GSEnergy"]
+    e_ed = -6.9117371455751
+    run1 = engine_run(["-Lx", 16, "-Ly", 1, "-heisenberg", 1, "-mwarmup", 64, "-nsweeps", 2, "-H_eps_tol", 1e-12])
+    out["e0_rel_err"] = abs(run1["GSEnergy"] - e_ed) / abs(e_ed)
+    out["e0_config"] = "configs[0]: Heisenberg 16x1 chain, m=64, 2 sweeps; exact-diagonalisation E0 = -6.9117371455751"
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -72,6 +105,7 @@ def main():
     ap.add_argument("--workload", default="cfg4", help="BASELINE.json config: cfg1..cfg5 (default cfg4 = J1-J2 20x8, m=2048)")
     ap.add_argument("--ncv", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the engine legs (sites/sec per sweep, E0 rel-err)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -163,13 +197,24 @@ def main():
                      "tiles_stage1": info.n_tiles_stage1, "tiles_stage2": info.n_tiles_stage2,
                      "hbm_frac_of_peak": (info.bytes_alg + info.bytes_workspace) / max((ms1 + ms2) / max(napp, 1) * 1e-3, 1e-12) / (HBM_PEAK_TBS * 1e12)},
     }
+    traffic_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic.json")
+    if os.path.exists(traffic_file):          # PMC-measured L2-miss traffic of the same command (rocprofv3 passes, tools/profile.sh)
+        t = json.load(open(traffic_file)).get(f"{args.workload}@{world}")
+        if t and t.get("kernel") == kernel:
+            out["roofline"]["traffic"] = t["bytes_per_launch"]
+            out["roofline"]["traffic_source"] = t["source"]
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(sb)
     elif rank == 0:
         out["cpu_baseline"] = None
+    plan.destroy()
+    plan = None
+    if rank == 0 and world == 1 and not args.no_sweep:
+        out["sweep"] = sweep_legs()
     if rank == 0:
         print(json.dumps(out))
-    plan.destroy()
+    if plan is not None:
+        plan.destroy()
     if dist is not None:
         dist.destroy_process_group()
 

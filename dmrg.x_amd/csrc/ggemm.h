@@ -38,10 +38,11 @@ constexpr int GG_BM = 64, GG_BN = 64, GG_BK = 16, GG_THREADS = 256;
 // (coordinates still in 64-units), else 64 x 64.
 dmrgx_status ggemm_launch(const GTile* d_tiles, const GGroup* d_groups, const GProd* d_prods, int32_t ntiles, hipStream_t st, int big = 0);
 
-// Host-side helper: append the tiles of group `g` (M x N) to a tile list in 4 x 4 clusters (tiles of a cluster share
+// Host-side helper: append the tiles of group `g` (M x N) to a tile list in 8 x 8 clusters (tiles of a cluster share
 // A row-panels and B column-panels; the scheduler keeps a cluster on one XCD so they meet in its L2); `cost` (k-steps of
 // the group's product list) is stored in GTile::pad for the scheduler.
-constexpr int GG_CLUSTER = 4;
+int ggemm_cluster();   // cluster edge in tiles (default 8; DMRGX_CLUSTER overrides, developer aid)
+#define GG_CLUSTER (::dmrgx::ggemm_cluster())
 inline void ggemm_append_tiles(std::vector<GTile>& tiles, int32_t g, int32_t M, int32_t N, int32_t cost = 1) {
     const int32_t TM = (M + GG_BM - 1) / GG_BM, TN = (N + GG_BN - 1) / GG_BN;
     for (int32_t bm = 0; bm < TM; bm += GG_CLUSTER)

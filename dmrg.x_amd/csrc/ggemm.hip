@@ -257,6 +257,12 @@ ggemm_kernel(const GTile* __restrict__ tiles, const GGroup* __restrict__ groups,
             }
 }
 
+int ggemm_cluster()
+{
+    static const int c = [] { const char* e = getenv("DMRGX_CLUSTER"); const int v = e ? atoi(e) : 8; return v >= 1 && v <= 16 ? v : 8; }();
+    return c;
+}
+
 bool ggemm_use_big_tiles()
 {
     const char* e = getenv("DMRGX_TILES");
@@ -274,7 +280,7 @@ void ggemm_schedule(std::vector<GTile>& tiles, int unit)
         int64_t c = 0;
         // a cluster = the consecutive tiles of one group inside one GG_CLUSTER x GG_CLUSTER block of its tile grid
         const int W = GG_CLUSTER * unit, cm = tiles[i].tm / W, cn = tiles[i].tn / W;
-        while (j < tiles.size() && tiles[j].group == tiles[i].group && tiles[j].tm / W == cm && tiles[j].tn / W == cn && j - i < 64) { c += tiles[j].pad + 2; ++j; }
+        while (j < tiles.size() && tiles[j].group == tiles[i].group && tiles[j].tm / W == cm && tiles[j].tn / W == cn && j - i < 256) { c += tiles[j].pad + 2; ++j; }
         cl.push_back(Cl{i, j, c});
         i = j;
     }

@@ -7,7 +7,7 @@ for rep in 1 2; do for v in old new; do
   cp tools/ab/lib_$v.so dmrg.x_amd/libdmrgx_hip.so
   for W in ${WORKLOADS:-cfg4}; do
     echo "== $v $W rep$rep" >> $OUT
-    timeout -k 10 120 python3 bench.py --no-cpu-baseline --workload $W --steps 48 --warmup 8 >> $OUT 2>&1 || exit 1
+    timeout -k 10 120 python3 bench.py --no-cpu-baseline --no-sweep --workload $W --steps 48 --warmup 8 >> $OUT 2>&1 || exit 1
   done
 done; done
 cp tools/ab/lib_new.so dmrg.x_amd/libdmrgx_hip.so

@@ -9,5 +9,5 @@ for T in ${TILES:-64}; do
 for U in ${UNITS:-6144}; do
 for MN in ${MINS:-16}; do
   echo "== $W tiles=$T units=$U min=$MN" >> $OUT
-  DMRGX_TILES=$T DMRGX_SPLIT_UNITS=$U DMRGX_SPLIT_MIN=$MN timeout -k 10 120 python3 bench.py --no-cpu-baseline --workload $W --steps 32 --warmup 8 >> $OUT 2>&1 || exit 1
+  DMRGX_TILES=$T DMRGX_SPLIT_UNITS=$U DMRGX_SPLIT_MIN=$MN timeout -k 10 120 python3 bench.py --no-cpu-baseline --no-sweep --workload $W --steps 32 --warmup 8 >> $OUT 2>&1 || exit 1
 done; done; done; done
