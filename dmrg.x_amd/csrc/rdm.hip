@@ -18,12 +18,14 @@
 namespace dmrgx {
 namespace {
 
-constexpr int JB = 16, JS = 2 * JB;          // block size, sub-problem size (32 x 32 in LDS: ~12x cheaper per solve
-                                             // than 64 x 64 for 2x the rounds; the solve is LDS-instruction bound)
-constexpr int JACOBI_INNER_SWEEPS = 1;       // partial sub-solves: the serial LDS Jacobi is the round's critical path, and
-                                             // two cyclic sweeps per visit cost fewer total microseconds than full solves
+constexpr int JB = 16, JS = 2 * JB;          // block size, sub-problem size.  Every outer round costs one sub-solve plus one
+                                             // update launch of pure latency (~20 + 13 us at any matrix size); 32 x 32
+                                             // sub-problems (31 dependent rotation rounds on 256 threads) measured best:
+                                             // JB = 32 halves the rounds but its 63-round, 1024-thread solve is > 2x slower
+constexpr int JACOBI_INNER_SWEEPS = 1;       // one cyclic sweep per visit: the outer sweeps finish the job (fewer total us)
 constexpr int JT = JS / 16;                  // outputs per thread and dimension in the 16 x 16-thread LDS matmul
 constexpr int JLD = JS + 1;
+constexpr int SUB_THREADS = JB * JB;           // sub-solve: one thread per pair of rotation pairs
 
 struct MatDesc { int64_t a_off, v_off; int32_t n, npad, nb, pad; };
 struct PairRef { int32_t mat, j; };
@@ -68,22 +70,57 @@ __global__ void __launch_bounds__(256) transpose_kernel(const TrTile* __restrict
     }
 }
 
+// Round-robin tournament pairing of JS indices: pair u of round rr (p < q); no integer division (rr < JS-1, u < JB).
+__device__ __forceinline__ void jacobi_pair(int rr, int u, int& p, int& q)
+{
+    int a = rr + u, b = rr - u;
+    if (a >= JS - 1) a -= JS - 1;
+    if (b < 0) b += JS - 1;
+    if (u == 0) { a = JS - 1; b = rr; }
+    p = min(a, b); q = max(a, b);
+}
+
+// 1/sqrt(x): hardware estimate (v_rsq_f64) + two Newton steps -- the sub-solve is a chain of dependent scalar math on
+// one wave per SIMD, so the length of this sequence is what a Jacobi round costs.
+__device__ __forceinline__ double fast_rsqrt(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+    y = y * (1.5 - 0.5 * x * y * y);
+    y = y * (1.5 - 0.5 * x * y * y);
+    return y;
+}
+
+// Jacobi rotation annihilating a_pq: with d = (a_qq - a_pp)/2 and h = hypot(d, a_pq), cos(2 theta) = |d|/h, so
+// c^2 = (1 + |d|/h)/2 and s = sign(d a_pq) |a_pq| / (2 h c)  -- two rsqrt, no division, c^2 + s^2 = 1 by construction.
+__device__ __forceinline__ void jacobi_rotation(double apq, double app, double aqq, double& c, double& s)
+{
+    c = 1.0; s = 0.0;
+    const double apq2 = apq * apq;
+    if (apq2 > 1e-300 && apq2 > 1e-36 * fabs(app * aqq)) {
+        const double d = 0.5 * (aqq - app);
+        const double ih = fast_rsqrt(d * d + apq2);
+        const double c2 = 0.5 + 0.5 * fabs(d) * ih;
+        const double ic = fast_rsqrt(c2);
+        c = c2 * ic;
+        s = ((d >= 0.0) == (apq >= 0.0) ? 0.5 : -0.5) * fabs(apq) * ih * ic;
+    }
+}
+
 // Solve the JS x JS symmetric sub-problem of block pair (I,J) by cyclic Jacobi in LDS; R (row-major JS x JS) such
 // that R^T S R is diagonal is written to rbuf[pair].
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(SUB_THREADS)
 jacobi_sub_kernel(const MatDesc* __restrict__ mats, const PairRef* __restrict__ pairs, double* __restrict__ buf, double* __restrict__ rbuf, int round)
 {
-    __shared__ double S[JS * JLD], R[JS * JLD];
-    __shared__ double cs[JB], sn[JB];
-    __shared__ int pp[JB], qq[JB];
-    __shared__ double red0[4], red1[4];
+    __shared__ double S2[2][JS * JLD], R[JS * JLD];   // S is double-buffered: a round reads one copy and writes the other
+    __shared__ double red0[SUB_THREADS / 64], red1[SUB_THREADS / 64];
+    double* S = S2[0];
     const PairRef pr = pairs[blockIdx.x];
     const MatDesc m = mats[pr.mat];
     int I, J;
     pair_blocks(m.nb, round, pr.j, I, J);
     const int tid = threadIdx.x;
     double* A = buf + m.a_off;
-    for (int e = tid; e < JS * JS; e += 256) {
+    for (int e = tid; e < JS * JS; e += SUB_THREADS) {
         const int i = e / JS, j = e % JS;
         const int gi = (i < JB ? I * JB + i : J * JB + i - JB), gj = (j < JB ? I * JB + j : J * JB + j - JB);
         S[i * JLD + j] = A[(int64_t)gi * m.npad + gj];
@@ -93,7 +130,7 @@ jacobi_sub_kernel(const MatDesc* __restrict__ mats, const PairRef* __restrict__ 
     for (int sweep = 0; sweep < JACOBI_INNER_SWEEPS; ++sweep) {
         // convergence: off-diagonal mass relative to the diagonal (wave-uniform decision); the outer sweeps finish the job
         double off = 0.0, dg = 0.0;
-        for (int e = tid; e < JS * JS; e += 256) {
+        for (int e = tid; e < JS * JS; e += SUB_THREADS) {
             const int i = e / JS, j = e % JS;
             const double v = S[i * JLD + j];
             if (i == j) dg += v * v; else off += v * v;
@@ -101,50 +138,40 @@ jacobi_sub_kernel(const MatDesc* __restrict__ mats, const PairRef* __restrict__ 
         for (int o = 32; o > 0; o >>= 1) { off += __shfl_down(off, o, 64); dg += __shfl_down(dg, o, 64); }
         if ((tid & 63) == 0) { red0[tid >> 6] = off; red1[tid >> 6] = dg; }
         __syncthreads();
-        const double offt = red0[0] + red0[1] + red0[2] + red0[3], dgt = red1[0] + red1[1] + red1[2] + red1[3];
+        double offt = 0.0, dgt = 0.0;
+        for (int w = 0; w < SUB_THREADS / 64; ++w) { offt += red0[w]; dgt += red1[w]; }
         __syncthreads();
         if (offt <= 1e-26 * dgt) break;
+        // One thread per pair of rotation pairs (k, l): it owns the 2 x 2 block rows {p_k, q_k} x columns {p_l, q_l}
+        // of S, recomputes both rotations itself from the pivots it reads (division-free, two rsqrt each) and applies
+        // J_k^T . J_l to its block in registers -- one barrier per round, no serial parameter phase, no second pass
+        // over S.  The same thread carries rows 2k, 2k+1 of R through J_l.
+        const int k = tid / JB, l = tid % JB;
+        double* Sn = S2[1];
         for (int rr = 0; rr < JS - 1; ++rr) {
-            if (tid < JB) {
-                int p, q;
-                if (tid == 0) { p = JS - 1; q = rr; }
-                else { p = (rr + tid) % (JS - 1); q = (rr - tid + (JS - 1)) % (JS - 1); }
-                if (p > q) { const int t = p; p = q; q = t; }
-                const double apq = S[p * JLD + q], app = S[p * JLD + p], aqq = S[q * JLD + q];
-                double c = 1.0, s = 0.0;
-                if (fabs(apq) > 1e-300 && fabs(apq) > 1e-18 * sqrt(fabs(app * aqq))) {
-                    const double tau = (aqq - app) / (2.0 * apq);
-                    const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
-                    c = 1.0 / sqrt(1.0 + t * t);
-                    s = t * c;
-                }
-                cs[tid] = c; sn[tid] = s; pp[tid] = p; qq[tid] = q;
+            int pk, qk, pl, ql;
+            jacobi_pair(rr, k, pk, qk);
+            jacobi_pair(rr, l, pl, ql);
+            double ck, sk, cl, sl;
+            jacobi_rotation(S[pk * JLD + qk], S[pk * JLD + pk], S[qk * JLD + qk], ck, sk);
+            jacobi_rotation(S[pl * JLD + ql], S[pl * JLD + pl], S[ql * JLD + ql], cl, sl);
+            const double b00 = S[pk * JLD + pl], b01 = S[pk * JLD + ql], b10 = S[qk * JLD + pl], b11 = S[qk * JLD + ql];
+            const double t00 = cl * b00 - sl * b01, t01 = sl * b00 + cl * b01;
+            const double t10 = cl * b10 - sl * b11, t11 = sl * b10 + cl * b11;
+            Sn[pk * JLD + pl] = ck * t00 - sk * t10; Sn[pk * JLD + ql] = ck * t01 - sk * t11;
+            Sn[qk * JLD + pl] = sk * t00 + ck * t10; Sn[qk * JLD + ql] = sk * t01 + ck * t11;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int i = 2 * k + h;
+                const double rp = R[i * JLD + pl], rq = R[i * JLD + ql];
+                R[i * JLD + pl] = cl * rp - sl * rq; R[i * JLD + ql] = sl * rp + cl * rq;
             }
-            __syncthreads();
-            // columns of S and R:  [x_p, x_q] <- [c x_p - s x_q, s x_p + c x_q]
-            for (int e = tid; e < JB * JS; e += 256) {
-                const int k = e / JS, i = e % JS;
-                const int p = pp[k], q = qq[k];
-                const double c = cs[k], s = sn[k];
-                const double sp = S[i * JLD + p], sq = S[i * JLD + q];
-                S[i * JLD + p] = c * sp - s * sq; S[i * JLD + q] = s * sp + c * sq;
-                const double rp = R[i * JLD + p], rq = R[i * JLD + q];
-                R[i * JLD + p] = c * rp - s * rq; R[i * JLD + q] = s * rp + c * rq;
-            }
-            __syncthreads();
-            // rows of S
-            for (int e = tid; e < JB * JS; e += 256) {
-                const int k = e / JS, j = e % JS;
-                const int p = pp[k], q = qq[k];
-                const double c = cs[k], s = sn[k];
-                const double sp = S[p * JLD + j], sq = S[q * JLD + j];
-                S[p * JLD + j] = c * sp - s * sq; S[q * JLD + j] = s * sp + c * sq;
-            }
-            __syncthreads();
+            __syncthreads();                               // one barrier per round: the next round reads Sn, writes S
+            double* t = S; S = Sn; Sn = t;
         }
     }
     double* Rout = rbuf + (int64_t)blockIdx.x * JS * JS;
-    for (int e = tid; e < JS * JS; e += 256) Rout[e] = R[(e / JS) * JLD + (e % JS)];
+    for (int e = tid; e < JS * JS; e += SUB_THREADS) Rout[e] = R[(e / JS) * JLD + (e % JS)];
 }
 
 // out(JS x JS) = L * M, all in LDS; 16 x 16 threads, each a JT x JT block
@@ -422,7 +449,7 @@ extern "C" dmrgx_status dmrgx_rdm_create(const dmrgx_sectors* left, const dmrgx_
         }
         if (conv) break;
         for (int r = 0; r < rounds; ++r) {
-            hipLaunchKernelGGL(jacobi_sub_kernel, dim3((unsigned)pairs.size()), dim3(256), 0, st, dm, d_pairs.as<PairRef>(), buf, buf + rbuf_off, r);
+            hipLaunchKernelGGL(jacobi_sub_kernel, dim3((unsigned)pairs.size()), dim3(SUB_THREADS), 0, st, dm, d_pairs.as<PairRef>(), buf, buf + rbuf_off, r);
             hipLaunchKernelGGL(jacobi_update_kernel, dim3((unsigned)tiles.size()), dim3(256), 0, st, dm, d_pstart.as<int32_t>(), d_tiles.as<UpdTask>(), buf, buf + rbuf_off, r);
             DMRGX_HIP(hipGetLastError());
         }
