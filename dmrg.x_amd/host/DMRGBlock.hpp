@@ -277,8 +277,23 @@ public:
         std::vector<std::vector<double*>> dptr(nops, std::vector<double*>((size_t)nn, nullptr));
         std::vector<double* const*> dpp(nops);
         const std::vector<int32_t> new_sizes(R.kept.begin(), R.kept.end());
+        // all rotated cells of all operators live in ONE device allocation (cells are views: buf + off), written by the
+        // rotation kernels -- no per-cell hipMalloc, no host mirror
+        size_t total = 0;
         for (size_t o = 0; o < nops; ++o) {
             if (!src[o]) SETERRQ1(mpi_comm, PETSC_ERR_ARG_CORRUPT, "Source operator %zu not created.", o);
+            for (int32_t a = 0; a < nn; ++a) {
+                const int32_t qc = R.old_sector[a] + src[o]->shift;
+                if (qc < 0 || qc >= (int32_t)R.old_sizes.size() || new_of_old[qc] < 0) continue;
+                total += (size_t)R.kept[a] * (size_t)R.kept[new_of_old[qc]];
+            }
+        }
+        std::shared_ptr<dmrgx_host::DevBuffer> arena;
+        try { arena = std::make_shared<dmrgx_host::DevBuffer>(total, dmrgx_host::DevBuffer::device_only_t{}); }
+        catch (const std::exception& e) { SETERRQ1(mpi_comm, PETSC_ERR_MEM, "rotated operator storage: %s", e.what()); }
+        double* const abase = arena->dev_uninitialised();
+        size_t cursor = 0;
+        for (size_t o = 0; o < nops; ++o) {
             src[o]->to_secop(ops[o], cellstore[o]);
             Mat d = std::make_shared<dmrgx_host::SectorMat>();
             d->shift = src[o]->shift; d->sizes = new_sizes;
@@ -288,8 +303,9 @@ public:
                 const int32_t ap = new_of_old[qc];
                 dmrgx_host::MatCell c;
                 c.q = a; c.nr = R.kept[a]; c.nc = R.kept[ap]; c.ld = c.nc;
-                c.buf = std::make_shared<dmrgx_host::DevBuffer>((size_t)c.nr * c.nc);
-                dptr[o][a] = c.buf->dev_uninitialised();
+                c.buf = arena; c.off = (int64_t)cursor;
+                dptr[o][a] = abase + cursor;
+                cursor += (size_t)c.nr * c.nc;
                 d->cells.push_back(c);
             }
             dpp[o] = dptr[o].data();

@@ -20,6 +20,9 @@ namespace dmrgx_host {
 class DevBuffer {
 public:
     explicit DevBuffer(size_t n) : n_(n), h_(n, 0.0), where_(HOST) {}
+    /** device-resident buffer whose content is produced by a kernel: no host mirror is allocated until someone asks for it */
+    struct device_only_t {};
+    DevBuffer(size_t n, device_only_t) : n_(n), where_(DEVICE) { alloc_dev(); }
     DevBuffer(const DevBuffer&) = delete;
     DevBuffer& operator=(const DevBuffer&) = delete;
     ~DevBuffer() { if (d_) dmrgx_free(d_); }
