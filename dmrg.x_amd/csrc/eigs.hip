@@ -38,7 +38,7 @@ multi_dot_kernel(const double* __restrict__ V, int64_t ldv, int nv, const double
     double acc[DOT_CHUNK];
 #pragma unroll
     for (int i = 0; i < DOT_CHUNK; ++i) acc[i] = 0.0;
-    for (int64_t e = (int64_t)blockIdx.x * DOT_THREADS + threadIdx.x; e < n; e += (int64_t)DOT_BLOCKS * DOT_THREADS) {
+    for (int64_t e = (int64_t)blockIdx.x * DOT_THREADS + threadIdx.x; e < n; e += (int64_t)gridDim.x * DOT_THREADS) {
         const double wv = w[e];
 #pragma unroll
         for (int i = 0; i < DOT_CHUNK; ++i) {
@@ -57,19 +57,19 @@ multi_dot_kernel(const double* __restrict__ V, int64_t ldv, int nv, const double
     if (threadIdx.x < DOT_CHUNK) {
         double s = 0.0;
         for (int wv = 0; wv < DOT_THREADS / 64; ++wv) s += red[wv][threadIdx.x];
-        partial[(int64_t)(v0 + threadIdx.x) * DOT_BLOCKS + blockIdx.x] = s;
+        partial[(int64_t)(v0 + threadIdx.x) * gridDim.x + blockIdx.x] = s;
     }
 }
 
 // out[i] = sum_b partial[i*DOT_BLOCKS + b]   (deterministic order)
 __global__ void __launch_bounds__(DOT_THREADS)
-reduce_partials_kernel(const double* __restrict__ partial, double* __restrict__ out, int count)
+reduce_partials_kernel(const double* __restrict__ partial, double* __restrict__ out, int count, int nblk)
 {
     __shared__ double red[DOT_THREADS / 64];
     const int i = blockIdx.x;
     if (i >= count) return;
     double s = 0.0;
-    for (int b = threadIdx.x; b < DOT_BLOCKS; b += DOT_THREADS) s += partial[(int64_t)i * DOT_BLOCKS + b];
+    for (int b = threadIdx.x; b < nblk; b += DOT_THREADS) s += partial[(int64_t)i * nblk + b];
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
@@ -87,7 +87,7 @@ multi_axpy_kernel(const double* __restrict__ V, int64_t ldv, int nv, const doubl
     __syncthreads();
     if (blockIdx.x == 0 && threadIdx.x < nv && hacc) hacc[threadIdx.x] += cs[threadIdx.x];
     double nrm = 0.0;
-    for (int64_t e = (int64_t)blockIdx.x * DOT_THREADS + threadIdx.x; e < n; e += (int64_t)DOT_BLOCKS * DOT_THREADS) {
+    for (int64_t e = (int64_t)blockIdx.x * DOT_THREADS + threadIdx.x; e < n; e += (int64_t)gridDim.x * DOT_THREADS) {
         double x = w[e];
         for (int i = 0; i < nv; ++i) x -= cs[i] * V[(int64_t)i * ldv + e];
         w[e] = x;
@@ -115,7 +115,7 @@ axpy_dot_kernel(const double* __restrict__ V, int64_t ldv, int nv, const double*
     double acc[FUSE_NV + 1];
 #pragma unroll
     for (int i = 0; i <= FUSE_NV; ++i) acc[i] = 0.0;
-    for (int64_t e = (int64_t)blockIdx.x * DOT_THREADS + threadIdx.x; e < n; e += (int64_t)DOT_BLOCKS * DOT_THREADS) {
+    for (int64_t e = (int64_t)blockIdx.x * DOT_THREADS + threadIdx.x; e < n; e += (int64_t)gridDim.x * DOT_THREADS) {
         double v[FUSE_NV];
 #pragma unroll
         for (int i = 0; i < FUSE_NV; ++i) v[i] = i < nv ? V[(int64_t)i * ldv + e] : 0.0;
@@ -140,7 +140,7 @@ axpy_dot_kernel(const double* __restrict__ V, int64_t ldv, int nv, const double*
         const int src = threadIdx.x < nv ? threadIdx.x : FUSE_NV;
         double s2 = 0.0;
         for (int wv = 0; wv < DOT_THREADS / 64; ++wv) s2 += red[wv][src];
-        partial[(int64_t)threadIdx.x * DOT_BLOCKS + blockIdx.x] = s2;
+        partial[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] = s2;
     }
 }
 
@@ -155,7 +155,7 @@ axpy_normalise_kernel(const double* __restrict__ V, int64_t ldv, int nv, const d
     if (blockIdx.x == 0 && threadIdx.x < nv && hacc) hacc[threadIdx.x] += cs[threadIdx.x];
     const double s2 = *nrm2;
     const double inv = s2 > 1e-290 ? 1.0 / sqrt(s2) : 0.0;
-    for (int64_t e = (int64_t)blockIdx.x * DOT_THREADS + threadIdx.x; e < n; e += (int64_t)DOT_BLOCKS * DOT_THREADS) {
+    for (int64_t e = (int64_t)blockIdx.x * DOT_THREADS + threadIdx.x; e < n; e += (int64_t)gridDim.x * DOT_THREADS) {
         double x = w[e];
         for (int i = 0; i < nv; ++i) x -= cs[i] * V[(int64_t)i * ldv + e];
         dst[e] = x * inv;
@@ -299,6 +299,7 @@ extern "C" dmrgx_status dmrgx_eigs_lowest(dmrgx_kron_plan* plan, const dmrgx_eig
     DMRGX_HIP(hipMemsetAsync(dW.p, 0, dW.bytes, st));
     if (dist) DMRGX_HIP(hipMemsetAsync(dX.p, 0, dX.bytes, st));
 
+    const int nblk = DOT_BLOCKS;      // (scaling the grid down with n was measured slower even at n = 1.6e5: these passes are latency-bound)
     auto allreduce = [&](double* buf, int64_t count) -> dmrgx_status {
         if (!dist) return DMRGX_OK;
         return opts->allreduce_sum(opts->user, buf, count, st);
@@ -306,16 +307,16 @@ extern "C" dmrgx_status dmrgx_eigs_lowest(dmrgx_kron_plan* plan, const dmrgx_eig
     // dots of w against V[0..nv) plus w.w  -> c1[0..nv]
     auto multi_dot = [&](int nv) -> dmrgx_status {
         const int chunks = (nv + 1 + DOT_CHUNK - 1) / DOT_CHUNK;
-        hipLaunchKernelGGL(multi_dot_kernel, dim3(DOT_BLOCKS, chunks), dim3(DOT_THREADS), 0, st, V, n, nv, w, n, dPartial.as<double>());
+        hipLaunchKernelGGL(multi_dot_kernel, dim3(nblk, chunks), dim3(DOT_THREADS), 0, st, V, n, nv, w, n, dPartial.as<double>());
         DMRGX_HIP(hipGetLastError());
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3(nv + 1), dim3(DOT_THREADS), 0, st, dPartial.as<double>(), c1, nv + 1);
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(nv + 1), dim3(DOT_THREADS), 0, st, dPartial.as<double>(), c1, nv + 1, nblk);
         DMRGX_HIP(hipGetLastError());
         return allreduce(c1, nv + 1);
     };
     // final == false: only subtract.  final == true: also set nrm = ||w_new||^2 from the dots just reduced.
     auto multi_axpy = [&](int nv, double* hacc, bool final) -> dmrgx_status {
         if (final) { hipLaunchKernelGGL(norm_after_projection_kernel, dim3(1), dim3(64), 0, st, c1, nv, nrm); DMRGX_HIP(hipGetLastError()); }
-        hipLaunchKernelGGL(multi_axpy_kernel, dim3(DOT_BLOCKS), dim3(DOT_THREADS), 0, st, V, n, nv, c1, w, n, dPartial.as<double>(), hacc);
+        hipLaunchKernelGGL(multi_axpy_kernel, dim3(nblk), dim3(DOT_THREADS), 0, st, V, n, nv, c1, w, n, dPartial.as<double>(), hacc);
         DMRGX_HIP(hipGetLastError());
         return DMRGX_OK;
     };
@@ -367,9 +368,9 @@ extern "C" dmrgx_status dmrgx_eigs_lowest(dmrgx_kron_plan* plan, const dmrgx_eig
             DMRGX_CHK(multi_dot(nv));                         // pass 1: c1 = V^T w                (one fused all-reduce)
             if (nv <= FUSE_NV) {
                 // w' = w - V c1 fused with pass 2's dots: c2 = V^T w', w'.w'            (one fused all-reduce)
-                hipLaunchKernelGGL(axpy_dot_kernel, dim3(DOT_BLOCKS), dim3(DOT_THREADS), 0, st, V, n, nv, c1, w, n, dPartial.as<double>(), Hrow(j));
+                hipLaunchKernelGGL(axpy_dot_kernel, dim3(nblk), dim3(DOT_THREADS), 0, st, V, n, nv, c1, w, n, dPartial.as<double>(), Hrow(j));
                 DMRGX_HIP(hipGetLastError());
-                hipLaunchKernelGGL(reduce_partials_kernel, dim3(nv + 1), dim3(DOT_THREADS), 0, st, dPartial.as<double>(), c2, nv + 1);
+                hipLaunchKernelGGL(reduce_partials_kernel, dim3(nv + 1), dim3(DOT_THREADS), 0, st, dPartial.as<double>(), c2, nv + 1, nblk);
                 DMRGX_HIP(hipGetLastError());
                 DMRGX_CHK(allreduce(c2, nv + 1));
             } else {
@@ -380,7 +381,7 @@ extern "C" dmrgx_status dmrgx_eigs_lowest(dmrgx_kron_plan* plan, const dmrgx_eig
             // beta^2 = w'.w' - |c2|^2 ; v_{j+1} = (w' - V c2) / beta
             hipLaunchKernelGGL(norm_after_projection_kernel, dim3(1), dim3(64), 0, st, c2, nv, nrm);
             DMRGX_HIP(hipGetLastError());
-            hipLaunchKernelGGL(axpy_normalise_kernel, dim3(DOT_BLOCKS), dim3(DOT_THREADS), 0, st, V, n, nv, c2, w, vec(j + 1), n, nrm, Hrow(j));
+            hipLaunchKernelGGL(axpy_normalise_kernel, dim3(nblk), dim3(DOT_THREADS), 0, st, V, n, nv, c2, w, vec(j + 1), n, nrm, Hrow(j));
             DMRGX_HIP(hipGetLastError());
             DMRGX_HIP(hipMemcpyAsync(Hrow(j) + m + 1, nrm, sizeof(double), hipMemcpyDeviceToDevice, st));
         }

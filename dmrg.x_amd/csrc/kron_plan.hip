@@ -105,16 +105,19 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const RedTile* __restr
 {
     const RedTile t = tiles[blockIdx.x];
     const RedTask k = tasks[t.task];
-    const int64_t mn = (int64_t)k.M * k.N;
+    const uint32_t mn = (uint32_t)k.M * (uint32_t)k.N, N = (uint32_t)k.N;     // a split block has < 2^31 elements (host check)
     const double* sl = arena + k.slab_off;
-    for (int i = threadIdx.x; i < RED_CHUNK; i += 256) {
-        const int64_t e = (int64_t)t.chunk * RED_CHUNK + i;
-        if (e >= mn) break;
-        const int32_t row = (int32_t)(e / k.N), col = (int32_t)(e - (int64_t)row * k.N);
-        double* d = y + k.dst_off + (int64_t)row * k.ldc + col;
-        double v = *d;
-        for (int s = 0; s < k.nslab; ++s) v += sl[(int64_t)s * mn + e];
-        *d = v;
+    double* yb = y + k.dst_off;
+#pragma unroll
+    for (int i = 0; i < RED_CHUNK / 256; ++i) {
+        const uint32_t e = (uint32_t)t.chunk * RED_CHUNK + (uint32_t)i * 256u + threadIdx.x;
+        if (e < mn) {
+            const uint32_t row = e / N, col = e - row * N;
+            double* d = yb + (size_t)row * k.ldc + col;
+            double v = *d;
+            for (int s = 0; s < k.nslab; ++s) v += sl[(size_t)s * mn + e];
+            *d = v;
+        }
     }
 }
 
@@ -244,6 +247,7 @@ struct Builder {
             const int32_t gemm_begin = groups[g].prod_begin + groups[g].n_axpy, gemm_end = groups[g].prod_end;
             int32_t S = (int32_t)std::min<double>(64.0, std::max(1.0, std::floor(cost / seg_target + 0.5)));
             S = std::max(1, std::min(S, gemm_end - gemm_begin));
+            if ((int64_t)groups[g].M * groups[g].N >= (int64_t)1 << 31) S = 1;      // slab_reduce_kernel indexes a block with 32 bits
             if (S == 1) { ggemm_append_tiles_mixed(tiles2b, tiles2, g, groups[g].M, groups[g].N, cost, big); continue; }
             max_split = std::max(max_split, S);
             const int64_t mn = (int64_t)groups[g].M * groups[g].N;
