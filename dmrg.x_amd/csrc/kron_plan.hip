@@ -108,17 +108,24 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const RedTile* __restr
     const uint32_t mn = (uint32_t)k.M * (uint32_t)k.N, N = (uint32_t)k.N;     // a split block has < 2^31 elements (host check)
     const double* sl = arena + k.slab_off;
     double* yb = y + k.dst_off;
+    constexpr int NE = RED_CHUNK / 256;
+    const uint32_t e0 = (uint32_t)t.chunk * RED_CHUNK + threadIdx.x;
+    double v[NE];
+    double* d[NE];
 #pragma unroll
-    for (int i = 0; i < RED_CHUNK / 256; ++i) {
-        const uint32_t e = (uint32_t)t.chunk * RED_CHUNK + (uint32_t)i * 256u + threadIdx.x;
-        if (e < mn) {
-            const uint32_t row = e / N, col = e - row * N;
-            double* d = yb + (size_t)row * k.ldc + col;
-            double v = *d;
-            for (int s = 0; s < k.nslab; ++s) v += sl[(size_t)s * mn + e];
-            *d = v;
-        }
+    for (int i = 0; i < NE; ++i) {
+        const uint32_t e = min(e0 + (uint32_t)i * 256u, mn - 1);        // clamped: every lane loads, only valid ones store
+        const uint32_t row = e / N, col = e - row * N;
+        d[i] = yb + (size_t)row * k.ldc + col;
+        v[i] = *d[i];
     }
+    for (int s = 0; s < k.nslab; ++s) {                                  // slab-major: NE independent loads in flight per step,
+        const double* p = sl + (size_t)s * mn;                           // each element still summed in slab order
+#pragma unroll
+        for (int i = 0; i < NE; ++i) v[i] += p[min(e0 + (uint32_t)i * 256u, mn - 1)];
+    }
+#pragma unroll
+    for (int i = 0; i < NE; ++i) if (e0 + (uint32_t)i * 256u < mn) *d[i] = v[i];
 }
 
 }  // namespace
