@@ -62,6 +62,11 @@ class AxpyTask(C.Structure):
                 ("nr", C.c_int32), ("nc", C.c_int32), ("transposed", C.c_int32), ("alpha", C.c_double)]
 
 
+class GemmTask(C.Structure):
+    _fields_ = [("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("accumulate", C.c_int32),
+                ("A", C.c_void_p), ("lda", C.c_int64), ("B", C.c_void_p), ("ldb", C.c_int64), ("C", C.c_void_p), ("ldc", C.c_int64)]
+
+
 class Rotation(C.Structure):
     _fields_ = [("n_new", C.c_int32), ("old_sector", C.POINTER(C.c_int32)), ("kept", C.POINTER(C.c_int32)), ("rot_t", C.POINTER(C.c_void_p))]
 
@@ -111,6 +116,8 @@ SIGNATURES = {
     "dmrgx_memcpy_d2d": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "dmrgx_memset_zero": (C.c_int32, [C.c_void_p, C.c_size_t, C.c_void_p]),
     "dmrgx_stream_sync": (C.c_int32, [C.c_void_p]),
+    "dmrgx_dgemm_batch": (C.c_int32, [C.c_int32, C.c_void_p, C.c_void_p]),
+    "dmrgx_dot": (C.c_int32, [C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.c_void_p]),
     "dmrgx_eigs_lowest": (C.c_int32, [C.c_void_p, C.POINTER(EigsOpts), C.POINTER(C.c_double), C.c_void_p,
                                       C.POINTER(EigsStats), C.c_void_p]),
 }

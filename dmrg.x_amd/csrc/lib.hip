@@ -64,6 +64,37 @@ extern "C" dmrgx_status dmrgx_dgemm_nn(int32_t M, int32_t N, int32_t K, const do
     return DMRGX_OK;
 }
 
+extern "C" dmrgx_status dmrgx_dgemm_batch(int32_t count, const dmrgx_gemm_task* t, void* stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (count < 0 || (count > 0 && !t)) DMRGX_FAIL(DMRGX_ERR_ARG, "dgemm_batch: bad argument");
+    std::vector<GProd> prods;
+    std::vector<GGroup> groups;
+    std::vector<GTile> tiles, big;
+    for (int32_t i = 0; i < count; ++i) {
+        const dmrgx_gemm_task& g = t[i];
+        if (g.M < 0 || g.N < 0 || g.K < 0 || (g.M && g.N && (!g.C || g.ldc < g.N)) || (g.M && g.N && g.K && (!g.A || !g.B || g.lda < g.K || g.ldb < g.N)))
+            DMRGX_FAIL(DMRGX_ERR_ARG, "dgemm_batch: bad task %d (M=%d N=%d K=%d)", i, g.M, g.N, g.K);
+        if (g.M == 0 || g.N == 0) continue;
+        const int32_t p0 = (int32_t)prods.size();
+        if (g.K > 0) prods.push_back(GProd{g.A, g.B, (int32_t)g.lda, (int32_t)g.ldb, g.K, GPROD_GEMM, 1.0});
+        groups.push_back(GGroup{g.C, (int32_t)g.ldc, g.M, g.N, p0, (int32_t)prods.size(), 0, g.accumulate ? 1 : 0});
+        ggemm_append_tiles_mixed(big, tiles, (int32_t)groups.size() - 1, g.M, g.N, (g.K + GG_BK - 1) / GG_BK);
+    }
+    if (groups.empty()) return DMRGX_OK;
+    if (prods.empty()) prods.push_back(GProd{nullptr, nullptr, 0, 0, 0, GPROD_GEMM, 0.0});
+    ggemm_schedule(tiles); ggemm_schedule(big, 2);
+    DevBuf dp, dg, dt, db;
+    DMRGX_CHK(upload(dp, prods, st));
+    DMRGX_CHK(upload(dg, groups, st));
+    DMRGX_CHK(upload(dt, tiles, st));
+    DMRGX_CHK(upload(db, big, st));
+    DMRGX_CHK(ggemm_launch(db.as<GTile>(), dg.as<GGroup>(), dp.as<GProd>(), (int32_t)big.size(), st, 1));
+    DMRGX_CHK(ggemm_launch(dt.as<GTile>(), dg.as<GGroup>(), dp.as<GProd>(), (int32_t)tiles.size(), st, 0));
+    DMRGX_HIP(hipStreamSynchronize(st));   // tables are freed on return
+    return DMRGX_OK;
+}
+
 extern "C" dmrgx_status dmrgx_malloc(void** p, size_t bytes)
 {
     if (!p) DMRGX_FAIL(DMRGX_ERR_ARG, "malloc: null argument");
@@ -83,3 +114,39 @@ extern "C" dmrgx_status dmrgx_memcpy_d2d(void* d, const void* s, size_t n, void*
 extern "C" dmrgx_status dmrgx_memset_zero(void* d, size_t n, void* st)
 { if (n) DMRGX_HIP(hipMemsetAsync(d, 0, n, (hipStream_t)st)); return DMRGX_OK; }
 extern "C" dmrgx_status dmrgx_stream_sync(void* st) { DMRGX_HIP(hipStreamSynchronize((hipStream_t)st)); return DMRGX_OK; }
+
+// ---- <x, y> on the device (correlators: VecDot of the reference, include/DMRGBlockContainer.hpp:2291) ------------------
+namespace dmrgx {
+namespace {
+constexpr int VDOT_BLOCKS = 512, VDOT_THREADS = 256;
+__global__ void __launch_bounds__(VDOT_THREADS) vdot_partial_kernel(const double* __restrict__ x, const double* __restrict__ y, int64_t n, double* __restrict__ partial)
+{
+    __shared__ double red[VDOT_THREADS / 64];
+    double s = 0.0;
+    for (int64_t e = (int64_t)blockIdx.x * VDOT_THREADS + threadIdx.x; e < n; e += (int64_t)VDOT_BLOCKS * VDOT_THREADS) s += x[e] * y[e];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { double t = 0.0; for (int k = 0; k < VDOT_THREADS / 64; ++k) t += red[k]; partial[blockIdx.x] = t; }
+}
+}  // namespace
+}  // namespace dmrgx
+
+extern "C" dmrgx_status dmrgx_dot(int64_t n, const double* x_dev, const double* y_dev, double* host_out, void* stream)
+{
+    if (n < 0 || !host_out || (n > 0 && (!x_dev || !y_dev))) DMRGX_FAIL(DMRGX_ERR_ARG, "dot: bad argument");
+    *host_out = 0.0;
+    if (n == 0) return DMRGX_OK;
+    hipStream_t st = (hipStream_t)stream;
+    DevBuf part;
+    DMRGX_CHK(part.alloc(dmrgx::VDOT_BLOCKS * sizeof(double)));
+    hipLaunchKernelGGL(dmrgx::vdot_partial_kernel, dim3(dmrgx::VDOT_BLOCKS), dim3(dmrgx::VDOT_THREADS), 0, st, x_dev, y_dev, n, part.as<double>());
+    DMRGX_HIP(hipGetLastError());
+    std::vector<double> h(dmrgx::VDOT_BLOCKS);
+    DMRGX_HIP(hipMemcpyAsync(h.data(), part.p, h.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    DMRGX_HIP(hipStreamSynchronize(st));
+    double t = 0.0;
+    for (double v : h) t += v;          // fixed order: reproducible
+    *host_out = t;
+    return DMRGX_OK;
+}

@@ -229,6 +229,7 @@ public:
     }
     PetscErrorCode AssembleOperators() { return 0; }
 
+    PetscBool HasSm() const { return init_Sm; }
     /** Sm(i) = Sp(i)^T as a view: the kernels read Sp transposed, nothing is copied. */
     PetscErrorCode CreateSm()
     {

@@ -96,6 +96,7 @@ public:
         fprintf(fp_timings, "[\n");
         ierr = PetscFOpen(mpi_comm, (data_dir + "EntanglementSpectra.json").c_str(), "w", &fp_entanglement); CHKERRQ(ierr);
         fprintf(fp_entanglement, "[\n");
+        ierr = PetscFOpen(mpi_comm, (data_dir + "Correlations.json").c_str(), "w", &fp_corr); CHKERRQ(ierr);
         ierr = PetscFOpen(mpi_comm, (data_dir + "DMRGRun.json").c_str(), "w", &fp_data); CHKERRQ(ierr);
         fprintf(fp_data, "{\n"); Ham.SaveOut(fp_data); fprintf(fp_data, ",\n  \"QNSector\": %g", qn_sector); fflush(fp_data);
 
@@ -127,12 +128,33 @@ public:
         return 0;
     }
 
-    /** Registers an n-point correlator (kept for the driver; measurements are SURVEY 8f N3). */
+    /** Registers an n-point correlator, measured on the superblock ground state at the centre of the lattice at the end
+        of the warm-up and of every sweep.  Sites are numbered on the superblock; an operator on the right half is
+        carried over to the environment block by reflection (include/DMRGBlockContainer.hpp:627-682 of the reference). */
     PetscErrorCode SetUpCorrelation(const std::vector<Op>& OpList, const std::string& name, const std::string& desc)
     {
         if (!init) SETERRQ(mpi_comm, 1, "Initialize() must be called first.");
-        for (const Op& o : OpList) if (o.idx < 0 || o.idx >= num_sites) SETERRQ2(mpi_comm, 1, "Operator index %lld out of range [0,%lld).", LLD(o.idx), LLD(num_sites));
-        corr_names.push_back(name); corr_descs.push_back(desc); corr_ops.push_back(OpList);
+        if (LoopType == SweepStep) SETERRQ(mpi_comm, 1, "Setup correlation functions should be called before starting the sweeps.");
+        Correlator m;
+        m.idx = (PetscInt)measurements.size();
+        m.name = name; m.desc1 = desc;
+        m.desc2 += "< ";
+        for (const Op& op : OpList) m.desc2 += OpToStr(op.OpType) + "_{" + std::to_string(op.idx) + "} ";
+        m.desc2 += ">";
+        for (const Op& op : OpList) {
+            if (0 <= op.idx && op.idx < num_sites / 2) m.SysOps.push_back(op);
+            else if (num_sites / 2 <= op.idx && op.idx < num_sites) m.EnvOps.push_back({op.OpType, num_sites - 1 - op.idx});
+            else SETERRQ2(mpi_comm, 1, "Operator index must be in the range [0,%lld). Got %lld.", LLD(num_sites), LLD(op.idx));
+        }
+        if (m.SysOps.empty()) { m.SysOps = m.EnvOps; m.EnvOps.clear(); }      /* reflection symmetry */
+        m.desc3 += "< ( ";
+        for (const Op& op : m.SysOps) m.desc3 += OpToStr(op.OpType) + "_{" + std::to_string(op.idx) + "} ";
+        if (m.SysOps.empty()) m.desc3 += "1 ";
+        m.desc3 += ") (x) ( ";
+        for (const Op& op : m.EnvOps) m.desc3 += OpToStr(op.OpType) + "_{" + std::to_string(op.idx) + "} ";
+        if (m.EnvOps.empty()) m.desc3 += "1 ";
+        m.desc3 += ") >";
+        measurements.push_back(m);
         return 0;
     }
 
@@ -250,6 +272,10 @@ public:
         if (fp_step) { fprintf(fp_step, "\n  ]\n}\n"); fclose(fp_step); fp_step = NULL; }
         if (fp_timings) { fprintf(fp_timings, "\n  ]\n}\n"); fclose(fp_timings); fp_timings = NULL; }
         if (fp_entanglement) { fprintf(fp_entanglement, "\n]\n"); fclose(fp_entanglement); fp_entanglement = NULL; }
+        if (fp_corr) {
+            if (!corr_headers_printed) { PetscErrorCode e2 = PrintCorrelationHeaders(); CHKERRQ(e2); }
+            fprintf(fp_corr, "\n  ]\n}\n"); fclose(fp_corr); fp_corr = NULL;
+        }
         if (fp_data) {
             fprintf(fp_data, ",\n  \"Sweeps\": [");
             for (size_t i = 0; i < sweeps_mstates.size(); ++i) fprintf(fp_data, "%s%lld", i ? ", " : "", LLD(sweeps_mstates[i]));
@@ -339,7 +365,7 @@ public:
 
         BasisTransformation BT_L, BT_R;
         ierr = GetTruncation(KronBlocks, gsv_r, MStates, BT_L, BT_R); CHKERRQ(ierr);
-        (void)do_measurements;                                            /* correlators: SURVEY 8f N3 */
+        ierr = CalculateCorrelations_BlockDiag(KronBlocks, gsv_r, do_measurements); CHKERRQ(ierr);
         ierr = VecDestroy(&gsv_r); CHKERRQ(ierr);
         ierr = SysBlockOut.Destroy(); CHKERRQ(ierr);
         ierr = EnvBlockOut.Destroy(); CHKERRQ(ierr);
@@ -368,6 +394,146 @@ public:
         ierr = SaveStepData(step); CHKERRQ(ierr);
         ierr = SaveTimingsData(timings); CHKERRQ(ierr);
         ++GlobIdx; ++StepIdx;
+        return 0;
+    }
+
+    /** Correlations.json: {"info": [...one entry per correlator...], "values": [[...one row per measurement...]]}
+        (schema of include/DMRGBlockContainer.hpp:2071-2097,2318-2335 of the reference; values are written with 15
+        significant digits instead of the reference's %g). */
+    PetscErrorCode PrintCorrelationHeaders()
+    {
+        if (mpi_rank || !fp_corr || corr_headers_printed) return 0;
+        fprintf(fp_corr, "{\n  \"info\" :\n  [\n");
+        for (size_t i = 0; i < measurements.size(); ++i) {
+            const Correlator& c = measurements[i];
+            fprintf(fp_corr, "%s    {\n      \"corrIdx\" : %lld,\n      \"name\"    : \"%s\",\n      \"desc1\"   : \"%s\",\n      \"desc2\"   : \"%s\",\n      \"desc3\"   : \"%s\"\n    }",
+                    i ? ",\n" : "", LLD(c.idx), c.name.c_str(), c.desc1.c_str(), c.desc2.c_str(), c.desc3.c_str());
+        }
+        fprintf(fp_corr, "\n  ],\n  \"values\" :\n  [\n");
+        fflush(fp_corr);
+        corr_headers_printed = PETSC_TRUE;
+        return 0;
+    }
+
+    /** Product of the listed single-site operators of one block, in the block's basis (the reference multiplies the
+        retrieved matrices with MatMatMult, include/DMRGBlockContainer.hpp:2333-2410).  A single operator is handed out
+        as it is stored (views included), an empty list is the identity; products are formed on the device, one MFMA
+        GEMM per sector block. */
+    typedef std::map<std::pair<int, PetscInt>, Mat> DenseCache;        /**< (operator type, site) -> dense form, per measurement */
+    PetscErrorCode CalculateOperatorProduct(Block& blk, const std::vector<Op>& ops, Mat& out, DenseCache& cache, const bool want_dense = false)
+    {
+        PetscErrorCode ierr;
+        auto fetch = [&](const Op& o, Mat& m) -> PetscErrorCode {
+            if (o.idx < 0 || o.idx >= blk.NumSites()) SETERRQ2(mpi_comm, PETSC_ERR_ARG_OUTOFRANGE, "Correlator site %lld outside the block's %lld sites.", LLD(o.idx), LLD(blk.NumSites()));
+            switch (o.OpType) {
+                case OpSz: m = blk.Sz(o.idx); break;
+                case OpSp: m = blk.Sp(o.idx); break;
+                case OpSm: m = blk.Sm(o.idx); break;
+                default: SETERRQ(mpi_comm, PETSC_ERR_ARG_WRONG, "Correlators take Sz, Sp and Sm operators.");
+            }
+            return 0;
+        };
+        auto dense = [&](const Op& o, Mat& d) -> PetscErrorCode {
+            const auto key = std::make_pair((int)o.OpType, o.idx);
+            auto it = cache.find(key);
+            if (it != cache.end()) { d = it->second; return 0; }
+            Mat m;
+            PetscErrorCode e = fetch(o, m); CHKERRQ(e);
+            e = dmrgx_host::SectorMatDensify(m, d); if (e) SETERRQ1(mpi_comm, 1, "operator product: %s", dmrgx_last_error());
+            cache[key] = d;
+            return 0;
+        };
+        if (ops.empty()) {                                          /* identity: one scaled-identity cell per sector */
+            out = std::make_shared<dmrgx_host::SectorMat>();
+            out->shift = 0; out->sizes = blk.Magnetization.Sizes32();
+            for (int32_t q = 0; q < (int32_t)out->sizes.size(); ++q) {
+                dmrgx_host::MatCell c;
+                c.q = q; c.nr = c.nc = out->sizes[q]; c.kind = DMRGX_CELL_IDENT; c.scale = 1.0;
+                out->cells.push_back(c);
+            }
+            return 0;
+        }
+        if (ops.size() == 1 && !want_dense) return fetch(ops[0], out);
+        Mat prod;
+        ierr = dense(ops[0], prod); CHKERRQ(ierr);
+        for (size_t i = 1; i < ops.size(); ++i) {
+            Mat next, tmp;
+            ierr = dense(ops[i], next); CHKERRQ(ierr);
+            ierr = dmrgx_host::SectorMatMatMult(prod, next, tmp); if (ierr) SETERRQ1(mpi_comm, 1, "operator product: %s", dmrgx_last_error());
+            prod = tmp;
+        }
+        out = prod;
+        return 0;
+    }
+
+    /** < psi | (product of SysOps) (x) (product of EnvOps) | psi > for every registered correlator, through a one-term
+        superblock plan, one MatMult and one dot product each (include/DMRGBlockContainer.hpp:2255-2303). */
+    PetscErrorCode CalculateCorrelations_BlockDiag(KronBlocks_t& KronBlocks, const Vec& gsv_r, const PetscBool flg = PETSC_TRUE)
+    {
+        PetscErrorCode ierr = PrintCorrelationHeaders(); CHKERRQ(ierr);
+        if (!flg) return 0;
+        std::vector<PetscScalar> CorrValues(measurements.size(), 0.0);
+        Block& L = KronBlocks.LeftBlockRefMod();
+        Block& R = KronBlocks.RightBlockRefMod();
+        bool need_sm = false;
+        for (const Correlator& c : measurements) { for (const Op& o : c.SysOps) need_sm |= (o.OpType == OpSm); for (const Op& o : c.EnvOps) need_sm |= (o.OpType == OpSm); }
+        const bool l_had = L.HasSm(), r_had = R.HasSm();
+        if (need_sm && !l_had) { ierr = L.CreateSm(); CHKERRQ(ierr); }
+        if (need_sm && !R.HasSm()) { ierr = R.CreateSm(); CHKERRQ(ierr); }
+        Vec Op_Vec;
+        {
+            Op_Vec = std::make_shared<dmrgx_host::VecImpl>();
+            Op_Vec->n = gsv_r->n;
+            Op_Vec->buf = std::make_shared<dmrgx_host::DevBuffer>((size_t)gsv_r->n, dmrgx_host::DevBuffer::device_only_t{});
+        }
+        DenseCache cacheL, cacheR;
+        const PetscInt nkb = KronBlocks.size();
+        for (size_t ic = 0; ic < measurements.size(); ++ic) {
+            const Correlator& c = measurements[ic];
+            int shift = 0;
+            for (const Op& o : c.SysOps) shift += int(o.OpType);
+            for (const Op& o : c.EnvOps) shift += int(o.OpType);
+            if (shift != 0) { CorrValues[c.idx] = 0.0; continue; }          /* changes the total Sz: no overlap with the target sector */
+            double v = 0.0;
+            if (c.EnvOps.empty()) {
+                /* operators on the system block only: (P (x) 1) psi is Y_k = P[IL(k)] X_k for every KronBlock -- one grouped
+                   MFMA launch over all blocks, no plan (the bulk of the driver's correlators) */
+                Mat P;
+                ierr = CalculateOperatorProduct(L, c.SysOps, P, cacheL, true); CHKERRQ(ierr);
+                if (dmrgx_memset_zero(Op_Vec->buf->dev_uninitialised(), (size_t)gsv_r->n * sizeof(double), nullptr)) SETERRQ1(mpi_comm, 1, "%s", dmrgx_last_error());
+                std::vector<dmrgx_gemm_task> tasks;
+                const double* x = gsv_r->buf->dev_ro();
+                double* y = Op_Vec->buf->dev_uninitialised();
+                for (PetscInt k = 0; k < nkb; ++k) {
+                    const int32_t il = (int32_t)KronBlocks.LeftIdx(k), ir = (int32_t)KronBlocks.RightIdx(k);
+                    const int32_t nl = (int32_t)L.Magnetization.Sizes(il), nr = (int32_t)R.Magnetization.Sizes(ir);
+                    for (const dmrgx_host::MatCell& pc : P->cells) {
+                        if (pc.q != il) continue;
+                        tasks.push_back(dmrgx_gemm_task{nl, nr, nl, 0, pc.buf->dev_ro() + pc.off, pc.ld, x + KronBlocks.Offsets(k), nr, y + KronBlocks.Offsets(k), nr});
+                    }
+                }
+                if (!tasks.empty() && dmrgx_dgemm_batch((int32_t)tasks.size(), tasks.data(), nullptr)) SETERRQ1(mpi_comm, 1, "dmrgx_dgemm_batch: %s", dmrgx_last_error());
+            } else {
+                Mat PL, PR, KronOp;
+                ierr = CalculateOperatorProduct(L, c.SysOps, PL, cacheL); CHKERRQ(ierr);
+                ierr = CalculateOperatorProduct(R, c.EnvOps, PR, cacheR); CHKERRQ(ierr);
+                ierr = KronBlocks.KronConstructShifted(PL, PR, KronOp); CHKERRQ(ierr);
+                ierr = MatMult(KronOp, gsv_r, Op_Vec); CHKERRQ(ierr);
+                ierr = MatDestroy_KronSumShell(&KronOp); CHKERRQ(ierr);
+                ierr = MatDestroy(&KronOp); CHKERRQ(ierr);
+            }
+            if (dmrgx_dot(gsv_r->n, Op_Vec->buf->dev_ro(), gsv_r->buf->dev_ro(), &v, nullptr)) SETERRQ1(mpi_comm, 1, "dmrgx_dot: %s", dmrgx_last_error());
+            CorrValues[c.idx] = v;
+        }
+        if (need_sm && !l_had) { ierr = L.DestroySm(); CHKERRQ(ierr); }
+        if (need_sm && !r_had && R.HasSm()) { ierr = R.DestroySm(); CHKERRQ(ierr); }
+        if (!mpi_rank && fp_corr) {
+            fprintf(fp_corr, "%s    [", corr_printed_first ? ",\n" : "");
+            corr_printed_first = PETSC_TRUE;
+            for (size_t i = 0; i < measurements.size(); ++i) fprintf(fp_corr, "%s %.15g", i ? "," : "", CorrValues[i]);
+            fprintf(fp_corr, " ]");
+            fflush(fp_corr);
+        }
         return 0;
     }
 
@@ -501,7 +667,7 @@ private:
     PetscReal eps_tol = 1.0e-8;     /* SLEPc's default relative residual tolerance */
     PetscInt eps_ncv = 16, eps_max_it = 1000;
     std::string scratch_dir, data_dir;
-    FILE *fp_step = NULL, *fp_timings = NULL, *fp_entanglement = NULL, *fp_data = NULL;
+    FILE *fp_step = NULL, *fp_timings = NULL, *fp_entanglement = NULL, *fp_data = NULL, *fp_corr = NULL;
     PetscInt mwarmup = 0, nsweeps = 0, msweep_idx = 0;
     std::vector<PetscInt> msweeps, maxnsweeps, sweeps_mstates;
     SweepMode_t sweep_mode = SWEEP_MODE_NULL;
@@ -516,8 +682,13 @@ private:
     PetscLogDouble t0abs = 0.0;
     PetscInt total_matmults = 0, last_sweep_steps = 0, last_sweep_matmults = 0;
     double total_eigs_seconds = 0.0, last_sweep_seconds = 0.0;
-    std::vector<std::string> corr_names, corr_descs;
-    std::vector<std::vector<Op>> corr_ops;
+    struct Correlator {
+        PetscInt idx = 0;
+        std::vector<Op> SysOps, EnvOps;     /**< operators on the (enlarged) system / environment block, block-local site index */
+        std::string name, desc1, desc2, desc3;
+    };
+    std::vector<Correlator> measurements;
+    PetscBool corr_headers_printed = PETSC_FALSE, corr_printed_first = PETSC_FALSE;
 };
 
 #endif

@@ -117,15 +117,26 @@ public:
         return BuildPlan(LeftBlock.H, RightBlock.H, TermsLR, MatOut);
     }
 
-    /** Single product Mat_L (x) Mat_R on the KronBlocks (correlators), matrix-free like the Hamiltonian. */
+    /** Single product Mat_L (x) Mat_R on the KronBlocks (correlators), matrix-free like the Hamiltonian
+        (src/DMRGKron.cpp:635-693 of the reference).  The operator types are checked against the matrices' sector
+        blocks as the reference does; the matrices carry their own sector shift (a transposed view such as Sm(i) is read
+        transposed, never materialised). */
     PetscErrorCode KronConstruct(const Mat& Mat_L, const Op_t& OpType_L, const Mat& Mat_R, const Op_t& OpType_R, Mat& MatOut)
     {
         PetscErrorCode ierr;
         ierr = LeftBlock.MatCheckOperatorBlocks(OpType_L, Mat_L); CHKERRQ(ierr);
         ierr = RightBlock.MatCheckOperatorBlocks(OpType_R, Mat_R); CHKERRQ(ierr);
+        return KronConstructShifted(Mat_L, Mat_R, MatOut);
+    }
+
+    /** Same, for operator products whose total sector shift is not one of the Op_t values (e.g. Sp_i Sp_j on one side):
+        the shifts are read from the matrices. */
+    PetscErrorCode KronConstructShifted(const Mat& Mat_L, const Mat& Mat_R, Mat& MatOut)
+    {
+        if (!Mat_L || !Mat_R) SETERRQ(mpi_comm, PETSC_ERR_ARG_CORRUPT, "KronConstruct: null operator.");
         extra_left = Mat_L; extra_right = Mat_R;
-        std::vector<Hamiltonians::Term> one = {{1.0, OpType_L, -1, OpType_R, -1}};
-        ierr = BuildPlan(nullptr, nullptr, one, MatOut);
+        std::vector<Hamiltonians::Term> one = {{1.0, OpSz, -1, OpSz, -1}};
+        PetscErrorCode ierr = BuildPlan(nullptr, nullptr, one, MatOut);
         extra_left = nullptr; extra_right = nullptr;
         return ierr;
     }
@@ -151,8 +162,8 @@ private:
             if (!m) return -1;
             store.emplace_back();
             dmrgx_secop so;
-            if (m->transpose_of) m->transpose_of->to_secop(so, store.back(), true, (int32_t)op);
-            else if (op == OpSm) m->to_secop(so, store.back(), true, -1);
+            if (m->transpose_of) m->transpose_of->to_secop(so, store.back(), true, -m->transpose_of->shift);
+            else if (site >= 0 && op == OpSm) m->to_secop(so, store.back(), true, -1);   /* block operator Sp(site) read as Sm */
             else m->to_secop(so, store.back());
             ops.push_back(so);
             idx[key] = (int32_t)ops.size() - 1;

@@ -189,6 +189,93 @@ inline PetscErrorCode MatDestroy(Mat* m) { if (m && *m) { (*m)->release(); m->re
 inline PetscErrorCode VecDestroy(Vec* v) { if (v) v->reset(); return 0; }
 inline PetscErrorCode MatGetSize(const Mat& m, PetscInt* M, PetscInt* N) { if (!m) return PETSC_ERR_ARG_CORRUPT; *M = *N = m->N(); return 0; }
 
+/** Dense form of an operator: one device-resident dense cell per sector block (q -> q+shift), the cells of `src`
+    accumulated into it on the device (dmrgx_cells_axpy: dense, identity and -- for a transposed view such as Sm(i) --
+    transposed sources).  Used for operator products inside one block basis (correlators,
+    include/DMRGBlockContainer.hpp:2333-2410 of the reference); never on the superblock path. */
+inline PetscErrorCode SectorMatDensify(const Mat& src_in, Mat& out)
+{
+    if (!src_in) return PETSC_ERR_ARG_CORRUPT;
+    const bool tr = (bool)src_in->transpose_of;
+    const Mat src = tr ? src_in->transpose_of : src_in;
+    const int32_t shift = tr ? -src->shift : src->shift;
+    const int32_t ns = (int32_t)src->sizes.size();
+    out = std::make_shared<SectorMat>();
+    out->shift = shift; out->sizes = src->sizes;
+    std::vector<int32_t> cell_of_sector((size_t)ns, -1);
+    size_t total = 0;
+    for (int32_t q = 0; q < ns; ++q) {
+        const int32_t qc = q + shift;
+        if (qc < 0 || qc >= ns) continue;
+        total += (size_t)src->sizes[q] * (size_t)src->sizes[qc];
+    }
+    std::shared_ptr<DevBuffer> arena;
+    try { arena = std::make_shared<DevBuffer>(total, DevBuffer::device_only_t{}); } catch (const std::exception&) { return PETSC_ERR_MEM; }
+    double* base = arena->dev_uninitialised();
+    if (total && dmrgx_memset_zero(base, total * sizeof(double), nullptr)) return 1;
+    size_t cursor = 0;
+    for (int32_t q = 0; q < ns; ++q) {
+        const int32_t qc = q + shift;
+        if (qc < 0 || qc >= ns) continue;
+        MatCell c;
+        c.q = q; c.nr = src->sizes[q]; c.nc = src->sizes[qc]; c.ld = c.nc; c.buf = arena; c.off = (int64_t)cursor;
+        cursor += (size_t)c.nr * c.nc;
+        cell_of_sector[(size_t)q] = (int32_t)out->cells.size();
+        out->cells.push_back(c);
+    }
+    std::vector<dmrgx_axpy_task> tasks;
+    for (MatCell& c : src->cells) {
+        const int32_t qdst = tr ? c.q + src->shift : c.q;           /* transposed: block (q -> q+s) lands in row sector q+s */
+        if (qdst < 0 || qdst >= ns || cell_of_sector[(size_t)qdst] < 0) continue;
+        const MatCell& d = out->cells[(size_t)cell_of_sector[(size_t)qdst]];
+        double* blk = base + d.off;
+        dmrgx_axpy_task t;
+        t.dst_base = blk;
+        t.ldd = d.ld;
+        t.transposed = tr ? 1 : 0;
+        if (tr) { t.dst = blk + (int64_t)c.c0 * d.ld + c.r0; t.nr = c.nc; t.nc = c.nr; }
+        else    { t.dst = blk + (int64_t)c.r0 * d.ld + c.c0; t.nr = c.nr; t.nc = c.nc; }
+        if (c.kind == DMRGX_CELL_DENSE) { t.src = c.buf->dev_ro() + c.off; t.lds = c.ld; t.alpha = 1.0; }
+        else { t.src = nullptr; t.lds = 0; t.alpha = c.scale; }
+        tasks.push_back(t);
+    }
+    if (!tasks.empty() && dmrgx_cells_axpy((int32_t)tasks.size(), tasks.data(), nullptr)) return 1;
+    return 0;
+}
+
+/** C = A * B for two operators in dense form on the same block basis (shifts add); per row sector one MFMA GEMM. */
+inline PetscErrorCode SectorMatMatMult(const Mat& A, const Mat& B, Mat& C)
+{
+    if (!A || !B || A->sizes != B->sizes) return PETSC_ERR_ARG_CORRUPT;
+    const int32_t ns = (int32_t)A->sizes.size(), sA = A->shift, sB = B->shift;
+    C = std::make_shared<SectorMat>();
+    C->shift = sA + sB; C->sizes = A->sizes;
+    size_t total = 0;
+    for (int32_t q = 0; q < ns; ++q) { const int32_t qc = q + sA + sB; if (qc >= 0 && qc < ns) total += (size_t)A->sizes[q] * (size_t)A->sizes[qc]; }
+    std::shared_ptr<DevBuffer> arena;
+    try { arena = std::make_shared<DevBuffer>(total, DevBuffer::device_only_t{}); } catch (const std::exception&) { return PETSC_ERR_MEM; }
+    double* base = arena->dev_uninitialised();
+    if (total && dmrgx_memset_zero(base, total * sizeof(double), nullptr)) return 1;
+    auto cell_at = [](const Mat& M, int32_t q) -> const MatCell* { for (const MatCell& c : M->cells) if (c.q == q) return &c; return nullptr; };
+    size_t cursor = 0;
+    std::vector<dmrgx_gemm_task> tasks;
+    for (int32_t q = 0; q < ns; ++q) {
+        const int32_t qa = q + sA, qc = qa + sB;
+        if (qc < 0 || qc >= ns) continue;
+        MatCell c;
+        c.q = q; c.nr = A->sizes[q]; c.nc = A->sizes[qc]; c.ld = c.nc; c.buf = arena; c.off = (int64_t)cursor;
+        cursor += (size_t)c.nr * c.nc;
+        C->cells.push_back(c);
+        if (qa < 0 || qa >= ns) continue;                            /* the intermediate sector does not exist: zero block */
+        const MatCell* a = cell_at(A, q);
+        const MatCell* b = cell_at(B, qa);
+        if (!a || !b || c.nr == 0 || c.nc == 0 || a->nc == 0) continue;
+        tasks.push_back(dmrgx_gemm_task{c.nr, c.nc, a->nc, 0, a->buf->dev_ro() + a->off, a->ld, b->buf->dev_ro() + b->off, b->ld, base + c.off, c.ld});
+    }
+    if (!tasks.empty() && dmrgx_dgemm_batch((int32_t)tasks.size(), tasks.data(), nullptr)) return 1;   /* one grouped launch */
+    return 0;
+}
+
 }  // namespace dmrgx_host
 
 using dmrgx_host::Mat;

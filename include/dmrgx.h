@@ -155,6 +155,16 @@ dmrgx_status dmrgx_stripe_bounds(int32_t n_right, int32_t world_size, int32_t ra
 /* C[M x N] (row-major, ldc) = A[M x K] (row-major, lda) * B[K x N] (row-major, ldb), device pointers. */
 dmrgx_status dmrgx_dgemm_nn(int32_t M, int32_t N, int32_t K, const double* A, int64_t lda,
                             const double* B, int64_t ldb, double* C, int64_t ldc, void* stream);
+/* The same for `count` independent products in one grouped launch (operator products per sector block, correlators:
+ * the MatMatMult calls of include/DMRGBlockContainer.hpp:2378-2395).  accumulate != 0: C += A*B.  Outputs must not
+ * overlap. */
+typedef struct {
+    int32_t M, N, K, accumulate;
+    const double* A; int64_t lda;
+    const double* B; int64_t ldb;
+    double* C; int64_t ldc;
+} dmrgx_gemm_task;
+dmrgx_status dmrgx_dgemm_batch(int32_t count, const dmrgx_gemm_task* tasks, void* stream);
 
 /* ---- K2: lowest eigenpair of the planned superblock Hamiltonian -------------------------------------- */
 typedef struct {
@@ -234,6 +244,9 @@ dmrgx_status dmrgx_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes,
 dmrgx_status dmrgx_memcpy_d2d(void* dst_dev, const void* src_dev, size_t bytes, void* stream);
 dmrgx_status dmrgx_memset_zero(void* dst_dev, size_t bytes, void* stream);
 dmrgx_status dmrgx_stream_sync(void* stream);
+/* *host_out = <x, y> (device vectors, fixed summation order); replaces VecDot in the correlator path
+ * (include/DMRGBlockContainer.hpp:2287-2293).  Synchronises the stream. */
+dmrgx_status dmrgx_dot(int64_t n, const double* x_dev, const double* y_dev, double* host_out, void* stream);
 
 #ifdef __cplusplus
 }

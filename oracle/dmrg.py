@@ -11,7 +11,7 @@ import numpy as np
 import scipy.sparse as sp
 import scipy.sparse.linalg as spla
 
-from .qn import QuantumNumbers, OracleError
+from .qn import QuantumNumbers, OracleError, OpSm, OpSz, OpSp
 from .block import Block
 from .kron import KronBlocks, KronEye_Explicit, KronSumConstruct_explicit
 
@@ -87,6 +87,38 @@ class StepRecord(dict):
     pass
 
 
+def _block_operator(blk, op, isite):
+    if op == OpSz:
+        return blk.SzData[isite]
+    if op == OpSp:
+        return blk.SpData[isite]
+    if op == OpSm:
+        return blk.SpData[isite].T.tocsr()          # Sm = Sp^T (src/DMRGBlock.cpp:630-632)
+    raise OracleError(1, "Correlators take Sz, Sp and Sm operators.")
+
+
+def operator_product(blk, ops):
+    """Product of single-site operators of one block in its basis, identity for an empty list
+    (CalculateOperatorProducts, include/DMRGBlockContainer.hpp:2333-2410)."""
+    n = blk.NumStates()
+    P = sp.identity(n, format="csr")
+    for (op, isite) in ops:
+        P = P @ _block_operator(blk, op, isite)
+    return P.tocsr()
+
+
+def correlator_value(kb, psi, sys_ops, env_ops):
+    """< psi | P_sys (x) P_env | psi > on the KronBlocks (include/DMRGBlockContainer.hpp:2255-2303): with
+    Psi[gL, gR] = psi this is sum(Psi * (P_sys Psi P_env^T))."""
+    _, _, _, _, _, gL, gR = kb.rows()
+    nL, nR = kb.LeftBlock.NumStates(), kb.RightBlock.NumStates()
+    Psi = sp.csr_matrix((psi, (gL, gR)), shape=(nL, nR))
+    PL, PR = operator_product(kb.LeftBlock, sys_ops), operator_product(kb.RightBlock, env_ops)
+    out = (PL @ Psi @ PR.T).tocsr()
+    # only components inside the target sector overlap with psi
+    return float(Psi.multiply(out).sum())
+
+
 class DMRGOracle:
     """CPU DMRG following DMRGBlockContainer<Block::SpinBase, J1J2XXZModel_SquareLattice>."""
 
@@ -105,9 +137,27 @@ class DMRGOracle:
         self.trunc_err = []
         self.GlobIdx = 0
         self.LoopIdx = 0
+        self.measurements = []      # (SysOps, EnvOps) with block-local site indices
+        self.corr_values = []       # one row per measurement step
+
+    def SetUpCorrelation(self, OpList):
+        """include/DMRGBlockContainer.hpp:627-682: operators on the right half are carried to the environment block by
+        reflection; a correlator living only on the right half is moved to the system block."""
+        N = self.num_sites
+        sys_ops, env_ops = [], []
+        for (op, idx) in OpList:
+            if 0 <= idx < N // 2:
+                sys_ops.append((op, idx))
+            elif N // 2 <= idx < N:
+                env_ops.append((op, N - 1 - idx))
+            else:
+                raise OracleError(1, "Operator index out of range")
+        if not sys_ops:
+            sys_ops, env_ops = env_ops, []
+        self.measurements.append((sys_ops, env_ops))
 
     # ---- one step (include/DMRGBlockContainer.hpp:1304-1653) ----
-    def SingleDMRGStep(self, SysBlock, EnvBlock, MStates, loop="Sweep"):
+    def SingleDMRGStep(self, SysBlock, EnvBlock, MStates, loop="Sweep", do_measurements=False):
         same = SysBlock is EnvBlock
         SysEnl = KronEye_Explicit(SysBlock, self.AddSite, self.Ham.H(SysBlock.NumSites() + 1))
         EnvEnl = SysEnl if same else KronEye_Explicit(EnvBlock, self.AddSite, self.Ham.H(EnvBlock.NumSites() + 1))
@@ -117,6 +167,8 @@ class DMRGOracle:
         H = KronSumConstruct_explicit(kb, Terms)
         gse, psi = lowest_eigenpair(H, seed=self.seed + self.GlobIdx)
         BT_L, BT_R = GetTruncation(kb, psi, MStates)
+        if do_measurements and self.measurements:                # :1543
+            self.corr_values.append([correlator_value(kb, psi, so, eo) for (so, eo) in self.measurements])
         SysOut = Block.with_sectors(SysEnl.NumSites(), BT_L["QN"].qn_list, BT_L["QN"].qn_size)
         SysOut.RotateOperators(SysEnl, BT_L["RotMatT"])
         if same:
@@ -175,7 +227,8 @@ class DMRGOracle:
             raise OracleError(1, "No DMRG Steps were performed since all site operators were created exactly.")
         for (s, env) in sched:
             assert s == self.sys_ninit
-            so, eo = self.SingleDMRGStep(self.sys_blocks[s - 1], self.sys_blocks[env - 1], self.mwarmup, loop="Warmup")
+            so, eo = self.SingleDMRGStep(self.sys_blocks[s - 1], self.sys_blocks[env - 1], self.mwarmup, loop="Warmup",
+                                         do_measurements=(s + 1 == self.num_sites // 2))     # :833
             self.sys_blocks[s] = so
             self.sys_blocks[env] = eo
             self.sys_ninit += 1
@@ -191,7 +244,8 @@ class DMRGOracle:
             self.sys_blocks[outsys], self.sys_blocks[outenv] = so, eo
         for iblock in range(min_block, N // 2):                    # :1059-1074
             insys, inenv, outsys, outenv = N - iblock - 3, iblock - 1, N - iblock - 2, iblock
-            so, eo = self.SingleDMRGStep(self.sys_blocks[insys], self.sys_blocks[inenv], MStates)
+            so, eo = self.SingleDMRGStep(self.sys_blocks[insys], self.sys_blocks[inenv], MStates,
+                                         do_measurements=(outsys == outenv))                  # :1073
             self.sys_blocks[outsys], self.sys_blocks[outenv] = so, eo
         self.LoopIdx += 1
 

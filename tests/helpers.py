@@ -50,3 +50,38 @@ def oracle_shell_from_superblock(sb, target=0.0):
     kb = KronBlocks(L, R, (target,))
     assert [(t[1], t[2]) for t in kb.kb] == list(sb.blocks), "KronBlock order differs from the reference's nested loop"
     return ShellCtx(kb, terms)
+
+
+# ---- independent exact diagonalisation of the lattice model (correlator known answers) -------------------------------
+def lattice_ground_state(ham):
+    """Dense ED of the whole lattice in the site basis (site 0 = most significant factor), from the model's own term
+    list.  Returns (E0, psi, site_op) where site_op(op, i) is the 2^N x 2^N matrix of a single-site operator."""
+    import scipy.sparse as sp
+    from oracle.qn import OpSm, OpSz, OpSp
+    N = ham.NumSites()
+    sz = sp.csr_matrix(np.array([[0.5, 0.0], [0.0, -0.5]]))
+    spl = sp.csr_matrix(np.array([[0.0, 1.0], [0.0, 0.0]]))
+    single = {OpSz: sz, OpSp: spl, OpSm: spl.T.tocsr()}
+    cache = {}
+
+    def site_op(op, i):
+        if (op, i) not in cache:
+            m = sp.identity(1, format="csr")
+            for s in range(N):
+                m = sp.kron(m, single[op] if s == i else sp.identity(2, format="csr"), format="csr")
+            cache[(op, i)] = m
+        return cache[(op, i)]
+
+    H = sp.csr_matrix((2 ** N, 2 ** N))
+    for t in ham.H(N):
+        H = H + t.a * (site_op(t.Iop, t.Isite) @ site_op(t.Jop, t.Jsite))
+    w, v = np.linalg.eigh(H.toarray())
+    return float(w[0]), v[:, 0].copy(), site_op
+
+
+def parse_desc2(desc2):
+    """'< Sz_{3} Sp_{4} >' -> [(OpSz, 3), (OpSp, 4)] (the engine / reference description string of a correlator)."""
+    import re
+    from oracle.qn import OpSm, OpSz, OpSp
+    kinds = {"Sz": OpSz, "Sp": OpSp, "Sm": OpSm}
+    return [(kinds[k], int(i)) for k, i in re.findall(r"(S[zpm])_\{(\d+)\}", desc2)]

@@ -9,6 +9,7 @@ import pytest
 
 from oracle.dmrg import DMRGOracle
 from oracle.hamiltonian import J1J2XXZModel_SquareLattice
+from helpers import lattice_ground_state, parse_desc2
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -76,6 +77,46 @@ def test_step_by_step_parity_with_oracle_under_truncation(tmp_path):
             assert abs(r[side] - o[side]) <= 1e-10 * abs(o[side]) + 1e-13, (r["GlobIdx"], side, r[side], o[side])
     assert max(o["TruncErr_Sys"] for o in orc.steps) > 1e-4               # the truncation was real
     assert run["MatMults"] > 0 and timings["headers"][-1] == "MatMults"
+    # correlators: same measurement steps, same values as the oracle's restatement
+    corr = json.load(open(str(tmp_path) + "/Correlations.json"))
+    orc2 = DMRGOracle(H, 4, qn_sector=1.0)
+    for c in corr["info"]:
+        orc2.SetUpCorrelation(parse_desc2(c["desc2"]))
+    orc2.Warmup()
+    orc2.Sweeps(nsweeps=2)
+    assert len(corr["values"]) == len(orc2.corr_values) == 3              # end of warm-up + one per sweep
+    nonzero = 0
+    for got, want in zip(corr["values"], orc2.corr_values):
+        assert len(got) == len(want) == len(corr["info"])
+        for c, g, w in zip(corr["info"], got, want):
+            assert abs(g - w) <= 1e-10 * max(abs(w), 1e-2), (c["name"], g, w)
+            nonzero += abs(w) > 1e-3
+    assert nonzero > 20                                                    # Sz = 1 sector: magnetisations do not vanish
+
+
+def test_correlators_match_exact_diagonalisation(tmp_path):
+    """Every correlator the driver registers (magnetisations, the three bond correlators of every nearest-neighbour
+    pair, the Sz strings) on the 4x2 Heisenberg lattice against dense ED of the lattice: m = 64 keeps everything, so
+    the values are exact ground-state expectation values; the J-weighted bond correlators add up to E0."""
+    rows, run, _ = run_engine(tmp_path, "-Lx", 4, "-Ly", 2, "-heisenberg", 1, "-mwarmup", 64, "-nsweeps", 1, "-H_eps_tol", 1e-13)
+    ham = J1J2XXZModel_SquareLattice(Lx=4, Ly=2, heisenberg=1.0)
+    e0, psi, site_op = lattice_ground_state(ham)
+    corr = json.load(open(str(tmp_path) + "/Correlations.json"))
+    names = [c["name"] for c in corr["info"]]
+    assert "Magnetization(3)" in names and "MagnetizationRowX1" in names and "Polyakov" in names and "Polyakov2" in names
+    assert sum(n.startswith("NearestNeighbor") for n in names) == 3 * len(ham.NeighborPairs())
+    assert len(corr["values"]) == 2
+    vals = {}
+    for c, v in zip(corr["info"], corr["values"][-1]):
+        ops = parse_desc2(c["desc2"])
+        P = None
+        for (op, i) in ops:
+            P = site_op(op, i) if P is None else P @ site_op(op, i)
+        exact = float(psi @ (P @ psi))
+        assert abs(v - exact) <= 1e-10, (c["name"], v, exact)
+        vals[tuple(ops)] = v
+    bond = sum(t.a * vals[((t.Iop, t.Isite), (t.Jop, t.Jsite))] for t in ham.H(8))
+    assert abs(bond - e0) <= 1e-10 * abs(e0) and abs(run["GSEnergy"] - e0) <= 1e-10 * abs(e0)
 
 
 def test_driver_fails_loudly_on_bad_options(tmp_path):

@@ -325,3 +325,45 @@ def test_apply_when_one_side_has_fewer_distinct_operators(mods, mode):
         torch.cuda.synchronize()
         assert np.abs(yd.cpu().numpy() - y_ref).max() <= RTOL * np.abs(y_ref).max()
     plan.destroy()
+
+
+def test_device_dot_product(pkg):
+    """dmrgx_dot (VecDot of the correlator path) against numpy, fixed summation order -> bit-reproducible."""
+    import ctypes as C
+    import torch
+    from dmrgx_amd import _capi
+    L = _capi.lib()
+    rng = np.random.default_rng(7)
+    for n in (1, 63, 4097, 300001):
+        x, y = rng.standard_normal(n), rng.standard_normal(n)
+        xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+        out1, out2 = C.c_double(0.0), C.c_double(0.0)
+        assert L.dmrgx_dot(n, xd.data_ptr(), yd.data_ptr(), C.byref(out1), None) == 0
+        assert L.dmrgx_dot(n, xd.data_ptr(), yd.data_ptr(), C.byref(out2), None) == 0
+        assert out1.value == out2.value
+        assert abs(out1.value - float(x @ y)) <= 1e-12 * np.sqrt(n) * max(1.0, abs(float(x @ y)))
+    assert L.dmrgx_dot(-1, None, None, C.byref(out1), None) == 62
+
+
+def test_dgemm_batch_matches_numpy(pkg):
+    """dmrgx_dgemm_batch: ragged independent products (and an accumulate task) in one grouped launch."""
+    import ctypes as C
+    import torch
+    from dmrgx_amd import _capi
+    L = _capi.lib()
+    rng = np.random.default_rng(11)
+    shapes = [(70, 33, 129), (1, 1, 1), (64, 64, 16), (200, 5, 77), (17, 140, 0)]
+    host, dev, tasks = [], [], (_capi.GemmTask * len(shapes))()
+    for i, (M, N, K) in enumerate(shapes):
+        A, B, C0 = rng.standard_normal((M, max(K, 1))), rng.standard_normal((max(K, 1), N)), rng.standard_normal((M, N))
+        acc = int(i == 3)
+        Ad, Bd, Cd = torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda(), torch.from_numpy(C0.copy()).cuda()
+        dev.append((Ad, Bd, Cd))
+        want = (A[:, :K] @ B[:K, :]) + (C0 if acc else 0.0) if K else (C0 if acc else np.zeros((M, N)))
+        host.append(want)
+        tasks[i] = _capi.GemmTask(M, N, K, acc, Ad.data_ptr(), A.shape[1], Bd.data_ptr(), N, Cd.data_ptr(), N)
+    assert L.dmrgx_dgemm_batch(len(shapes), C.cast(tasks, C.c_void_p), None) == 0
+    for (_, _, Cd), want in zip(dev, host):
+        got = Cd.cpu().numpy()
+        assert np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max())
+    assert L.dmrgx_dgemm_batch(-1, None, None) == 62

@@ -177,3 +177,37 @@ def test_exact_energy_chain_cfg1():
     assert len([s for s in d.steps if s["loop"] == "Sweep"]) == 16 - 4          # N-4 steps per sweep
     e = min(s["GSEnergy"] for s in d.steps if s["NSites_SysEnl"] + s["NSites_EnvEnl"] == 16)
     assert abs(e - (-6.9117371455751)) < 1e-10 * abs(e)
+
+
+def test_oracle_correlators_match_exact_diagonalisation():
+    """Pins the oracle's restatement of the correlator path (SetUpCorrelation's reflection rule, operator products,
+    <psi| P_sys (x) P_env |psi>; include/DMRGBlockContainer.hpp:627-682,2255-2410) against dense ED of the 4x2 lattice:
+    with m = 64 nothing is truncated, so every correlator must equal the exact ground-state expectation value."""
+    from helpers import lattice_ground_state
+    from oracle.qn import OpSm, OpSz, OpSp
+    ham = J1J2XXZModel_SquareLattice(Lx=4, Ly=2, heisenberg=1.0)
+    e0, psi, site_op = lattice_ground_state(ham)
+    orc = DMRGOracle(ham, 64)
+    lists = [[(OpSz, 1)], [(OpSz, 6)]]
+    for a, b in ham.NeighborPairs():
+        lists += [[(OpSz, a), (OpSz, b)], [(OpSp, a), (OpSm, b)], [(OpSm, a), (OpSp, b)]]
+    lists += [[(OpSz, ham.To1D(ix, 1)) for ix in range(4)], [(OpSz, 0), (OpSz, 1), (OpSz, 6), (OpSz, 7)],
+              [(OpSp, 2), (OpSm, 3), (OpSz, 4)], [(OpSp, 5), (OpSm, 6)]]
+    for l in lists:
+        orc.SetUpCorrelation(l)
+    orc.Warmup()
+    orc.Sweeps(nsweeps=1)
+    assert abs(orc.gse - e0) <= 1e-12 * abs(e0)
+    assert len(orc.corr_values) == 2                      # end of warm-up, end of the sweep
+    bond = 0.0
+    for l, v in zip(lists, orc.corr_values[-1]):
+        P = None
+        for (op, i) in l:
+            P = site_op(op, i) if P is None else P @ site_op(op, i)
+        exact = float(psi @ (P @ psi))
+        assert abs(v - exact) <= 1e-12, (l, v, exact)
+    # bond energies add up to E0:  sum over terms a <O_i O_j>
+    vals = dict((tuple(l), v) for l, v in zip(lists, orc.corr_values[-1]))
+    for t in ham.H(8):
+        bond += t.a * vals[((t.Iop, t.Isite), (t.Jop, t.Jsite))]
+    assert abs(bond - e0) <= 1e-12 * abs(e0)
