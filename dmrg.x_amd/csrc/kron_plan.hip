@@ -247,40 +247,70 @@ struct Builder {
         static const double units = getenv("DMRGX_SPLIT_UNITS") ? atof(getenv("DMRGX_SPLIT_UNITS")) : 8192.0;
         static const double min_seg = getenv("DMRGX_SPLIT_MIN") ? atof(getenv("DMRGX_SPLIT_MIN")) : 16.0;
         const double seg_target = std::max(total / units, min_seg);
+        static const int taper = getenv("DMRGX_SPLIT_TAPER") ? atoi(getenv("DMRGX_SPLIT_TAPER")) : 0;
         const size_t ng = stage2_groups.size();
         for (size_t gi = 0; gi < ng; ++gi) {
             const int32_t g = stage2_groups[gi];
             const int32_t cost = ksteps(g);
-            const int32_t gemm_begin = groups[g].prod_begin + groups[g].n_axpy, gemm_end = groups[g].prod_end;
-            int32_t S = (int32_t)std::min<double>(64.0, std::max(1.0, std::floor(cost / seg_target + 0.5)));
-            S = std::max(1, std::min(S, gemm_end - gemm_begin));
-            if ((int64_t)groups[g].M * groups[g].N >= (int64_t)1 << 31) S = 1;      // slab_reduce_kernel indexes a block with 32 bits
+            const int32_t axpy_begin = groups[g].prod_begin, gemm_begin = groups[g].prod_begin + groups[g].n_axpy, gemm_end = groups[g].prod_end;
+            int32_t gcost = 0;
+            for (int32_t p = gemm_begin; p < gemm_end; ++p) gcost += (prods[p].K + GG_BK - 1) / GG_BK;
+            // Cut points of the group's GEMM stream, in k-steps: equal segments of ~seg_target.  Cuts may fall inside a
+            // product: a product is just (pointers, K), so it is split at a multiple of GG_BK.  (DMRGX_SPLIT_TAPER=1
+            // additionally cuts the last segment into 1/2, 1/4, 1/4 so that every XCD finishes on short units; measured
+            // neutral to slightly negative at cfg3-cfg5, off by default.)
+            std::vector<int32_t> cuts;
+            {
+                int32_t S = (int32_t)std::min<double>(64.0, std::max(1.0, std::floor(gcost / seg_target + 0.5)));
+                if ((int64_t)groups[g].M * groups[g].N >= (int64_t)1 << 31) S = 1;      // slab_reduce_kernel indexes a block with 32 bits
+                if (gcost < 2) S = 1;
+                S = std::min(S, gcost);
+                for (int32_t i = 1; i < S; ++i) cuts.push_back((int32_t)(((int64_t)gcost * i) / S));
+                if (taper && S > 1) {
+                    const int32_t lo = cuts.back(), r = gcost - lo;
+                    if (r >= 16) { cuts.push_back(lo + r / 2); cuts.push_back(lo + r / 2 + r / 4); }
+                }
+                cuts.push_back(gcost);
+                cuts.erase(std::unique(cuts.begin(), cuts.end()), cuts.end());
+            }
+            const int32_t S = (int32_t)cuts.size();
             if (S == 1) { ggemm_append_tiles_mixed(tiles2b, tiles2, g, groups[g].M, groups[g].N, cost, big); continue; }
             max_split = std::max(max_split, S);
             const int64_t mn = (int64_t)groups[g].M * groups[g].N;
             red_tasks.push_back(RedTask{groups[g].c_off, slab_base + slab_elems, groups[g].ldc, groups[g].M, groups[g].N, S - 1});
             for (int64_t c = 0; c * RED_CHUNK < mn; ++c) red_tiles.push_back(RedTile{(int32_t)red_tasks.size() - 1, (int32_t)c});
-            int32_t gcost = 0;
-            for (int32_t p = gemm_begin; p < gemm_end; ++p) gcost += (prods[p].K + GG_BK - 1) / GG_BK;
-            int32_t p = gemm_begin, done = 0;
+            // product start positions in k-steps
+            std::vector<int32_t> pstart;
+            { int32_t acc = 0; for (int32_t p = gemm_begin; p < gemm_end; ++p) { pstart.push_back(acc); acc += (prods[p].K + GG_BK - 1) / GG_BK; } }
+            const int32_t n_axpy = groups[g].n_axpy;
+            int32_t lo = 0;
             for (int32_t sidx = 0; sidx < S; ++sidx) {
-                const int32_t want = (int32_t)(((int64_t)gcost * (sidx + 1)) / S);
-                const int32_t b = p;
-                int32_t c = 0;
-                while (p < gemm_end && (done < want || p == b) && (gemm_end - p) > (S - 1 - sidx)) { const int32_t k = (prods[p].K + GG_BK - 1) / GG_BK; done += k; c += k; ++p; }
-                if (sidx == S - 1) while (p < gemm_end) { c += (prods[p].K + GG_BK - 1) / GG_BK; ++p; }
+                const int32_t hi = cuts[sidx];
+                const int32_t nb = (int32_t)prods.size();
+                if (sidx == 0) for (int32_t q = 0; q < n_axpy; ++q) { const RelProd ax = prods[axpy_begin + q]; prods.push_back(ax); }
+                for (int32_t p = gemm_begin; p < gemm_end; ++p) {
+                    const int32_t ps = pstart[p - gemm_begin], pe = ps + (prods[p].K + GG_BK - 1) / GG_BK;
+                    const int32_t olo = std::max(lo, ps), ohi = std::min(hi, pe);
+                    if (olo >= ohi) continue;
+                    RelProd sub = prods[p];
+                    const int32_t k0 = (olo - ps) * GG_BK, k1 = std::min(prods[p].K, (ohi - ps) * GG_BK);
+                    sub.a_off += k0; sub.b_off += (int64_t)k0 * sub.ldb; sub.K = k1 - k0;
+                    prods.push_back(sub);
+                }
+                const int32_t ne = (int32_t)prods.size();
                 if (sidx == 0) {
-                    groups[g].prod_end = p;
-                    ggemm_append_tiles_mixed(tiles2b, tiles2, g, groups[g].M, groups[g].N, c + groups[g].n_axpy, big);
+                    groups[g].prod_begin = nb; groups[g].prod_end = ne;
+                    ggemm_append_tiles_mixed(tiles2b, tiles2, g, groups[g].M, groups[g].N, (hi - lo) + n_axpy, big);
                 } else {
                     RelGroup ng2 = groups[g];
                     ng2.c_base = BASE_ARENA;
                     ng2.c_off = slab_base + slab_elems + (int64_t)(sidx - 1) * mn;
                     ng2.ldc = ng2.N;
-                    ng2.prod_begin = b; ng2.prod_end = p; ng2.n_axpy = 0; ng2.accumulate = 0;
+                    ng2.prod_begin = nb; ng2.prod_end = ne; ng2.n_axpy = 0; ng2.accumulate = 0;
                     groups.push_back(ng2);
-                    ggemm_append_tiles_mixed(tiles2b, tiles2, (int32_t)groups.size() - 1, ng2.M, ng2.N, c, big);
+                    ggemm_append_tiles_mixed(tiles2b, tiles2, (int32_t)groups.size() - 1, ng2.M, ng2.N, hi - lo, big);
                 }
+                lo = hi;
             }
             slab_elems += (int64_t)(S - 1) * mn;
         }

@@ -99,7 +99,7 @@ def test_striped_plans_reassemble_full_apply(mods):
     full.destroy()
 
 
-@pytest.mark.parametrize("cfg", ["cfg2", "cfg3", "cfg4"])
+@pytest.mark.parametrize("cfg", ["cfg2", "cfg3", "cfg4", "cfg5"])
 def test_full_size_properties(mods, cfg):
     """BASELINE sizes: size-independent properties -- linearity and symmetry <u,Hv> = <Hu,v>."""
     sbm, wl, _ = mods
@@ -367,3 +367,93 @@ def test_dgemm_batch_matches_numpy(pkg):
         got = Cd.cpu().numpy()
         assert np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max())
     assert L.dmrgx_dgemm_batch(-1, None, None) == 62
+
+
+def _dense_operator(op, sizes):
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    M = np.zeros((off[-1], off[-1]))
+    for c in op.cells:
+        q, qc = c.row_sector, c.row_sector + op.shift
+        r, s = off[q] + c.r0, off[qc] + c.c0
+        if c.kind == 1:
+            M[r:r + c.nr, s:s + c.nc] += c.array
+        else:
+            M[r:r + c.nr, s:s + c.nc] += c.scale * np.eye(c.nr, c.nc)
+    return M
+
+
+def test_apply_degenerate_layouts_vs_dense_kron(mods):
+    """Edge cases of the layout: 1 x 1 and single-row/column KronBlocks, cells that cover only part of a sector block, an
+    identity cell, terms whose shifted sector does not exist at the ends, more ranks than columns -- against the dense
+    Kronecker product restricted to the target sector; a zero-size sector is rejected like the reference's
+    QuantumNumbers does (src/QuantumNumbers.cpp:9-50)."""
+    sbm, wl, _ = mods
+    from dmrgx_amd.workloads import OpCell, SectorOperator, Superblock, CELL_DENSE, CELL_IDENT
+    rng = np.random.default_rng(42)
+    lsz, rsz = [1, 3, 1, 2], [2, 1, 5, 1]
+    lqn = rqn = [1.5, 0.5, -0.5, -1.5]
+    blocks = [(0, 3), (1, 2), (2, 1), (3, 0)]            # Sz_L + Sz_R = 0
+
+    def dense_op(shift, sizes, partial=False):
+        cells = []
+        for q in range(4):
+            qc = q + shift
+            if not 0 <= qc < 4 or sizes[q] == 0 or sizes[qc] == 0:
+                continue
+            nr, nc = sizes[q], sizes[qc]
+            if partial and nr > 1:                       # two cells covering the top and the bottom rows separately
+                cells.append(OpCell(q, 0, 0, 1, nc, CELL_DENSE, 0.0, rng.standard_normal((1, nc))))
+                cells.append(OpCell(q, 1, 0, nr - 1, nc, CELL_DENSE, 0.0, rng.standard_normal((nr - 1, nc))))
+            else:
+                cells.append(OpCell(q, 0, 0, nr, nc, CELL_DENSE, 0.0, rng.standard_normal((nr, nc))))
+        return SectorOperator(shift, cells)
+
+    def sym(op):
+        for c in op.cells:
+            if c.nr == c.nc:
+                c.array = 0.5 * (c.array + c.array.T)
+        return op
+
+    OpSz_, OpSp_, OpSm_ = 0, 1, -1
+    left_ops = {(OpSp_, 0): dense_op(+1, lsz, partial=True), (OpSz_, 0): dense_op(0, lsz),
+                (OpSz_, 1): SectorOperator(0, [OpCell(q, 0, 0, lsz[q], lsz[q], CELL_IDENT, 0.25 * (q + 1)) for q in range(4) if lsz[q]])}
+    right_ops = {(OpSp_, 0): dense_op(+1, rsz), (OpSz_, 0): dense_op(0, rsz, partial=True), (OpSz_, 1): dense_op(0, rsz)}
+    terms = [(0.7, OpSp_, 0, OpSm_, 0), (0.7, OpSm_, 0, OpSp_, 0), (1.3, OpSz_, 0, OpSz_, 0), (-0.4, OpSz_, 1, OpSz_, 1)]
+    sb = Superblock("edge", lsz, rsz, lqn, rqn, blocks, left_ops, right_ops, sym(dense_op(0, lsz)), sym(dense_op(0, rsz)), terms, 2, 2)
+    # dense reference
+    A = {k: _dense_operator(v, lsz) for k, v in left_ops.items()}
+    B = {k: _dense_operator(v, rsz) for k, v in right_ops.items()}
+    A[(OpSm_, 0)], B[(OpSm_, 0)] = A[(OpSp_, 0)].T, B[(OpSp_, 0)].T
+    HL, HR = _dense_operator(sb.h_left, lsz), _dense_operator(sb.h_right, rsz)
+    full = np.kron(HL, np.eye(sum(rsz))) + np.kron(np.eye(sum(lsz)), HR)
+    for (a, io, isite, jo, jsite) in terms:
+        full += a * np.kron(A[(io, isite)], B[(jo, jsite)])
+    loff, roff = np.concatenate([[0], np.cumsum(lsz)]), np.concatenate([[0], np.cumsum(rsz)])
+    idx = [(loff[il] + i) * sum(rsz) + roff[ir] + j for il, ir in blocks for i in range(lsz[il]) for j in range(rsz[ir])]
+    Hsb = full[np.ix_(idx, idx)]
+    assert sb.n_states == len(idx) == 1 + 3 * 5 + 1 + 2 * 2
+    bad = Superblock("bad", [0, 3, 1, 2], rsz, lqn, rqn, blocks, {}, {}, SectorOperator(0, []), SectorOperator(0, []), [], 1, 1)
+    with pytest.raises(Exception, match="size 0"):
+        sbm.KronPlan(bad)
+    plan = sbm.KronPlan(sb)
+    for _ in range(3):
+        x = rng.standard_normal(sb.n_states)
+        y = _apply(plan, x)
+        assert np.abs(y - Hsb @ x).max() <= 1e-13 * max(1.0, np.abs(Hsb @ x).max())
+    plan.destroy()
+    # more ranks than columns in some blocks: stripes of width 0 must be accepted and reassemble
+    W = 4
+    plans = [sbm.KronPlan(sb, world_size=W, rank=r) for r in range(W)]
+    info = plans[0].info
+    x = rng.standard_normal(sb.n_states)
+    xs = torch.zeros(info.vec_len, dtype=torch.float64, device="cuda")
+    plans[0].to_striped(torch.from_numpy(x).cuda(), xs)
+    ys = torch.zeros_like(xs)
+    for p in plans:
+        p.apply(xs, ys[p.info.local_offset:p.info.local_offset + p.info.local_len])
+    yd = torch.zeros(sb.n_states, dtype=torch.float64, device="cuda")
+    plans[0].from_striped(ys, yd)
+    torch.cuda.synchronize()
+    assert np.abs(yd.cpu().numpy() - Hsb @ x).max() <= 1e-13 * max(1.0, np.abs(Hsb @ x).max())
+    for p in plans:
+        p.destroy()
