@@ -124,6 +124,142 @@ public:
         return 0;
     }
 
+    /* ---- checkpoint files ----------------------------------------------------------------
+       Same directory layout and text files as the reference (src/DMRGBlock.cpp:889-971): BlockInfo.dat,
+       QuantumNumbers.dat, Sz_%09d.mat, Sp_%09d.mat, H_%09d.mat.  The operator files hold this engine's sector-cell
+       form (little-endian): int64 {magic "DMRGXOP1", shift, nsec, sizes[nsec], ncells}, then per cell int64 {row
+       sector, r0, c0, nr, nc, kind}, double scale and, for dense cells, nr*nc doubles row-major.  (The reference writes
+       PETSc's binary MatView format, which is not part of its source tree.) */
+    static std::string OpFilename(const std::string& dir, const std::string& name, const size_t isite = 0)
+    {
+        char buf[64];
+        snprintf(buf, sizeof(buf), "%s_%09zu.mat", name.c_str(), isite);
+        return dir + buf;
+    }
+    static PetscErrorCode WriteOperatorFile(const std::string& fn, const Mat& op)
+    {
+        if (!op || op->transpose_of || op->plan) return PETSC_ERR_ARG_WRONG;
+        FILE* fp = fopen(fn.c_str(), "wb");
+        if (!fp) return PETSC_ERR_FILE_OPEN;
+        auto put = [&](int64_t v) { fwrite(&v, sizeof(v), 1, fp); };
+        put(0x31504f5847524d44ll); put(op->shift); put((int64_t)op->sizes.size());
+        for (int32_t sz : op->sizes) put(sz);
+        put((int64_t)op->cells.size());
+        for (dmrgx_host::MatCell& c : op->cells) {
+            put(c.q); put(c.r0); put(c.c0); put(c.nr); put(c.nc); put(c.kind);
+            fwrite(&c.scale, sizeof(double), 1, fp);
+            if (c.kind == DMRGX_CELL_DENSE) {
+                const double* h = c.buf->host_ro() + c.off;              /* D2H of the owning buffer on first touch */
+                for (int32_t i = 0; i < c.nr; ++i) fwrite(h + (int64_t)i * c.ld, sizeof(double), (size_t)c.nc, fp);
+            }
+        }
+        const bool ok = !ferror(fp);
+        fclose(fp);
+        return ok ? 0 : PETSC_ERR_FILE_OPEN;
+    }
+    static PetscErrorCode ReadOperatorFile(const std::string& fn, Mat& op)
+    {
+        FILE* fp = fopen(fn.c_str(), "rb");
+        if (!fp) return PETSC_ERR_FILE_OPEN;
+        bool ok = true;
+        auto get = [&]() { int64_t v = 0; if (fread(&v, sizeof(v), 1, fp) != 1) ok = false; return v; };
+        op = std::make_shared<dmrgx_host::SectorMat>();
+        if (get() != 0x31504f5847524d44ll) { fclose(fp); return PETSC_ERR_FILE_OPEN; }
+        op->shift = (int32_t)get();
+        const int64_t ns = get();
+        for (int64_t i = 0; ok && i < ns; ++i) op->sizes.push_back((int32_t)get());
+        const int64_t nc = get();
+        for (int64_t i = 0; ok && i < nc; ++i) {
+            dmrgx_host::MatCell c;
+            c.q = (int32_t)get(); c.r0 = (int32_t)get(); c.c0 = (int32_t)get(); c.nr = (int32_t)get(); c.nc = (int32_t)get(); c.kind = (int32_t)get();
+            if (fread(&c.scale, sizeof(double), 1, fp) != 1) ok = false;
+            if (ok && c.kind == DMRGX_CELL_DENSE) {
+                if (c.nr < 0 || c.nc < 0) { ok = false; break; }
+                c.ld = c.nc; c.off = 0;
+                c.buf = std::make_shared<dmrgx_host::DevBuffer>((size_t)c.nr * c.nc);
+                if (fread(c.buf->host(), sizeof(double), (size_t)c.nr * c.nc, fp) != (size_t)c.nr * c.nc) ok = false;
+            }
+            op->cells.push_back(c);
+        }
+        fclose(fp);
+        return ok ? 0 : PETSC_ERR_FILE_OPEN;
+    }
+
+    /** Writes the block into `dir` (which must exist) without destroying it: the checkpoint copy of SaveAndDestroy. */
+    PetscErrorCode SaveToDisk(const std::string& dir_in)
+    {
+        if (!init) SETERRQ(mpi_comm, PETSC_ERR_ARG_CORRUPT, "Block not yet initialized.");
+        std::string dir = dir_in;
+        if (dir.empty()) SETERRQ(mpi_comm, 1, "Save dir cannot be empty.");
+        if (dir.back() != '/') dir += '/';
+        PetscBool flg = PETSC_FALSE;
+        PetscErrorCode ierr = PetscTestDirectory(dir.c_str(), 'r', &flg); CHKERRQ(ierr);
+        if (!flg) SETERRQ1(mpi_comm, 1, "Directory %s does not exist. Please verify that -scratch_dir is specified correctly.", dir.c_str());
+        for (PetscInt i = 0; i < num_sites; ++i) { if (WriteOperatorFile(OpFilename(dir, "Sz", (size_t)i), SzData[(size_t)i])) SETERRQ1(mpi_comm, PETSC_ERR_FILE_OPEN, "cannot write %s", OpFilename(dir, "Sz", (size_t)i).c_str()); }
+        for (PetscInt i = 0; i < num_sites; ++i) { if (WriteOperatorFile(OpFilename(dir, "Sp", (size_t)i), SpData[(size_t)i])) SETERRQ1(mpi_comm, PETSC_ERR_FILE_OPEN, "cannot write %s", OpFilename(dir, "Sp", (size_t)i).c_str()); }
+        if (H) { if (WriteOperatorFile(OpFilename(dir, "H", 0), H)) SETERRQ1(mpi_comm, PETSC_ERR_FILE_OPEN, "cannot write %s", OpFilename(dir, "H", 0).c_str()); }
+        {
+            FILE* fp = fopen((dir + "BlockInfo.dat").c_str(), "w");
+            if (!fp) SETERRQ1(mpi_comm, PETSC_ERR_FILE_OPEN, "cannot write %sBlockInfo.dat", dir.c_str());
+            fprintf(fp, "%-30s %zu\n%-30s %zu\n%-30s %d\n%-30s %d\n%-30s %lld\n%-30s %lld\n%-30s %lld\n", "NumBytesPetscInt", sizeof(PetscInt),
+                    "NumBytesPetscScalar", sizeof(PetscScalar), "PetscUseComplex", 0, "SpinTypeKey", (int)spin_type, "NumSites", LLD(num_sites),
+                    "NumStates", LLD(num_states), "NumSectors", LLD(Magnetization.NumSectors()));
+            fclose(fp);
+        }
+        {
+            FILE* fp = fopen((dir + "QuantumNumbers.dat").c_str(), "w");
+            if (!fp) SETERRQ1(mpi_comm, PETSC_ERR_FILE_OPEN, "cannot write %sQuantumNumbers.dat", dir.c_str());
+            const std::vector<PetscInt> sz = Magnetization.Sizes();
+            const std::vector<PetscReal> ql = Magnetization.List();
+            for (size_t i = 0; i < sz.size(); ++i) fprintf(fp, "%lld %.17g\n", LLD(sz[i]), ql[i]);
+            fclose(fp);
+        }
+        return 0;
+    }
+
+    /** Rebuilds a block from the files written by SaveToDisk (InitializeFromDisk of the reference,
+        src/DMRGBlock.cpp:184-300: BlockInfo.dat and QuantumNumbers.dat are cross-checked). */
+    PetscErrorCode InitializeFromDisk(const MPI_Comm& comm_in, const std::string& dir_in)
+    {
+        std::string dir = dir_in;
+        if (dir.empty()) SETERRQ(comm_in, 1, "Block directory cannot be empty.");
+        if (dir.back() != '/') dir += '/';
+        std::map<std::string, long long> info;
+        {
+            FILE* fp = fopen((dir + "BlockInfo.dat").c_str(), "r");
+            if (!fp) SETERRQ1(comm_in, PETSC_ERR_FILE_OPEN, "cannot read %sBlockInfo.dat", dir.c_str());
+            char key[128]; long long val;
+            while (fscanf(fp, "%127s %lld", key, &val) == 2) info[key] = val;
+            fclose(fp);
+        }
+        for (const char* k : {"NumBytesPetscInt", "NumBytesPetscScalar", "PetscUseComplex", "NumSites", "NumStates", "NumSectors"})
+            if (!info.count(k)) SETERRQ2(comm_in, 1, "%sBlockInfo.dat: key %s missing.", dir.c_str(), k);
+        if (info["NumBytesPetscInt"] != (long long)sizeof(PetscInt) || info["NumBytesPetscScalar"] != (long long)sizeof(PetscScalar) || info["PetscUseComplex"] != 0)
+            SETERRQ1(comm_in, 1, "%sBlockInfo.dat was written with incompatible scalar/integer types.", dir.c_str());
+        std::vector<PetscReal> ql; std::vector<PetscInt> qs;
+        {
+            FILE* fp = fopen((dir + "QuantumNumbers.dat").c_str(), "r");
+            if (!fp) SETERRQ1(comm_in, PETSC_ERR_FILE_OPEN, "cannot read %sQuantumNumbers.dat", dir.c_str());
+            long long sz; double q;
+            while (fscanf(fp, "%lld %lf", &sz, &q) == 2) { qs.push_back((PetscInt)sz); ql.push_back(q); }
+            fclose(fp);
+        }
+        if ((long long)ql.size() != info["NumSectors"]) SETERRQ2(comm_in, 1, "QuantumNumbers.dat has %lld sectors, BlockInfo.dat says %lld.", LLD(ql.size()), info["NumSectors"]);
+        PetscErrorCode ierr = Initialize(comm_in, (PetscInt)info["NumSites"], ql, qs, PETSC_FALSE); CHKERRQ(ierr);
+        if (num_states != (PetscInt)info["NumStates"]) SETERRQ2(comm_in, 1, "Sector sizes add up to %lld states, BlockInfo.dat says %lld.", LLD(num_states), info["NumStates"]);
+        for (PetscInt i = 0; i < num_sites; ++i) {
+            if (ReadOperatorFile(OpFilename(dir, "Sz", (size_t)i), SzData[(size_t)i])) SETERRQ1(comm_in, PETSC_ERR_FILE_OPEN, "cannot read %s", OpFilename(dir, "Sz", (size_t)i).c_str());
+            if (ReadOperatorFile(OpFilename(dir, "Sp", (size_t)i), SpData[(size_t)i])) SETERRQ1(comm_in, PETSC_ERR_FILE_OPEN, "cannot read %s", OpFilename(dir, "Sp", (size_t)i).c_str());
+        }
+        {   /* a block without a Hamiltonian (fixtures) has no H file */
+            PetscBool has_h = PETSC_FALSE;
+            ierr = PetscTestFile(OpFilename(dir, "H", 0).c_str(), 'r', &has_h); CHKERRQ(ierr);
+            if (has_h && ReadOperatorFile(OpFilename(dir, "H", 0), H)) SETERRQ1(comm_in, PETSC_ERR_FILE_OPEN, "cannot read %s", OpFilename(dir, "H", 0).c_str());
+        }
+        ierr = CheckOperatorBlocks(); CHKERRQ(ierr);
+        return 0;
+    }
+
     /* ---- scratch storage: names kept, blocks stay in HBM ------------------------------------------------ */
     PetscErrorCode InitializeSave(const std::string& save_dir_in) { save_dir = save_dir_in; init_save = PETSC_TRUE; return 0; }
     PetscErrorCode SetDiskStorage(const std::string& read_dir_in, const std::string& write_dir_in) { read_dir = read_dir_in; write_dir = write_dir_in; save_dir = read_dir_in; disk_set = PETSC_TRUE; return 0; }

@@ -18,6 +18,8 @@
 #include <algorithm>
 #include <cmath>
 #include <iomanip>
+#include <fstream>
+#include <sstream>
 #include <iostream>
 #include <map>
 #include <set>
@@ -64,6 +66,34 @@ public:
         char path[PETSC_MAX_PATH_LEN];
         ierr = MPI_Comm_size(mpi_comm, &mpi_size); CHKERRQ(ierr);
         ierr = MPI_Comm_rank(mpi_comm, &mpi_rank); CHKERRQ(ierr);
+        /*  checkpoint restart (include/DMRGBlockContainer.hpp:282-361 of the reference): -restart_dir points to the scratch
+            directory of a previous run; the last Sweep_%09d with a Sweep.dat is resumed, its Hamiltonian.dat overrides
+            the model options and, with -restart_options, its PetscOptions.dat the sweep schedule */
+        ierr = PetscOptionsGetString(NULL, NULL, "-restart_dir", path, PETSC_MAX_PATH_LEN, &restart); CHKERRQ(ierr);
+        ierr = PetscOptionsGetBool(NULL, NULL, "-restart_options", &restart_options, NULL); CHKERRQ(ierr);
+        if (restart) {
+            restart_dir = std::string(path);
+            if (restart_dir.back() != '/') restart_dir += '/';
+            const PetscInt MAX_SWEEP_IDX = 1000000;
+            PetscInt ridx = 0;
+            PetscBool flg = PETSC_FALSE;
+            while (ridx < MAX_SWEEP_IDX) { ierr = PetscTestDirectory((restart_dir + SweepDir(ridx)).c_str(), 'r', &flg); CHKERRQ(ierr); if (flg) break; ++ridx; }
+            if (ridx == MAX_SWEEP_IDX) SETERRQ1(mpi_comm, 1, "No Sweep directory was found in %s", restart_dir.c_str());
+            while (ridx < MAX_SWEEP_IDX) { ierr = PetscTestFile((restart_dir + SweepDir(ridx + 1) + "Sweep.dat").c_str(), 'r', &flg); CHKERRQ(ierr); if (flg) ++ridx; else break; }
+            restart_dir += SweepDir(ridx);
+            ierr = SetOptionsFromFile(restart_dir + "Hamiltonian.dat"); CHKERRQ(ierr);
+            std::map<std::string, PetscInt> dict;
+            ierr = RetrieveInfoFile(restart_dir + "Sweep.dat", dict); CHKERRQ(ierr);
+            for (const char* k : {"GlobIdx", "LoopIdx", "num_sys_blocks", "sys_ninit", "num_sites"})
+                if (!dict.count(k)) SETERRQ2(mpi_comm, 1, "%sSweep.dat: key %s missing.", restart_dir.c_str(), k);
+            GlobIdx = dict["GlobIdx"]; LoopIdx = dict["LoopIdx"] + 1;      /* saved before the increment */
+            num_sys_blocks = dict["num_sys_blocks"]; restart_sys_ninit = dict["sys_ninit"]; restart_num_sites = dict["num_sites"];
+            if (restart_options) {
+                ierr = SetOptionsFromFile(restart_dir + "PetscOptions.dat"); CHKERRQ(ierr);
+                if (dict.count("msweep_idx")) restart_msweep_idx = dict["msweep_idx"];
+            }
+            if (!mpi_rank) printf("RESTART from %s  (GlobIdx %lld, LoopIdx %lld, %lld blocks)\n", restart_dir.c_str(), LLD(GlobIdx), LLD(LoopIdx), LLD(restart_sys_ninit));
+        }
         ierr = Ham.SetFromOptions(); CHKERRQ(ierr);
         ierr = SingleSite.Initialize(mpi_comm, 1, PETSC_DEFAULT); CHKERRQ(ierr);
         num_sites = Ham.NumSites();
@@ -84,6 +114,9 @@ public:
         ierr = PetscOptionsGetString(NULL, NULL, "-scratch_dir", path, PETSC_MAX_PATH_LEN, &opt); CHKERRQ(ierr);
         scratch_dir = opt ? std::string(path) : std::string("./scratch_dir/");
         if (scratch_dir.back() != '/') scratch_dir += '/';
+        do_scratch_dir = opt;        /* blocks live in HBM (288 GB): checkpoints are written only when -scratch_dir is given */
+        if (do_scratch_dir && !mpi_rank) { ierr = Makedir(scratch_dir); CHKERRQ(ierr); }
+        if (restart && num_sites != restart_num_sites) SETERRQ2(mpi_comm, 1, "The restart data is for %lld sites, the model has %lld.", LLD(restart_num_sites), LLD(num_sites));
         ierr = PetscOptionsGetString(NULL, NULL, "-data_dir", path, PETSC_MAX_PATH_LEN, &opt); CHKERRQ(ierr);
         data_dir = opt ? std::string(path) : std::string("./data_dir/");
         if (data_dir.back() != '/') data_dir += '/';
@@ -168,6 +201,18 @@ public:
         PetscErrorCode ierr;
         ierr = PetscTime(&t0abs); CHKERRQ(ierr);
         if (warmed_up) SETERRQ(mpi_comm, 1, "Warmup has already been called, and it can only be called once.");
+        if (restart) {   /* the warm-up is replaced by loading the checkpointed blocks (reference :737-757) */
+            if (!mpi_rank) printf("Loading blocks from file...\n");
+            num_sys_blocks = num_sites - 1;
+            sys_blocks.resize((size_t)num_sys_blocks);
+            for (PetscInt ib = 0; ib < restart_sys_ninit; ++ib) {
+                ierr = sys_blocks[(size_t)ib].InitializeFromDisk(mpi_comm, restart_dir + BlockDir("Sys", ib)); CHKERRQ(ierr);
+            }
+            sys_ninit = restart_sys_ninit;
+            warmed_up = PETSC_TRUE;
+            ierr = PetscTime(&t0abs); CHKERRQ(ierr);
+            return 0;
+        }
         if (!mpi_rank) printf("WARMUP\n");
         num_sys_blocks = num_sites - 1;
         sys_blocks.resize((size_t)num_sys_blocks);
@@ -197,6 +242,7 @@ public:
         }
         if (sys_ninit != num_sites / 2) SETERRQ2(mpi_comm, 1, "Expected sys_ninit = num_sites/2 = %lld. Got %lld.", LLD(num_sites / 2), LLD(sys_ninit));
         warmed_up = PETSC_TRUE;
+        ierr = SaveSweepsData(); CHKERRQ(ierr);
         ++LoopIdx;
         return 0;
     }
@@ -205,10 +251,11 @@ public:
     {
         if (dry_run || mwarmup == 0) return 0;
         PetscErrorCode ierr;
-        if (sweep_mode == SWEEP_MODE_NSWEEPS) { for (msweep_idx = 0; msweep_idx < nsweeps; ++msweep_idx) { ierr = SingleSweep(mwarmup); CHKERRQ(ierr); } }
-        else if (sweep_mode == SWEEP_MODE_MSWEEPS) { for (msweep_idx = 0; msweep_idx < (PetscInt)msweeps.size(); ++msweep_idx) { ierr = SingleSweep(msweeps.at(msweep_idx)); CHKERRQ(ierr); } }
+        const PetscInt first = (restart && restart_options) ? restart_msweep_idx + 1 : 0;      /* continue the saved schedule */
+        if (sweep_mode == SWEEP_MODE_NSWEEPS) { for (msweep_idx = first; msweep_idx < nsweeps; ++msweep_idx) { ierr = SingleSweep(mwarmup); CHKERRQ(ierr); } }
+        else if (sweep_mode == SWEEP_MODE_MSWEEPS) { for (msweep_idx = first; msweep_idx < (PetscInt)msweeps.size(); ++msweep_idx) { ierr = SingleSweep(msweeps.at(msweep_idx)); CHKERRQ(ierr); } }
         else if (sweep_mode == SWEEP_MODE_TOLERANCE_TEST) {
-            for (msweep_idx = 0; msweep_idx < (PetscInt)msweeps.size(); ++msweep_idx) {
+            for (msweep_idx = first; msweep_idx < (PetscInt)msweeps.size(); ++msweep_idx) {
                 const PetscInt mstates = msweeps.at(msweep_idx), max_iter = maxnsweeps.at(msweep_idx);
                 if (max_iter == 0) continue;
                 PetscInt iter = 0; bool cont;
@@ -260,6 +307,7 @@ public:
         if (!mpi_rank) printf("SWEEP DONE  steps=%lld  time=%.6f s  sites/s=%.3f  MatMults=%lld  E=%.12g\n", LLD(GlobIdx - steps0), ts1 - ts0,
                               (GlobIdx - steps0) / (ts1 - ts0), LLD(total_matmults - mm0), gse);
         last_sweep_seconds = ts1 - ts0; last_sweep_steps = GlobIdx - steps0; last_sweep_matmults = total_matmults - mm0;
+        ierr = SaveSweepsData(); CHKERRQ(ierr);
         ++LoopIdx;
         return 0;
     }
@@ -393,7 +441,70 @@ public:
         trunc_err.push_back(BT_L.TruncErr);
         ierr = SaveStepData(step); CHKERRQ(ierr);
         ierr = SaveTimingsData(timings); CHKERRQ(ierr);
-        ++GlobIdx; ++StepIdx;
+        ++GlobIdx; ++StepIdx; ++rows_written;
+        return 0;
+    }
+
+    /* ---- checkpoint / restart (reference include/DMRGBlockContainer.hpp:2456-2481,2689-2764) ---------- */
+    static std::string BlockDir(const std::string& BlockType, const PetscInt& iblock) { char b[64]; snprintf(b, sizeof(b), "%s_%09lld/", BlockType.c_str(), LLD(iblock)); return b; }
+    static std::string SweepDir(const PetscInt& isweep) { char b[64]; snprintf(b, sizeof(b), "Sweep_%09lld/", LLD(isweep)); return b; }
+
+    /** "-key value" lines of a file go into the options database (PetscOptionsInsertFile of the reference). */
+    PetscErrorCode SetOptionsFromFile(const std::string& filename)
+    {
+        std::ifstream f(filename);
+        if (!f) SETERRQ1(mpi_comm, PETSC_ERR_FILE_OPEN, "cannot read %s", filename.c_str());
+        std::string line;
+        while (std::getline(f, line)) {
+            std::istringstream ls(line);
+            std::string key, val;
+            if (!(ls >> key) || key.size() < 2 || key[0] != '-') continue;
+            ls >> val;
+            PetscErrorCode ierr = PetscOptionsSetValue(NULL, key.c_str(), val.c_str()); CHKERRQ(ierr);
+        }
+        return 0;
+    }
+    PetscErrorCode RetrieveInfoFile(const std::string& filename, std::map<std::string, PetscInt>& dict)
+    {
+        std::ifstream f(filename);
+        if (!f) SETERRQ1(mpi_comm, PETSC_ERR_FILE_OPEN, "cannot read %s", filename.c_str());
+        std::string key; long long val;
+        while (f >> key >> val) dict[key] = (PetscInt)val;
+        return 0;
+    }
+    /** the sweep-schedule options, as given on the command line (reference :2689-2722) */
+    PetscErrorCode SaveAsOptions(const std::string& filename)
+    {
+        std::ofstream f(filename);
+        if (!f) SETERRQ1(mpi_comm, PETSC_ERR_FILE_OPEN, "cannot write %s", filename.c_str());
+        char val[4096]; PetscBool set;
+        for (const char* key : {"-spin", "-mstates", "-mwarmup", "-nsweeps", "-msweeps", "-maxnsweeps"}) {
+            PetscErrorCode ierr = PetscOptionsGetString(NULL, NULL, key, val, sizeof(val), &set); CHKERRQ(ierr);
+            if (set) f << key << " " << (val[0] ? val : "yes") << "\n";
+        }
+        return 0;
+    }
+    /** End of the warm-up / of a sweep: everything a later run needs to continue from here -- the model
+        (Hamiltonian.dat), the sweep schedule (PetscOptions.dat), the counters (Sweep.dat) and the first num_sites/2
+        blocks (Sys_%09d/), under scratch_dir/Sweep_%09d/ (reference :2724-2764 + Block::SaveAndDestroy). */
+    PetscErrorCode SaveSweepsData()
+    {
+        if (!do_scratch_dir || mpi_rank) return 0;
+        PetscErrorCode ierr;
+        const std::string dir = scratch_dir + SweepDir(LoopIdx);
+        ierr = Makedir(dir); CHKERRQ(ierr);
+        for (PetscInt ib = 0; ib < sys_ninit; ++ib) {
+            ierr = Makedir(dir + BlockDir("Sys", ib)); CHKERRQ(ierr);
+            ierr = sys_blocks[(size_t)ib].SaveToDisk(dir + BlockDir("Sys", ib)); CHKERRQ(ierr);
+        }
+        ierr = Ham.SaveAsOptions(dir + "Hamiltonian.dat"); CHKERRQ(ierr);
+        ierr = SaveAsOptions(dir + "PetscOptions.dat"); CHKERRQ(ierr);
+        std::ofstream f(dir + "Sweep.dat");          /* written last: its presence marks the checkpoint as complete */
+        if (!f) SETERRQ1(mpi_comm, PETSC_ERR_FILE_OPEN, "cannot write %sSweep.dat", dir.c_str());
+        const PetscInt num_env_blocks = 1, env_ninit = 0;
+        auto dump = [&](const char* k, PetscInt v) { f << std::setw(20) << k << "  " << v << "\n"; };
+        dump("GlobIdx", GlobIdx); dump("LoopIdx", LoopIdx); dump("num_sys_blocks", num_sys_blocks); dump("num_env_blocks", num_env_blocks);
+        dump("sys_ninit", sys_ninit); dump("env_ninit", env_ninit); dump("num_sites", num_sites); dump("sweep_mode", (PetscInt)sweep_mode); dump("msweep_idx", msweep_idx);
         return 0;
     }
 
@@ -622,7 +733,7 @@ private:
     }
     PetscErrorCode SaveStepData(const StepData& d)
     {
-        fprintf(fp_step, "%s    [ %lld, %s, %lld, %lld, %lld, %lld, %lld, %lld, %lld, %lld, %lld, %lld, %lld, %lld, %lld, %.12g, %.12g, %.12g]", GlobIdx ? ",\n" : "",
+        fprintf(fp_step, "%s    [ %lld, %s, %lld, %lld, %lld, %lld, %lld, %lld, %lld, %lld, %lld, %lld, %lld, %lld, %lld, %.12g, %.12g, %.12g]", rows_written ? ",\n" : "",
                 LLD(GlobIdx), LoopType ? "\"Sweep\"" : "\"Warmup\"", LLD(LoopIdx), LLD(StepIdx), LLD(d.NumSites_Sys), LLD(d.NumSites_Env), LLD(d.NumSites_SysEnl), LLD(d.NumSites_EnvEnl),
                 LLD(d.NumStates_Sys), LLD(d.NumStates_Env), LLD(d.NumStates_SysEnl), LLD(d.NumStates_EnvEnl), LLD(d.NumStates_SysRot), LLD(d.NumStates_EnvRot), LLD(d.NumStates_H),
                 d.TruncErr_Sys, d.TruncErr_Env, d.GSEnergy);
@@ -636,14 +747,14 @@ private:
     }
     PetscErrorCode SaveTimingsData(const TimingsData& d)
     {
-        fprintf(fp_timings, "%s    [ %lld, %.9g, %.9g, %.9g, %.9g, %.9g, %.9g, %lld ]", GlobIdx ? ",\n" : "", LLD(GlobIdx), d.Total, d.tEnlr, d.tKron, d.tDiag, d.tRdms, d.tRotb, LLD(d.nMatMult));
+        fprintf(fp_timings, "%s    [ %lld, %.9g, %.9g, %.9g, %.9g, %.9g, %.9g, %lld ]", rows_written ? ",\n" : "", LLD(GlobIdx), d.Total, d.tEnlr, d.tKron, d.tDiag, d.tRdms, d.tRotb, LLD(d.nMatMult));
         fflush(fp_timings);
         return 0;
     }
     /** Per-sector RDM eigenvalues of one side, in the reference's EntanglementSpectra.json layout. */
     PetscErrorCode SaveEntanglementSpectrum(int side, const std::vector<Eigen_t>& eigen, const QuantumNumbers& qn)
     {
-        if (side == 0) fprintf(fp_entanglement, "%s  {\n    \"GlobIdx\": %lld,\n", GlobIdx ? ",\n" : "", LLD(GlobIdx));
+        if (side == 0) fprintf(fp_entanglement, "%s  {\n    \"GlobIdx\": %lld,\n", rows_written ? ",\n" : "", LLD(GlobIdx));
         fprintf(fp_entanglement, "    \"%s\": [\n", side == 0 ? "Sys" : "Env");
         PetscInt prev = -1; bool first_sector = true;
         for (const Eigen_t& e : eigen) {
@@ -689,6 +800,10 @@ private:
     };
     std::vector<Correlator> measurements;
     PetscBool corr_headers_printed = PETSC_FALSE, corr_printed_first = PETSC_FALSE;
+    PetscBool do_scratch_dir = PETSC_FALSE, restart = PETSC_FALSE, restart_options = PETSC_FALSE;
+    std::string restart_dir;
+    PetscInt restart_sys_ninit = 0, restart_num_sites = 0, restart_msweep_idx = -1;
+    PetscInt rows_written = 0;          /**< steps recorded by THIS run (a restarted run starts at GlobIdx > 0) */
 };
 
 #endif

@@ -51,6 +51,14 @@ int main()
             Mat m = (op == "Sz") ? blocks[name].Sz(site) : blocks[name].Sp(site);
             ierr = m->set(row, col, val);
             printf("rc %d\n", ierr);
+        } else if (cmd == "save") {
+            std::string name, dir; is >> name >> dir;
+            ierr = blocks[name].SaveToDisk(dir);
+            printf("rc %d\n", ierr);
+        } else if (cmd == "load") {
+            std::string name, dir; is >> name >> dir;
+            ierr = blocks[name].InitializeFromDisk(PETSC_COMM_WORLD, dir);
+            printf("rc %d\n", ierr);
         } else if (cmd == "check") {
             std::string name; is >> name;
             ierr = blocks[name].CheckOperatorBlocks();

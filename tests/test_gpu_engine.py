@@ -119,6 +119,41 @@ def test_correlators_match_exact_diagonalisation(tmp_path):
     assert abs(bond - e0) <= 1e-10 * abs(e0) and abs(run["GSEnergy"] - e0) <= 1e-10 * abs(e0)
 
 
+def test_checkpoint_restart_continues_the_run(tmp_path):
+    """one sweep + restart from its checkpoint + one sweep reproduces, step for step and bit for bit, the
+    second sweep of an uninterrupted two-sweep run (blocks are restored exactly, the eigensolver's start vectors depend
+    only on the restored global step index).  The checkpoint has the reference's directory layout."""
+    model = ["-Lx", 6, "-Ly", 2, "-J1", 1, "-Jz1", 1, "-J2", 0.5, "-Jz2", 0.5, "-mwarmup", 24, "-H_eps_tol", 1e-12]
+    (tmp_path / "a").mkdir(); (tmp_path / "b1").mkdir(); (tmp_path / "b2").mkdir()
+    rows_a, run_a, _ = run_engine(tmp_path / "a", *model, "-nsweeps", 2)
+    rows_b1, _, _ = run_engine(tmp_path / "b1", *model, "-nsweeps", 1, "-scratch_dir", str(tmp_path / "scratch1"))
+    sdir = tmp_path / "scratch1"
+    assert sorted(p.name for p in sdir.iterdir()) == ["Sweep_000000000", "Sweep_000000001"]        # warm-up, sweep 1
+    last = sdir / "Sweep_000000001"
+    for name in ("Hamiltonian.dat", "PetscOptions.dat", "Sweep.dat", "Sys_000000000/BlockInfo.dat", "Sys_000000005/QuantumNumbers.dat",
+                 "Sys_000000005/Sp_000000005.mat", "Sys_000000005/H_000000000.mat"):
+        assert (last / name).exists(), name
+    assert not (last / "Sys_000000006").exists()                                                    # only the first N/2 blocks
+    sweep = dict(ln.split() for ln in open(last / "Sweep.dat") if ln.strip())
+    assert int(sweep["LoopIdx"]) == 1 and int(sweep["sys_ninit"]) == 6 and int(sweep["num_sites"]) == 12
+    # restart: the model comes from Hamiltonian.dat (a deliberately wrong -Lx on the command line is overridden)
+    rows_b2, run_b2, _ = run_engine(tmp_path / "b2", "-Lx", 2, "-Ly", 2, "-mwarmup", 24, "-H_eps_tol", 1e-12, "-nsweeps", 1,
+                                    "-restart_dir", str(sdir), "-scratch_dir", str(tmp_path / "scratch2"))
+    n1 = len(rows_b1)
+    assert rows_a[:n1] and [r["GSEnergy"] for r in rows_a[:n1]] == [r["GSEnergy"] for r in rows_b1]
+    second = rows_a[n1:]
+    assert len(rows_b2) == len(second) == 12 - 4
+    for r, o in zip(rows_b2, second):
+        for key in ("GlobIdx", "LoopIdx", "NSites_Sys", "NSites_Env", "NumStates_H", "NStates_SysRot", "GSEnergy", "TruncErr_Sys", "TruncErr_Env"):
+            assert r[key] == o[key], (key, r[key], o[key])
+    assert run_b2["GSEnergy"] == run_a["GSEnergy"]
+    assert (tmp_path / "scratch2" / "Sweep_000000002" / "Sweep.dat").exists()                       # the restarted run checkpoints on
+    # a restart directory without checkpoints is refused
+    (tmp_path / "empty").mkdir()
+    out = subprocess.run([EXE, "-restart_dir", str(tmp_path / "empty"), "-mwarmup", "8", "-data_dir", str(tmp_path / "c") + "/"], capture_output=True, text=True, timeout=60)
+    assert out.returncode != 0 and "No Sweep directory" in out.stderr
+
+
 def test_driver_fails_loudly_on_bad_options(tmp_path):
     out = subprocess.run([EXE, "-Lx", "3", "-Ly", "1", "-mwarmup", "8", "-data_dir", str(tmp_path) + "/"], capture_output=True, text=True, timeout=60)
     assert out.returncode != 0 and "must be even" in out.stderr

@@ -107,3 +107,33 @@ def test_engine_hamiltonian_terms_match_oracle(opts):
         assert got == want
     snake = [tuple(int(x) for x in t.split(",")) for t in out[4].split()[1:]]
     assert all(H.To2D(i) == (ix, jy) and idx == i for i, (ix, jy, idx) in enumerate(snake))
+
+
+def test_engine_block_checkpoint_round_trip(tmp_path):
+    """tests/UnitTests_DMRGBlock_SaveInfo.cpp:17-88 of the reference: a block written to disk (BlockInfo.dat,
+    QuantumNumbers.dat, one file per operator) and rebuilt with InitializeFromDisk carries the same sectors and the same
+    operator entries; a directory that does not exist and a tampered BlockInfo.dat are refused."""
+    f = json.load(open(os.path.join(GOLD, "block_fixture.json")))
+    d = dict(nsites=f["nsites"], qn_list=f["qn_list"], qn_size=f["qn_size"], Sz={"0": f["valid"]["SetSz0"], "1": f["valid"]["SetSz1"]},
+             Sp={"0": f["valid"]["SetSp0"], "1": f["valid"]["SetSp1"]})
+    d1, d2 = str(tmp_path / "blk"), str(tmp_path / "missing")
+    os.makedirs(d1)
+    out = tool(block_lines("B", d) + [f"save B {d1}", f"save B {d2}", "dump B", f"load C {d1}", "check C", "dump C"])
+    rcs = [ln for ln in out if ln.startswith("rc ")]
+    n_set = len(block_lines("B", d))
+    assert rcs[n_set] == "rc 0" and rcs[n_set + 1] != "rc 0" and rcs[n_set + 2] == "rc 0" and rcs[n_set + 3] == "rc 0"
+    ends = [i for i, ln in enumerate(out) if ln == "end"]
+    first, second = out[:ends[0] + 1], out[ends[0] + 1:ends[1] + 1]
+    s1 = [ln for ln in first if ln.startswith("sectors")][0]
+    s2 = [ln for ln in second if ln.startswith("sectors")][0]
+    assert s1 == s2
+    assert parse_dump(first) == parse_dump(second) and len(parse_dump(first)) == 2 * f["nsites"]
+    for name in ("BlockInfo.dat", "QuantumNumbers.dat", "Sz_000000000.mat", "Sp_000000001.mat"):
+        assert os.path.exists(os.path.join(d1, name)), name
+    info = open(os.path.join(d1, "BlockInfo.dat")).read().split()
+    assert info[info.index("NumSites") + 1] == str(f["nsites"]) and info[info.index("NumSectors") + 1] == str(len(f["qn_list"]))
+    # tamper: a different sector count must be caught by the cross-check
+    txt = open(os.path.join(d1, "BlockInfo.dat")).read().replace("NumSectors" + " " * 21 + str(len(f["qn_list"])), "NumSectors" + " " * 21 + "9")
+    open(os.path.join(d1, "BlockInfo.dat"), "w").write(txt)
+    out = tool([f"load D {d1}"])
+    assert out[-1] != "rc 0"
