@@ -18,12 +18,14 @@
 namespace dmrgx {
 namespace {
 
-constexpr int JB = 16, JS = 2 * JB;          // block size, sub-problem size.  Every outer round costs one sub-solve plus one
+#ifndef DMRGX_JB
+#define DMRGX_JB 16
+#endif
+constexpr int JB = DMRGX_JB, JS = 2 * JB;          // block size, sub-problem size.  Every outer round costs one sub-solve plus one
                                              // update launch of pure latency (~20 + 13 us at any matrix size); 32 x 32
                                              // sub-problems (31 dependent rotation rounds on 256 threads) measured best:
                                              // JB = 32 halves the rounds but its 63-round, 1024-thread solve is > 2x slower
 constexpr int JACOBI_INNER_SWEEPS = 1;       // one cyclic sweep per visit: the outer sweeps finish the job (fewer total us)
-constexpr int JT = JS / 16;                  // outputs per thread and dimension in the 16 x 16-thread LDS matmul
 constexpr int JLD = JS + 1;
 constexpr int SUB_THREADS = JB * JB;           // sub-solve: one thread per pair of rotation pairs
 
@@ -174,30 +176,27 @@ jacobi_sub_kernel(const MatDesc* __restrict__ mats, const PairRef* __restrict__ 
     for (int e = tid; e < JS * JS; e += SUB_THREADS) Rout[e] = R[(e / JS) * JLD + (e % JS)];
 }
 
-// out(JS x JS) = L * M, all in LDS; 16 x 16 threads, each a JT x JT block
-__device__ __forceinline__ void lds_mm(const double* L, const double* M, double acc[JT][JT], int ty, int tx)
+// One 16 x 16 block (block row wr, block column wc) of L * M for two JS x JS operands in LDS (row stride JLD), on the MFMA
+// pipe: 8 x v_mfma_f64_16x16x4_f64 per wave.  Fragment maps as in ggemm.hip: A[i = l&15][k = l>>4], B[k = l>>4][j = l&15],
+// result col = l&15, row = (l>>4) + 4 reg.  (The plain-FMA version of this product was LDS-bandwidth bound: the update
+// kernel ran at ~12 TF/s and took 70 % of the eigensolve at m = 2048.)
+typedef double jd4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ jd4 mfma_block(const double* L, const double* M, int wr, int wc, int lane)
 {
+    static_assert(JS == 32, "mfma_block: a 32 x 32 tile is covered by 2 x 2 waves");
+    const int l15 = lane & 15, l4 = lane >> 4;
+    jd4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-    for (int i = 0; i < JT; ++i)
-#pragma unroll
-        for (int j = 0; j < JT; ++j) acc[i][j] = 0.0;
-    for (int k = 0; k < JS; ++k) {
-        double a[JT], b[JT];
-#pragma unroll
-        for (int i = 0; i < JT; ++i) a[i] = L[(JT * ty + i) * JLD + k];
-#pragma unroll
-        for (int j = 0; j < JT; ++j) b[j] = M[k * JLD + JT * tx + j];
-#pragma unroll
-        for (int i = 0; i < JT; ++i)
-#pragma unroll
-            for (int j = 0; j < JT; ++j) acc[i][j] += a[i] * b[j];
-    }
+    for (int kk = 0; kk < JS; kk += 4)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(L[(16 * wr + l15) * JLD + kk + l4], M[(kk + l4) * JLD + 16 * wc + l15], acc, 0, 0, 0);
+    return acc;
 }
 
 // One launch per round applies all rotations of the round:
-//   kind 0 (A, two-sided): block (P,Q) of the pair-block partition:  A[P,Q] <- R_P^T . A[P,Q] . R_Q   -- every JS x JS block
-//                          of A is read and written by exactly one workgroup, so the column and the row update of the
-//                          textbook formulation fuse into one pass over A (half the launches, half the traffic);
+//   kind 0 (A, two-sided): block (P,Q), P <= Q, of the pair-block partition:  A[P,Q] <- R_P^T . A[P,Q] . R_Q, and its
+//                          transpose is written to A[Q,P] -- every JS x JS block of A is written by exactly one workgroup, the
+//                          column and the row update of the textbook formulation fuse into one pass over the upper
+//                          triangle, and A stays symmetric to the last bit;
 //   kind 1 (V, one-sided): rows [JS*t, JS*t+JS) x pair-block Q:      V[t,Q] <- V[t,Q] . R_Q
 struct UpdTask { int32_t mat, p, q, kind; };     // p: pair index (kind 0) or row tile (kind 1); q: pair index (both local to mat)
 __global__ void __launch_bounds__(256)
@@ -207,7 +206,7 @@ jacobi_update_kernel(const MatDesc* __restrict__ mats, const int32_t* __restrict
     __shared__ double X[JS * JLD], RQ[JS * JLD], RP[JS * JLD];
     const UpdTask t = tasks[blockIdx.x];
     const MatDesc m = mats[t.mat];
-    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
     int IQ, JQ, IP = 0, JP = 0;
     pair_blocks(m.nb, round, t.q, IQ, JQ);
     if (t.kind == 0) pair_blocks(m.nb, round, t.p, IP, JP);
@@ -223,21 +222,27 @@ jacobi_update_kernel(const MatDesc* __restrict__ mats, const int32_t* __restrict
         if (t.kind == 0) RP[j * JLD + i] = Rp[e];                 // RP = R_P^T
     }
     __syncthreads();
-    double acc[JT][JT];
-    lds_mm(X, RQ, acc, ty, tx);                                   // X . R_Q
+    const int l15 = lane & 15, l4 = lane >> 4;
+    jd4 acc = mfma_block(X, RQ, wr, wc, lane);                    // X . R_Q
     if (t.kind == 0) {
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < JT; ++i)
-#pragma unroll
-            for (int j = 0; j < JT; ++j) X[(JT * ty + i) * JLD + JT * tx + j] = acc[i][j];
+        for (int r = 0; r < 4; ++r) X[(16 * wr + l4 + 4 * r) * JLD + 16 * wc + l15] = acc[r];
         __syncthreads();
-        lds_mm(RP, X, acc, ty, tx);                               // R_P^T . (X . R_Q)
+        acc = mfma_block(RP, X, wr, wc, lane);                    // R_P^T . (X . R_Q)
     }
 #pragma unroll
-    for (int i = 0; i < JT; ++i)
+    for (int r = 0; r < 4; ++r) M[(int64_t)rp(16 * wr + l4 + 4 * r) * m.npad + cq(16 * wc + l15)] = acc[r];
+    if (t.kind == 0 && t.p != t.q) {                              // mirror: A[Q,P] = (A[P,Q])^T, staged through LDS for row-wise stores
+        __syncthreads();
 #pragma unroll
-        for (int j = 0; j < JT; ++j) M[(int64_t)rp(JT * ty + i) * m.npad + cq(JT * tx + j)] = acc[i][j];
+        for (int r = 0; r < 4; ++r) X[(16 * wr + l4 + 4 * r) * JLD + 16 * wc + l15] = acc[r];
+        __syncthreads();
+        for (int e = tid; e < JS * JS; e += 256) {
+            const int i = e / JS, j = e % JS;                     // element (i, j) of the transposed block
+            M[(int64_t)cq(i) * m.npad + rp(j)] = X[j * JLD + i];
+        }
+    }
 }
 
 // per matrix and block of the grid: out[(mat*NORM_BLOCKS + b)*2] = partial sum of squares off the diagonal, [..+1] = on it
@@ -369,7 +374,7 @@ extern "C" dmrgx_status dmrgx_rdm_create(const dmrgx_sectors* left, const dmrgx_
         pair_start[mi] = (int32_t)pairs.size();
         const int np = m.nb / 2;
         for (int j = 0; j < np; ++j) pairs.push_back(PairRef{mi, j});
-        for (int p = 0; p < np; ++p) for (int q = 0; q < np; ++q) tiles.push_back(UpdTask{mi, p, q, 0});
+        for (int p = 0; p < np; ++p) for (int q = p; q < np; ++q) tiles.push_back(UpdTask{mi, p, q, 0});     // upper triangle; the kernel mirrors
         for (int t = 0; t < m.npad / JS; ++t) for (int q = 0; q < np; ++q) tiles.push_back(UpdTask{mi, t, q, 1});
     }
     const int64_t rbuf_off = total; total += (int64_t)pairs.size() * JS * JS;
