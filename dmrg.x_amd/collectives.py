@@ -22,7 +22,9 @@ def torch_hooks(dist, rank, world):
 
     def allgather(user, full_ptr, seg_stride, stream):
         full = _view(full_ptr, seg_stride * world, device)
-        dist.all_gather_into_tensor(full, full[rank * seg_stride:(rank + 1) * seg_stride])
+        # out-of-place send buffer: a copy of this rank's segment (a few MB over HBM) instead of relying on aliasing rules
+        # of the in-place form
+        dist.all_gather_into_tensor(full, full[rank * seg_stride:(rank + 1) * seg_stride].clone())
         return 0
 
     def allreduce(user, buf_ptr, count, stream):

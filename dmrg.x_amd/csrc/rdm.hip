@@ -445,13 +445,17 @@ extern "C" dmrgx_status dmrgx_rdm_create(const dmrgx_sectors* left, const dmrgx_
         DMRGX_HIP(hipMemcpyAsync(norms.data(), buf + norm_off, norms.size() * sizeof(double), hipMemcpyDeviceToHost, st));
         DMRGX_HIP(hipStreamSynchronize(st));
         bool conv = true;
+        static const bool trace = getenv("DMRGX_RDM_TRACE") != nullptr;      // developer aid: convergence history on stderr
+        double worst = 0.0;
         // off <= 1e-12 ||A||_F: V is a product of rotations (orthogonal to round-off whatever the convergence) and the
         // eigenvalues are re-evaluated as Rayleigh quotients below, whose error is O(off^2)
         for (int mi = 0; mi < nm; ++mi) {
             double off2 = 0.0, dg2 = 0.0;
             for (int b = 0; b < NORM_BLOCKS; ++b) { off2 += norms[(size_t)(mi * NORM_BLOCKS + b) * 2]; dg2 += norms[(size_t)(mi * NORM_BLOCKS + b) * 2 + 1]; }
             if (off2 > 1e-24 * (off2 + dg2)) conv = false;
+            worst = std::max(worst, off2 / std::max(off2 + dg2, 1e-300));
         }
+        if (trace) fprintf(stderr, "[rdm] sweep %d: max off^2/total^2 = %.3e\n", sweep, worst);
         if (conv) break;
         for (int r = 0; r < rounds; ++r) {
             hipLaunchKernelGGL(jacobi_sub_kernel, dim3((unsigned)pairs.size()), dim3(SUB_THREADS), 0, st, dm, d_pairs.as<PairRef>(), buf, buf + rbuf_off, r);
