@@ -283,13 +283,15 @@ struct Builder {
             std::vector<int32_t> pstart;
             { int32_t acc = 0; for (int32_t p = gemm_begin; p < gemm_end; ++p) { pstart.push_back(acc); acc += (prods[p].K + GG_BK - 1) / GG_BK; } }
             const int32_t n_axpy = groups[g].n_axpy;
-            int32_t lo = 0;
+            int32_t lo = 0, pcur = gemm_begin;
             for (int32_t sidx = 0; sidx < S; ++sidx) {
                 const int32_t hi = cuts[sidx];
                 const int32_t nb = (int32_t)prods.size();
                 if (sidx == 0) for (int32_t q = 0; q < n_axpy; ++q) { const RelProd ax = prods[axpy_begin + q]; prods.push_back(ax); }
-                for (int32_t p = gemm_begin; p < gemm_end; ++p) {
+                while (pcur < gemm_end && pstart[pcur - gemm_begin] + (prods[pcur].K + GG_BK - 1) / GG_BK <= lo) ++pcur;   // products are in stream order
+                for (int32_t p = pcur; p < gemm_end; ++p) {
                     const int32_t ps = pstart[p - gemm_begin], pe = ps + (prods[p].K + GG_BK - 1) / GG_BK;
+                    if (ps >= hi) break;
                     const int32_t olo = std::max(lo, ps), ohi = std::min(hi, pe);
                     if (olo >= ohi) continue;
                     RelProd sub = prods[p];
