@@ -144,16 +144,22 @@ axpy_dot_kernel(const double* __restrict__ V, int64_t ldv, int nv, const double*
     }
 }
 
-// Second Gram-Schmidt pass fused with the normalisation: dst = (w - V c) * (nrm2 > tiny ? 1/sqrt(nrm2) : 0)
+// Second Gram-Schmidt pass fused with the normalisation: dst = (w - V c) / beta with beta^2 = ||w - V c||^2 = c[nv] - |c|^2
+// (c[nv] = w.w; V orthonormal and c = V^T w the tiny refinement coefficients, so there is no cancellation): every
+// workgroup recomputes beta^2 from the nv+1 reduced dots -- no separate reduction pass, no extra all-reduce and no extra
+// launch -- and workgroup 0 records it in beta2_out (the step's row of the projected matrix).
 __global__ void __launch_bounds__(DOT_THREADS)
 axpy_normalise_kernel(const double* __restrict__ V, int64_t ldv, int nv, const double* __restrict__ c, const double* __restrict__ w,
-                      double* __restrict__ dst, int64_t n, const double* __restrict__ nrm2, double* __restrict__ hacc)
+                      double* __restrict__ dst, int64_t n, double* __restrict__ beta2_out, double* __restrict__ hacc)
 {
-    __shared__ double cs[MAX_NCV + 1];
-    if (threadIdx.x < nv) cs[threadIdx.x] = c[threadIdx.x];
+    __shared__ double cs[MAX_NCV + 2];
+    if (threadIdx.x <= nv) cs[threadIdx.x] = c[threadIdx.x];
     __syncthreads();
     if (blockIdx.x == 0 && threadIdx.x < nv && hacc) hacc[threadIdx.x] += cs[threadIdx.x];
-    const double s2 = *nrm2;
+    double s2 = cs[nv];
+    for (int i = 0; i < nv; ++i) s2 -= cs[i] * cs[i];          // same order in every thread: one value for the whole grid
+    s2 = s2 > 0.0 ? s2 : 0.0;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && beta2_out) *beta2_out = s2;
     const double inv = s2 > 1e-290 ? 1.0 / sqrt(s2) : 0.0;
     for (int64_t e = (int64_t)blockIdx.x * DOT_THREADS + threadIdx.x; e < n; e += (int64_t)gridDim.x * DOT_THREADS) {
         double x = w[e];
@@ -379,11 +385,8 @@ extern "C" dmrgx_status dmrgx_eigs_lowest(dmrgx_kron_plan* plan, const dmrgx_eig
                 DMRGX_HIP(hipMemcpyAsync(c2, c1, (size_t)(nv + 1) * sizeof(double), hipMemcpyDeviceToDevice, st));
             }
             // beta^2 = w'.w' - |c2|^2 ; v_{j+1} = (w' - V c2) / beta
-            hipLaunchKernelGGL(norm_after_projection_kernel, dim3(1), dim3(64), 0, st, c2, nv, nrm);
+            hipLaunchKernelGGL(axpy_normalise_kernel, dim3(nblk), dim3(DOT_THREADS), 0, st, V, n, nv, c2, w, vec(j + 1), n, Hrow(j) + m + 1, Hrow(j));
             DMRGX_HIP(hipGetLastError());
-            hipLaunchKernelGGL(axpy_normalise_kernel, dim3(nblk), dim3(DOT_THREADS), 0, st, V, n, nv, c2, w, vec(j + 1), n, nrm, Hrow(j));
-            DMRGX_HIP(hipGetLastError());
-            DMRGX_HIP(hipMemcpyAsync(Hrow(j) + m + 1, nrm, sizeof(double), hipMemcpyDeviceToDevice, st));
         }
         DMRGX_HIP(hipMemcpyAsync(hbuf.data(), dScal.p, (size_t)(m + 1) * row * sizeof(double), hipMemcpyDeviceToHost, st));
         DMRGX_HIP(hipStreamSynchronize(st));

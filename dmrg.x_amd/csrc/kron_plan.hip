@@ -171,15 +171,18 @@ struct dmrgx_kron_plan {
     dmrgx_kron_info info{};
     DevBuf arena;                       // operators + intermediates
     DevBuf d_rprods, d_rgroups;         // relative tables (stage 1 then stage 2, one array)
-    DevBuf d_prods, d_groups;           // patched absolute tables
+    // Patched (absolute-pointer) task tables, one set per (x, y) pair seen: a Lanczos solve applies the plan to the same
+    // ncv+1 basis vectors cycle after cycle, so after the first cycle no apply has to re-patch (one launch less per step).
+    struct Patched { const double* x = nullptr; double* y = nullptr; DevBuf prods, groups; };
+    std::vector<std::unique_ptr<Patched>> patched;
+    size_t patched_next = 0;            // round-robin victim once PATCHED_MAX sets exist
+    static constexpr size_t PATCHED_MAX = 24;
     DevBuf d_tiles1, d_tiles2, d_tiles1b, d_tiles2b;
     int32_t nprods = 0, ngroups = 0, ntiles1 = 0, ntiles2 = 0, ntiles1b = 0, ntiles2b = 0;
     DevBuf d_layout;
     int32_t nlayout = 0;
     DevBuf d_red_tasks, d_red_tiles;    // split-K fix-up tables
     int32_t n_red_tiles = 0;
-    const double* last_x = nullptr;     // tables are re-patched only when the (x,y) pair changes
-    double* last_y = nullptr;
     bool timing = false;                // per-stage HIP-event timing (dmrgx_kron_plan_timing)
     std::vector<hipEvent_t> ev;         // 3 events per recorded apply
     size_t ev_used = 0;
@@ -635,8 +638,6 @@ extern "C" dmrgx_status dmrgx_kron_plan_create(const dmrgx_kron_desc* d, void* s
     DMRGX_CHK(upload(P->d_tiles2b, B.tiles2b, st));
     DMRGX_CHK(upload(P->d_red_tasks, B.red_tasks, st));
     DMRGX_CHK(upload(P->d_red_tiles, B.red_tiles, st));
-    DMRGX_CHK(P->d_prods.alloc(std::max<size_t>(B.prods.size(), 1) * sizeof(GProd)));
-    DMRGX_CHK(P->d_groups.alloc(std::max<size_t>(B.groups.size(), 1) * sizeof(GGroup)));
     {   // layout conversion table (reference order <-> rank-major stripes)
         std::vector<LayoutSeg> segs;
         for (int32_t k = 0; k < nb; ++k) for (int32_t w = 0; w < W; ++w) {
@@ -676,16 +677,29 @@ extern "C" dmrgx_status dmrgx_kron_apply(dmrgx_kron_plan* P, const double* x_ful
 {
     hipStream_t st = (hipStream_t)stream;
     if (!P || !x_full || !y_local) DMRGX_FAIL(DMRGX_ERR_ARG, "kron_apply: null argument");
-    if (P->last_x != x_full || P->last_y != y_local) {
+    dmrgx_kron_plan::Patched* T = nullptr;
+    for (auto& c : P->patched) if (c->x == x_full && c->y == y_local) { T = c.get(); break; }
+    if (!T) {
+        if (P->patched.size() < dmrgx_kron_plan::PATCHED_MAX) {
+            std::unique_ptr<dmrgx_kron_plan::Patched> c(new (std::nothrow) dmrgx_kron_plan::Patched());
+            if (!c) DMRGX_FAIL(DMRGX_ERR_MEM, "out of host memory");
+            DMRGX_CHK(c->prods.alloc(std::max<size_t>((size_t)P->nprods, 1) * sizeof(GProd)));
+            DMRGX_CHK(c->groups.alloc(std::max<size_t>((size_t)P->ngroups, 1) * sizeof(GGroup)));
+            P->patched.push_back(std::move(c));
+            T = P->patched.back().get();
+        } else {
+            T = P->patched[P->patched_next].get();
+            P->patched_next = (P->patched_next + 1) % dmrgx_kron_plan::PATCHED_MAX;
+        }
+        T->x = x_full; T->y = y_local;
         const int n = std::max(P->nprods, P->ngroups);
         if (n > 0) {
             hipLaunchKernelGGL(patch_tables_kernel, dim3((n + 255) / 256), dim3(256), 0, st,
-                               P->d_rprods.as<RelProd>(), P->d_prods.as<GProd>(), P->nprods,
-                               P->d_rgroups.as<RelGroup>(), P->d_groups.as<GGroup>(), P->ngroups,
+                               P->d_rprods.as<RelProd>(), T->prods.as<GProd>(), P->nprods,
+                               P->d_rgroups.as<RelGroup>(), T->groups.as<GGroup>(), P->ngroups,
                                P->arena.as<double>(), x_full, y_local);
             DMRGX_HIP(hipGetLastError());
         }
-        P->last_x = x_full; P->last_y = y_local;
     }
     hipEvent_t* e = nullptr;
     if (P->timing && P->ev_used + 5 <= 5 * 4096) {
@@ -695,13 +709,13 @@ extern "C" dmrgx_status dmrgx_kron_apply(dmrgx_kron_plan* P, const double* x_ful
     }
     // four launches: {stage 1, stage 2} x {128x128 core tiles, 64x64 remainder tiles}, each bracketed by events
     if (e) DMRGX_HIP(hipEventRecord(e[0], st));
-    DMRGX_CHK(ggemm_launch(P->d_tiles1b.as<GTile>(), P->d_groups.as<GGroup>(), P->d_prods.as<GProd>(), P->ntiles1b, st, 1));
+    DMRGX_CHK(ggemm_launch(P->d_tiles1b.as<GTile>(), T->groups.as<GGroup>(), T->prods.as<GProd>(), P->ntiles1b, st, 1));
     if (e) DMRGX_HIP(hipEventRecord(e[1], st));
-    DMRGX_CHK(ggemm_launch(P->d_tiles1.as<GTile>(), P->d_groups.as<GGroup>(), P->d_prods.as<GProd>(), P->ntiles1, st, 0));
+    DMRGX_CHK(ggemm_launch(P->d_tiles1.as<GTile>(), T->groups.as<GGroup>(), T->prods.as<GProd>(), P->ntiles1, st, 0));
     if (e) DMRGX_HIP(hipEventRecord(e[2], st));
-    DMRGX_CHK(ggemm_launch(P->d_tiles2b.as<GTile>(), P->d_groups.as<GGroup>(), P->d_prods.as<GProd>(), P->ntiles2b, st, 1));
+    DMRGX_CHK(ggemm_launch(P->d_tiles2b.as<GTile>(), T->groups.as<GGroup>(), T->prods.as<GProd>(), P->ntiles2b, st, 1));
     if (e) DMRGX_HIP(hipEventRecord(e[3], st));
-    DMRGX_CHK(ggemm_launch(P->d_tiles2.as<GTile>(), P->d_groups.as<GGroup>(), P->d_prods.as<GProd>(), P->ntiles2, st, 0));
+    DMRGX_CHK(ggemm_launch(P->d_tiles2.as<GTile>(), T->groups.as<GGroup>(), T->prods.as<GProd>(), P->ntiles2, st, 0));
     if (e) DMRGX_HIP(hipEventRecord(e[4], st));
     if (P->n_red_tiles > 0) {
         hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)P->n_red_tiles), dim3(256), 0, st, P->d_red_tiles.as<RedTile>(), P->d_red_tasks.as<RedTask>(), y_local, P->arena.as<double>());
