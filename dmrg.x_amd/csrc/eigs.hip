@@ -367,6 +367,7 @@ extern "C" dmrgx_status dmrgx_eigs_lowest(dmrgx_kron_plan* plan, const dmrgx_eig
         int jend = m;                                         // benchmark mode: stop after exactly max_matvec MatMults
         if (opts->max_matvec > 0) jend = std::min(m, k + std::max(0, opts->max_matvec - n_matvec));
         const bool capped = jend < m || (opts->max_matvec > 0 && n_matvec + (m - k) >= opts->max_matvec);
+        bool early = false;
         for (int j = k; j < jend; ++j) {
             DMRGX_CHK(matvec(vec(j), w));
             ++n_matvec;
@@ -387,6 +388,21 @@ extern "C" dmrgx_status dmrgx_eigs_lowest(dmrgx_kron_plan* plan, const dmrgx_eig
             // beta^2 = w'.w' - |c2|^2 ; v_{j+1} = (w' - V c2) / beta
             hipLaunchKernelGGL(axpy_normalise_kernel, dim3(nblk), dim3(DOT_THREADS), 0, st, V, n, nv, c2, w, vec(j + 1), n, Hrow(j) + m + 1, Hrow(j));
             DMRGX_HIP(hipGetLastError());
+            // A start vector supplied by the caller (the sweep engine's transformed ground state) is usually within a few
+            // Lanczos steps of convergence: look at the Ritz pair every 4 steps instead of only at the end of the cycle.
+            if (opts->use_initial && opts->max_matvec <= 0 && j + 1 < m && (j + 1 - k) % 4 == 0) {
+                DMRGX_HIP(hipMemcpyAsync(hbuf.data(), dScal.p, (size_t)(m + 1) * row * sizeof(double), hipMemcpyDeviceToHost, st));
+                DMRGX_HIP(hipStreamSynchronize(st));
+                const int mm = j + 1;
+                std::vector<double> A((size_t)mm * mm, 0.0), th, Qs;
+                for (int jj = 0; jj < mm; ++jj) for (int i = 0; i <= jj; ++i) {
+                    const double v = (jj >= k) ? hbuf[(size_t)jj * row + i] : T[(size_t)i * m + jj];
+                    A[(size_t)i * mm + jj] = v; A[(size_t)jj * mm + i] = v;
+                }
+                jacobi_eigh(mm, A, th, Qs);
+                const double r = std::fabs(std::sqrt(std::max(0.0, hbuf[(size_t)(mm - 1) * row + m + 1])) * Qs[(size_t)(mm - 1) * mm + 0]);
+                if (r <= tol * std::max(std::fabs(th[0]), 1e-300)) { jend = mm; early = true; break; }
+            }
         }
         DMRGX_HIP(hipMemcpyAsync(hbuf.data(), dScal.p, (size_t)(m + 1) * row * sizeof(double), hipMemcpyDeviceToHost, st));
         DMRGX_HIP(hipStreamSynchronize(st));
@@ -404,6 +420,7 @@ extern "C" dmrgx_status dmrgx_eigs_lowest(dmrgx_kron_plan* plan, const dmrgx_eig
             Q.assign((size_t)m * m, 0.0);
             for (int i = 0; i < mm; ++i) Q[(size_t)i * m + 0] = Qs[(size_t)i * mm + 0];
             ++restarts;
+            if (early) converged = 1;
             break;
         }
         // projected matrix: kept Ritz block is diagonal, new columns come from the recorded coefficients

@@ -19,6 +19,7 @@
 #include <cmath>
 #include <iomanip>
 #include <fstream>
+#include <array>
 #include <sstream>
 #include <iostream>
 #include <map>
@@ -55,6 +56,9 @@ public:
         QuantumNumbers QN;      /**< sectors of the truncated block */
         PetscReal TruncErr = 0; /**< 1 - sum of kept (positive) eigenvalues */
     };
+
+    /** one (old sector, site state) piece of a sector of `block (x) site` */
+    struct EnlPart { int32_t old_sector, site_sector, off, size; };
 
     explicit DMRGBlockContainer(const MPI_Comm& mpi_comm) : mpi_comm(mpi_comm) {}
     ~DMRGBlockContainer() { PetscErrorCode ierr = Destroy(); CPP_CHKERR(ierr); }
@@ -109,6 +113,7 @@ public:
         ierr = PetscOptionsGetInt(NULL, NULL, "-H_eps_max_it", &eps_max_it, NULL); CHKERRQ(ierr);
         if (no_symm) SETERRQ(mpi_comm, PETSC_ERR_SUP, "Unsupported option: no_symm.");
         ierr = PetscOptionsGetBool(NULL, NULL, "-debug_check_symmetry", &debug_symm, NULL); CHKERRQ(ierr);
+        ierr = PetscOptionsGetBool(NULL, NULL, "-wavefunction_guess", &use_guess, NULL); CHKERRQ(ierr);
 
         PetscBool opt = PETSC_FALSE;
         ierr = PetscOptionsGetString(NULL, NULL, "-scratch_dir", path, PETSC_MAX_PATH_LEN, &opt); CHKERRQ(ierr);
@@ -399,6 +404,10 @@ public:
             dmrgx_eigs_opts o;
             memset(&o, 0, sizeof(o));
             o.ncv = (int32_t)eps_ncv; o.max_it = (int32_t)eps_max_it; o.tol = eps_tol; o.seed = 0x9E3779B9u + (uint64_t)GlobIdx;
+            bool guessed = false;
+            try { ierr = TransformedGuess(KronBlocks, SysBlock, EnvBlock, gsv_r, guessed); CHKERRQ(ierr); }
+            catch (const std::exception& e) { SETERRQ1(mpi_comm, 1, "wavefunction transformation: %s", e.what()); }
+            if (guessed) { o.use_initial = 1; ++guesses_used; }
             dmrgx_eigs_stats st;
             memset(&st, 0, sizeof(st));
             if (dmrgx_eigs_lowest(H->plan, &o, &gse_r, gsv_r->buf->dev_uninitialised(), &st, nullptr))
@@ -414,6 +423,24 @@ public:
         BasisTransformation BT_L, BT_R;
         ierr = GetTruncation(KronBlocks, gsv_r, MStates, BT_L, BT_R); CHKERRQ(ierr);
         ierr = CalculateCorrelations_BlockDiag(KronBlocks, gsv_r, do_measurements); CHKERRQ(ierr);
+        if (use_guess) {   /* what the next step needs to carry this ground state over */
+            prev.valid = false;
+            prev.insys = BlockIndex(SysBlock); prev.inenv = BlockIndex(EnvBlock); prev.outsys = BlockIndex(SysBlockOut); prev.outenv = BlockIndex(EnvBlockOut);
+            if (prev.insys >= 0 && prev.inenv >= 0 && prev.outsys >= 0 && prev.outenv >= 0 && BT_L.RotMatT && BT_R.RotMatT) {
+                prev.psi = gsv_r;
+                prev.kb.clear();
+                for (PetscInt k = 0; k < KronBlocks.size(); ++k)
+                    prev.kb.push_back({KronBlocks.LeftIdx(k), KronBlocks.RightIdx(k), SysBlockEnl.Magnetization.Sizes(KronBlocks.LeftIdx(k)),
+                                       EnvBlockEnl.Magnetization.Sizes(KronBlocks.RightIdx(k)), KronBlocks.Offsets(k)});
+                ierr = EnlargedParts(SysBlock, prev.partsL); CHKERRQ(ierr);
+                ierr = EnlargedParts(EnvBlock, prev.partsR); CHKERRQ(ierr);
+                prev.rotL = BT_L.RotMatT->rot; prev.rotR = BT_R.RotMatT->rot;
+                if (block_rot.size() < sys_blocks.size()) block_rot.resize(sys_blocks.size());
+                block_rot[(size_t)prev.outsys] = prev.rotL;
+                block_rot[(size_t)prev.outenv] = same ? prev.rotL : prev.rotR;
+                prev.valid = true;
+            }
+        }
         ierr = VecDestroy(&gsv_r); CHKERRQ(ierr);
         ierr = SysBlockOut.Destroy(); CHKERRQ(ierr);
         ierr = EnvBlockOut.Destroy(); CHKERRQ(ierr);
@@ -442,6 +469,169 @@ public:
         ierr = SaveStepData(step); CHKERRQ(ierr);
         ierr = SaveTimingsData(timings); CHKERRQ(ierr);
         ++GlobIdx; ++StepIdx; ++rows_written;
+        return 0;
+    }
+
+    /* ---- wavefunction transformation ------------------------------------------------------------------------------
+       The reference starts every eigensolve from a random vector (include/DMRGBlockContainer.hpp:1489-1496; its legacy
+       solver seeded it with the previous ground state, old/idmrg.cpp:203).  Here the previous step's ground state is
+       carried into the new superblock basis (White 1996): with R the truncation just computed on the growing side and R'
+       the stored truncation that created the shrinking side's block from the next smaller one,
+           psi'[(a' s_b), (b' s_c)] = sum  R[a'; (a s_a)]  psi[(a s_a), (b s_b)]  R'[b; (b' s_c)],
+       two grouped MFMA launches over sector blocks.  Converged results do not depend on the start vector; the number of
+       MatMults per step does.  -wavefunction_guess 0 restores the random start. */
+    PetscInt BlockIndex(const Block& b) const
+    {
+        if (sys_blocks.empty()) return -1;
+        const Block* first = &sys_blocks[0];
+        if (&b < first || &b >= first + sys_blocks.size()) return -1;
+        return (PetscInt)(&b - first);
+    }
+    /** Decomposition of the sectors of `old (x) site` into (old sector, site state) parts, in basis order
+        (the merged-KronBlock order of KronEye_Explicit). */
+    PetscErrorCode EnlargedParts(Block& old, std::vector<std::vector<EnlPart>>& parts)
+    {
+        KronBlocks_t KB(old, AddSite(), {}, NULL, -1);
+        parts.clear();
+        PetscReal last = 0; bool have = false;
+        for (PetscInt k = 0; k < KB.size(); ++k) {
+            if (!have || KB.QN(k) < last) { parts.emplace_back(); last = KB.QN(k); have = true; }
+            int32_t off = 0;
+            for (const EnlPart& e : parts.back()) off += e.size;
+            parts.back().push_back(EnlPart{(int32_t)KB.LeftIdx(k), (int32_t)KB.RightIdx(k), off, (int32_t)KB.Sizes(k)});
+        }
+        return 0;
+    }
+    /** Transposed copy (n x kept) of a rotation block (kept x n) on the device. */
+    static std::shared_ptr<dmrgx_host::DevBuffer> TransposedCopy(const std::shared_ptr<dmrgx_host::DevBuffer>& rt, int32_t kept, int32_t n)
+    {
+        auto t = std::make_shared<dmrgx_host::DevBuffer>((size_t)kept * n, dmrgx_host::DevBuffer::device_only_t{});
+        if ((size_t)kept * n == 0) return t;
+        if (dmrgx_memset_zero(t->dev_uninitialised(), (size_t)kept * n * sizeof(double), nullptr)) throw std::runtime_error(dmrgx_last_error());
+        dmrgx_axpy_task k;
+        k.dst = t->dev_uninitialised(); k.dst_base = nullptr; k.src = rt->dev_ro(); k.ldd = kept; k.lds = n; k.nr = n; k.nc = kept; k.transposed = 1; k.alpha = 1.0;
+        if (dmrgx_cells_axpy(1, &k, nullptr)) throw std::runtime_error(dmrgx_last_error());
+        return t;
+    }
+
+    /** Fills `guess` (device, layout of KronBlocks) from the previous step if the two steps are consecutive positions
+        of a sweep; returns used = false (guess untouched) otherwise or when any dimension does not line up. */
+    PetscErrorCode TransformedGuess(KronBlocks_t& KronBlocks, Block& SysBlock, Block& EnvBlock, const Vec& guess, bool& used)
+    {
+        used = false;
+        if (!use_guess || !prev.valid) return 0;
+        const PetscInt insys = BlockIndex(SysBlock), inenv = BlockIndex(EnvBlock);
+        if (insys < 0 || inenv < 0) return 0;
+        const bool grow_left = (insys == prev.outsys && inenv == prev.inenv - 1);
+        const bool grow_right = (inenv == prev.outenv && insys == prev.insys - 1);
+        if (!grow_left && !grow_right) return 0;
+        using dmrgx_host::BasisRotation;
+        /* G: this step's truncation on the growing side; S: creation rotation of the shrinking side's previous block */
+        const std::shared_ptr<BasisRotation> G = grow_left ? prev.rotL : prev.rotR;
+        const PetscInt shrink_idx = grow_left ? prev.inenv : prev.insys;
+        if (shrink_idx < 0 || shrink_idx >= (PetscInt)block_rot.size() || !block_rot[(size_t)shrink_idx] || !G) return 0;
+        const std::shared_ptr<BasisRotation> S = block_rot[(size_t)shrink_idx];
+        Block& Lnew = KronBlocks.LeftBlockRefMod();
+        Block& Rnew = KronBlocks.RightBlockRefMod();
+        /* new enlarged sectors: growing side = (new block (x) site), shrinking side must equal S's source basis */
+        std::vector<std::vector<EnlPart>> parts_grow;
+        PetscErrorCode ierr = EnlargedParts(grow_left ? SysBlock : EnvBlock, parts_grow); CHKERRQ(ierr);
+        Block& ShrinkEnl = grow_left ? Rnew : Lnew;
+        Block& GrowEnl = grow_left ? Lnew : Rnew;
+        const std::vector<int32_t> shrink_sizes = ShrinkEnl.Magnetization.Sizes32(), grow_sizes = GrowEnl.Magnetization.Sizes32();
+        if (shrink_sizes != S->old_sizes) return 0;
+        if (parts_grow.size() != grow_sizes.size()) return 0;
+        /* (new growing-block sector a, site state) -> (enlarged sector, offset) */
+        std::map<std::pair<int32_t, int32_t>, std::pair<int32_t, int32_t>> where;
+        for (size_t I = 0; I < parts_grow.size(); ++I)
+            for (const EnlPart& e : parts_grow[I]) where[{e.old_sector, e.site_sector}] = {(int32_t)I, e.off};
+        const std::vector<std::vector<EnlPart>>& parts_shrink_prev = grow_left ? prev.partsR : prev.partsL;
+        const int32_t nG = (int32_t)G->kept.size(), nS = (int32_t)S->kept.size();
+        /* sizes of the growing block's sectors must be G's kept counts, of the shrinking prev block S's kept counts */
+        {
+            const std::vector<int32_t> gs = (grow_left ? SysBlock : EnvBlock).Magnetization.Sizes32();
+            if ((int32_t)gs.size() != nG) return 0;
+            for (int32_t a = 0; a < nG; ++a) if (gs[(size_t)a] != G->kept[(size_t)a]) return 0;
+        }
+        std::vector<std::vector<int32_t>> G_of_old(G->old_sizes.size());
+        for (int32_t a = 0; a < nG; ++a) G_of_old[(size_t)G->old_sector[(size_t)a]].push_back(a);
+
+        /* stage 1: Phi = R_G applied on the growing side of every previous KronBlock */
+        struct PhiBlock { int32_t a, other, rows, cols; int64_t off; };
+        std::vector<PhiBlock> phis;
+        std::vector<dmrgx_gemm_task> t1;
+        int64_t phi_total = 0;
+        std::vector<std::shared_ptr<dmrgx_host::DevBuffer>> GT((size_t)nG), ST((size_t)nS);   /* transposed copies, made on demand */
+        const double* x = prev.psi->buf->dev_ro();
+        for (const auto& kb : prev.kb) {
+            const int32_t IL = (int32_t)kb[0], IR = (int32_t)kb[1], nL = (int32_t)kb[2], nR = (int32_t)kb[3];
+            const int32_t grow_sector = grow_left ? IL : IR;
+            if (grow_sector >= (int32_t)G_of_old.size()) return 0;
+            for (int32_t a : G_of_old[(size_t)grow_sector]) {
+                const int32_t ka = G->kept[(size_t)a];
+                if (ka == 0) continue;
+                PhiBlock pb;
+                pb.a = a; pb.other = grow_left ? IR : IL; pb.off = phi_total;
+                if (grow_left) { pb.rows = ka; pb.cols = nR; if (G->old_sizes[(size_t)IL] != nL) return 0; }
+                else           { pb.rows = nL; pb.cols = ka; if (G->old_sizes[(size_t)IR] != nR) return 0; }
+                phi_total += (int64_t)pb.rows * pb.cols;
+                phis.push_back(pb);
+                (void)kb;
+            }
+        }
+        if (phis.empty()) return 0;
+        auto phi = std::make_shared<dmrgx_host::DevBuffer>((size_t)phi_total, dmrgx_host::DevBuffer::device_only_t{});
+        double* ph = phi->dev_uninitialised();
+        {
+            size_t ip = 0;
+            for (const auto& kb : prev.kb) {
+                const int32_t IL = (int32_t)kb[0], IR = (int32_t)kb[1], nL = (int32_t)kb[2], nR = (int32_t)kb[3];
+                for (int32_t a : G_of_old[(size_t)(grow_left ? IL : IR)]) {
+                    const int32_t ka = G->kept[(size_t)a];
+                    if (ka == 0) continue;
+                    const PhiBlock& pb = phis[ip++];
+                    if (grow_left)          /* (ka x nL) . (nL x nR) */
+                        t1.push_back(dmrgx_gemm_task{ka, nR, nL, 0, G->rt[(size_t)a]->dev_ro(), nL, x + kb[4], nR, ph + pb.off, nR});
+                    else {                  /* (nL x nR) . (nR x ka) */
+                        if (!GT[(size_t)a]) GT[(size_t)a] = TransposedCopy(G->rt[(size_t)a], ka, nR);
+                        t1.push_back(dmrgx_gemm_task{nL, ka, nR, 0, x + kb[4], nR, GT[(size_t)a]->dev_ro(), ka, ph + pb.off, ka});
+                    }
+                }
+            }
+        }
+        /* stage 2: expand the shrinking side through S and place the pieces in the new KronBlocks */
+        std::vector<dmrgx_gemm_task> t2;
+        double* y = guess->buf->dev_uninitialised();
+        for (const PhiBlock& pb : phis) {
+            if (pb.other >= (int32_t)parts_shrink_prev.size()) return 0;
+            for (const EnlPart& e : parts_shrink_prev[(size_t)pb.other]) {      /* (sector j of the previous shrinking block, site state) */
+                const int32_t j = e.old_sector;
+                if (j >= nS || S->kept[(size_t)j] != e.size) return 0;
+                if (e.size == 0) continue;
+                const int32_t Jnew = S->old_sector[(size_t)j], nJ = S->old_sizes[(size_t)Jnew];
+                auto it = where.find({pb.a, e.site_sector});
+                if (it == where.end()) continue;                                /* that (sector, site state) does not exist in the new block */
+                const int32_t Inew = it->second.first, goff = it->second.second;
+                const PetscInt knew = grow_left ? KronBlocks.Map(Inew, Jnew) : KronBlocks.Map(Jnew, Inew);
+                if (knew < 0) continue;
+                const int64_t base = KronBlocks.Offsets(knew);
+                if (grow_left) {            /* rows = growing part (ka), cols = all of new env sector Jnew */
+                    const int32_t ldn = nJ;
+                    t2.push_back(dmrgx_gemm_task{pb.rows, nJ, e.size, 0, ph + pb.off + e.off, pb.cols, S->rt[(size_t)j]->dev_ro(), nJ,
+                                                 y + base + (int64_t)goff * ldn, ldn});
+                } else {                    /* rows = all of new sys sector Jnew, cols = growing part (ka) at column offset goff */
+                    if (!ST[(size_t)j]) ST[(size_t)j] = TransposedCopy(S->rt[(size_t)j], e.size, nJ);
+                    const int32_t ldn = grow_sizes[(size_t)Inew];
+                    t2.push_back(dmrgx_gemm_task{nJ, pb.cols, e.size, 0, ST[(size_t)j]->dev_ro(), e.size, ph + pb.off + (int64_t)e.off * pb.cols, pb.cols,
+                                                 y + base + goff, ldn});
+                }
+            }
+        }
+        if (t2.empty()) return 0;
+        if (dmrgx_memset_zero(y, (size_t)guess->n * sizeof(double), nullptr)) SETERRQ1(mpi_comm, 1, "%s", dmrgx_last_error());
+        if (dmrgx_dgemm_batch((int32_t)t1.size(), t1.data(), nullptr)) SETERRQ1(mpi_comm, 1, "wavefunction transformation: %s", dmrgx_last_error());
+        if (dmrgx_dgemm_batch((int32_t)t2.size(), t2.data(), nullptr)) SETERRQ1(mpi_comm, 1, "wavefunction transformation: %s", dmrgx_last_error());
+        used = true;
         return 0;
     }
 
@@ -804,6 +994,19 @@ private:
     std::string restart_dir;
     PetscInt restart_sys_ninit = 0, restart_num_sites = 0, restart_msweep_idx = -1;
     PetscInt rows_written = 0;          /**< steps recorded by THIS run (a restarted run starts at GlobIdx > 0) */
+
+    /* ---- start vector of the eigensolve from the previous step's ground state (White's wavefunction transformation) ---- */
+    struct PrevStep {
+        bool valid = false;
+        PetscInt insys = -1, inenv = -1, outsys = -1, outenv = -1;
+        Vec psi;
+        std::vector<std::array<PetscInt, 5>> kb;                   /**< (IL, IR, nL, nR, offset) of every KronBlock */
+        std::vector<std::vector<EnlPart>> partsL, partsR;            /**< decomposition of the enlarged sectors */
+        std::shared_ptr<dmrgx_host::BasisRotation> rotL, rotR;     /**< this step's truncations */
+    } prev;
+    std::vector<std::shared_ptr<dmrgx_host::BasisRotation>> block_rot;   /**< rotation that created sys_blocks[i] from sys_blocks[i-1] (x) site */
+    PetscBool use_guess = PETSC_TRUE;
+    PetscInt guesses_used = 0;
 };
 
 #endif
