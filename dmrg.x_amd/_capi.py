@@ -104,6 +104,8 @@ SIGNATURES = {
     "dmrgx_rdm_create": (C.c_int32, [C.POINTER(Sectors), C.POINTER(Sectors), C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                      C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
     "dmrgx_rdm_eigenvalues": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_double)]),
+    "dmrgx_rdm_create_warm": (C.c_int32, [C.POINTER(Sectors), C.POINTER(Sectors), C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                               C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
     "dmrgx_rdm_eigenvectors": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
     "dmrgx_rdm_info": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32)]),
     "dmrgx_rdm_destroy": (C.c_int32, [C.c_void_p]),

@@ -336,6 +336,13 @@ extern "C" dmrgx_status dmrgx_rdm_create(const dmrgx_sectors* left, const dmrgx_
                                          const int32_t* block_il, const int32_t* block_ir, const double* psi_dev,
                                          void* stream, dmrgx_rdm** out)
 {
+    return dmrgx_rdm_create_warm(left, right, nblocks, block_il, block_ir, psi_dev, nullptr, stream, out);
+}
+
+extern "C" dmrgx_status dmrgx_rdm_create_warm(const dmrgx_sectors* left, const dmrgx_sectors* right, int32_t nblocks,
+                                              const int32_t* block_il, const int32_t* block_ir, const double* psi_dev,
+                                              const double* const* v0_rows, void* stream, dmrgx_rdm** out)
+{
     hipStream_t st = (hipStream_t)stream;
     if (!left || !right || !block_il || !block_ir || !psi_dev || !out || nblocks <= 0) DMRGX_FAIL(DMRGX_ERR_ARG, "rdm_create: bad argument");
     *out = nullptr;
@@ -385,6 +392,9 @@ extern "C" dmrgx_status dmrgx_rdm_create(const dmrgx_sectors* left, const dmrgx_
     const int64_t diag_base = total; total += dtot;
     const int64_t rq_base = total; total += dtot;            // Rayleigh quotients, same indexing as the diagonals
     const int64_t w_base = total; total += 2 * N;            // W = Psi^T V_L (n_R x n_L) and Psi V_R (n_L x n_R) per block
+    // warm start: per matrix with a previous eigenbasis E (rows), W = E A and E^T (n x n each)
+    std::vector<int64_t> warm_w(nm, -1), warm_et(nm, -1);
+    if (v0_rows) for (int mi = 0; mi < nm; ++mi) if (v0_rows[mi]) { const int64_t nn = (int64_t)P->mats[mi].n * P->mats[mi].n; warm_w[mi] = total; total += nn; warm_et[mi] = total; total += nn; }
     DMRGX_CHK(P->buf.alloc((size_t)total * sizeof(double)));
     double* buf = P->buf.as<double>();
     DevBuf d_pairs, d_tiles, d_doff, d_pstart;
@@ -433,6 +443,54 @@ extern "C" dmrgx_status dmrgx_rdm_create(const dmrgx_sectors* left, const dmrgx_
         DMRGX_CHK(ggemm_launch(db.as<GTile>(), dg.as<GGroup>(), dp.as<GProd>(), (int32_t)gb.size(), st, 1));
         DMRGX_CHK(ggemm_launch(dt.as<GTile>(), dg.as<GGroup>(), dp.as<GProd>(), (int32_t)gt.size(), st, 0));
         DMRGX_HIP(hipStreamSynchronize(st));
+    }
+
+    // ---- warm start: A <- E A E^T, V <- E^T for matrices whose previous eigenbasis E (eigenvectors as rows) is supplied.
+    //      In a settled DMRG sweep the basis of the previous visit nearly diagonalises the new density matrix (measured:
+    //      off^2/total^2 ~ 1e-5 instead of 0.5), which saves the first ~3 of ~10 Jacobi sweeps; the rest is the linearly
+    //      converging tail of near-degenerate small eigenvalues.  Any orthogonal E is valid.
+    if (v0_rows) {
+        std::vector<TrTile> tt;
+        std::vector<GProd> p1, p2;
+        std::vector<GGroup> g1, g2;
+        std::vector<GTile> t1, t1b, t2, t2b;
+        for (int mi = 0; mi < nm; ++mi) {
+            if (!v0_rows[mi]) continue;
+            const MatDesc& m = P->mats[mi];
+            const int32_t n = m.n;
+            if (n == 0) continue;
+            const double* E = v0_rows[mi];
+            double* Wt = buf + warm_w[mi];
+            double* ET = buf + warm_et[mi];
+            for (int ti = 0; ti < (n + 31) / 32; ++ti) for (int tj = 0; tj < (n + 31) / 32; ++tj)
+                tt.push_back(TrTile{(int64_t)(E - buf), warm_et[mi], n, n, ti, tj});     // source addressed relative to the arena base
+            p1.push_back(GProd{E, buf + m.a_off, n, m.npad, n, GPROD_GEMM, 1.0});          // W = E A
+            g1.push_back(GGroup{Wt, n, n, n, (int32_t)p1.size() - 1, (int32_t)p1.size(), 0, 0});
+            ggemm_append_tiles_mixed(t1b, t1, (int32_t)g1.size() - 1, n, n, (n + GG_BK - 1) / GG_BK);
+            p2.push_back(GProd{Wt, ET, n, n, n, GPROD_GEMM, 1.0});                          // A = W E^T
+            g2.push_back(GGroup{buf + m.a_off, m.npad, n, n, (int32_t)p2.size() - 1, (int32_t)p2.size(), 0, 0});
+            ggemm_append_tiles_mixed(t2b, t2, (int32_t)g2.size() - 1, n, n, (n + GG_BK - 1) / GG_BK);
+        }
+        if (!tt.empty()) {
+            DevBuf d_tt, dp1, dg1, dt1, db1, dp2, dg2, dt2, db2;
+            DMRGX_CHK(upload(d_tt, tt, st));
+            hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)tt.size()), dim3(256), 0, st, d_tt.as<TrTile>(), (const double*)buf, buf);
+            DMRGX_HIP(hipGetLastError());
+            ggemm_schedule(t1); ggemm_schedule(t1b, 2); ggemm_schedule(t2); ggemm_schedule(t2b, 2);
+            DMRGX_CHK(upload(dp1, p1, st)); DMRGX_CHK(upload(dg1, g1, st)); DMRGX_CHK(upload(dt1, t1, st)); DMRGX_CHK(upload(db1, t1b, st));
+            DMRGX_CHK(upload(dp2, p2, st)); DMRGX_CHK(upload(dg2, g2, st)); DMRGX_CHK(upload(dt2, t2, st)); DMRGX_CHK(upload(db2, t2b, st));
+            DMRGX_CHK(ggemm_launch(db1.as<GTile>(), dg1.as<GGroup>(), dp1.as<GProd>(), (int32_t)t1b.size(), st, 1));
+            DMRGX_CHK(ggemm_launch(dt1.as<GTile>(), dg1.as<GGroup>(), dp1.as<GProd>(), (int32_t)t1.size(), st, 0));
+            DMRGX_CHK(ggemm_launch(db2.as<GTile>(), dg2.as<GGroup>(), dp2.as<GProd>(), (int32_t)t2b.size(), st, 1));
+            DMRGX_CHK(ggemm_launch(dt2.as<GTile>(), dg2.as<GGroup>(), dp2.as<GProd>(), (int32_t)t2.size(), st, 0));
+            for (int mi = 0; mi < nm; ++mi) {
+                if (!v0_rows[mi] || P->mats[mi].n == 0) continue;
+                const MatDesc& m = P->mats[mi];
+                DMRGX_HIP(hipMemcpy2DAsync(buf + m.v_off, (size_t)m.npad * sizeof(double), buf + warm_et[mi], (size_t)m.n * sizeof(double),
+                                           (size_t)m.n * sizeof(double), (size_t)m.n, hipMemcpyDeviceToDevice, st));
+            }
+            DMRGX_HIP(hipStreamSynchronize(st));      // tables are freed at scope exit
+        }
     }
 
     // ---- batched block Jacobi ------------------------------------------------------------------------------------

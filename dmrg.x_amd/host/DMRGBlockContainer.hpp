@@ -114,6 +114,7 @@ public:
         if (no_symm) SETERRQ(mpi_comm, PETSC_ERR_SUP, "Unsupported option: no_symm.");
         ierr = PetscOptionsGetBool(NULL, NULL, "-debug_check_symmetry", &debug_symm, NULL); CHKERRQ(ierr);
         ierr = PetscOptionsGetBool(NULL, NULL, "-wavefunction_guess", &use_guess, NULL); CHKERRQ(ierr);
+        ierr = PetscOptionsGetBool(NULL, NULL, "-rdm_warm_start", &use_rdm_warm, NULL); CHKERRQ(ierr);
 
         PetscBool opt = PETSC_FALSE;
         ierr = PetscOptionsGetString(NULL, NULL, "-scratch_dir", path, PETSC_MAX_PATH_LEN, &opt); CHKERRQ(ierr);
@@ -421,7 +422,7 @@ public:
         timings.tDiag = tdiag - tkron;
 
         BasisTransformation BT_L, BT_R;
-        ierr = GetTruncation(KronBlocks, gsv_r, MStates, BT_L, BT_R); CHKERRQ(ierr);
+        ierr = GetTruncation(KronBlocks, gsv_r, MStates, BT_L, BT_R, BlockIndex(SysBlockOut), BlockIndex(EnvBlockOut)); CHKERRQ(ierr);
         ierr = CalculateCorrelations_BlockDiag(KronBlocks, gsv_r, do_measurements); CHKERRQ(ierr);
         if (use_guess) {   /* what the next step needs to carry this ground state over */
             prev.valid = false;
@@ -841,7 +842,8 @@ public:
     /** Reduced density matrices of both sides, their full spectra (device), the global cut to MStates states and the
         rotation matrices.  The ordering rules are the reference's: concatenate the spectra KronBlock by KronBlock,
         stable-sort by decreasing eigenvalue, keep the first min(MStates, #), stable-sort the survivors by sector. */
-    PetscErrorCode GetTruncation(const KronBlocks_t& KronBlocks, const Vec& gsv_r, const PetscInt& MStates, BasisTransformation& BT_L, BasisTransformation& BT_R)
+    PetscErrorCode GetTruncation(const KronBlocks_t& KronBlocks, const Vec& gsv_r, const PetscInt& MStates, BasisTransformation& BT_L, BasisTransformation& BT_R,
+                                 const PetscInt keyL = -1, const PetscInt keyR = -1)
     {
         PetscErrorCode ierr;
         if (gsv_r->n != KronBlocks.NumStates()) SETERRQ2(PETSC_COMM_SELF, 1, "Incorrect vector length. Expected %lld. Got %lld.", LLD(KronBlocks.NumStates()), LLD(gsv_r->n));
@@ -857,9 +859,36 @@ public:
         dmrgx_rdm* rdm = nullptr;
         PetscLogDouble tr0, tr1;
         PetscTime(&tr0);
-        if (dmrgx_rdm_create(&sl, &sr, (int32_t)nb, bil.data(), bir.data(), gsv_r->buf->dev_ro(), nullptr, &rdm)) SETERRQ1(mpi_comm, 1, "dmrgx_rdm_create: %s", dmrgx_last_error());
+        /* warm start of the block-Jacobi eigensolver: the eigenbasis found at the previous visit of the block being created
+           (same index, same sector sizes) almost diagonalises the new density matrix once the sweeps settle */
+        const PetscInt keys[2] = {keyL, keyR};
+        std::vector<const double*> v0((size_t)(2 * nb), nullptr);
+        PetscInt nwarm = 0;
+        if (use_rdm_warm) for (int side = 0; side < 2; ++side) {
+            auto it = rdm_basis.find({keys[side], (keyR == keyL) ? 0 : side});      /* centre step: both sides are the same block */
+            if (keys[side] < 0 || it == rdm_basis.end() || it->second.sizes != (side == 0 ? ls : rs)) continue;
+            for (PetscInt k = 0; k < nb; ++k) {
+                auto e = it->second.E.find(side == 0 ? bil[k] : bir[k]);
+                if (e != it->second.E.end() && e->second) { v0[(size_t)(2 * k + side)] = e->second->dev_ro(); ++nwarm; }
+            }
+        }
+        if (dmrgx_rdm_create_warm(&sl, &sr, (int32_t)nb, bil.data(), bir.data(), gsv_r->buf->dev_ro(), nwarm ? v0.data() : nullptr, nullptr, &rdm))
+            SETERRQ1(mpi_comm, 1, "dmrgx_rdm_create: %s", dmrgx_last_error());
+        if (use_rdm_warm) for (int side = 0; side < 2; ++side) {      /* remember this visit's eigenbases (all eigenvectors, as rows) */
+            if (keys[side] < 0 || (side == 1 && keyR == keyL)) continue;
+            WarmBasis& wb = rdm_basis[{keys[side], side}];
+            wb.sizes = side == 0 ? ls : rs;
+            wb.E.clear();
+            for (PetscInt k = 0; k < nb; ++k) {
+                const int32_t sec = side == 0 ? bil[k] : bir[k], n = (side == 0 ? ls : rs)[(size_t)sec];
+                if (n == 0) continue;
+                auto buf = std::make_shared<dmrgx_host::DevBuffer>((size_t)n * n, dmrgx_host::DevBuffer::device_only_t{});
+                if (dmrgx_rdm_eigenvectors(rdm, side, (int32_t)k, n, buf->dev_uninitialised(), n, nullptr)) { dmrgx_rdm_destroy(rdm); SETERRQ1(mpi_comm, 1, "dmrgx_rdm_eigenvectors: %s", dmrgx_last_error()); }
+                wb.E[sec] = buf;
+            }
+        }
         PetscTime(&tr1);
-        if (!mpi_rank && verbose) { int32_t nsw = 0; dmrgx_rdm_info(rdm, &nsw); printf("  RDM: %lld KronBlocks, block-Jacobi sweeps %d, create %.6f s\n", LLD(nb), nsw, tr1 - tr0); }
+        if (!mpi_rank && verbose) { int32_t nsw = 0; dmrgx_rdm_info(rdm, &nsw); printf("  RDM: %lld KronBlocks, %lld warm-started, block-Jacobi sweeps %d, create %.6f s\n", LLD(nb), LLD(nwarm), nsw, tr1 - tr0); }
         BasisTransformation* BT[2] = {&BT_L, &BT_R};
         for (int side = 0; side < 2; ++side) {
             std::vector<Eigen_t> eigen;
@@ -886,7 +915,7 @@ public:
             for (const auto& kv : per) {
                 const PetscInt blk = kv.first, k = kv.second.first, cnt = kv.second.second, n = M[side]->Sizes(blk);
                 rot->old_sector.push_back((int32_t)blk); rot->kept.push_back((int32_t)cnt);
-                auto buf = std::make_shared<dmrgx_host::DevBuffer>((size_t)cnt * n);
+                auto buf = std::make_shared<dmrgx_host::DevBuffer>((size_t)cnt * n, dmrgx_host::DevBuffer::device_only_t{});
                 if (dmrgx_rdm_eigenvectors(rdm, side, (int32_t)k, (int32_t)cnt, buf->dev_uninitialised(), n, nullptr)) { dmrgx_rdm_destroy(rdm); SETERRQ1(mpi_comm, 1, "dmrgx_rdm_eigenvectors: %s", dmrgx_last_error()); }
                 rot->rt.push_back(buf);
                 qn_list.push_back(M[side]->List(blk)); qn_size.push_back(cnt);
@@ -1007,6 +1036,10 @@ private:
     std::vector<std::shared_ptr<dmrgx_host::BasisRotation>> block_rot;   /**< rotation that created sys_blocks[i] from sys_blocks[i-1] (x) site */
     PetscBool use_guess = PETSC_TRUE;
     PetscInt guesses_used = 0;
+    /* eigenbases of the density matrices at the previous visit of every block: warm start of the Jacobi eigensolver */
+    struct WarmBasis { std::vector<int32_t> sizes; std::map<int32_t, std::shared_ptr<dmrgx_host::DevBuffer>> E; };
+    std::map<std::pair<PetscInt, int>, WarmBasis> rdm_basis;
+    PetscBool use_rdm_warm = PETSC_TRUE;
 };
 
 #endif

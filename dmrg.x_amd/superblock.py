@@ -174,7 +174,8 @@ class ReducedDensityMatrices:
     """Device RDM blocks + spectra of a superblock state (GetTruncation's rank-0 loop,
     include/DMRGBlockContainer.hpp:1715-1775).  psi: device tensor in the reference's vector layout."""
 
-    def __init__(self, left_sizes, right_sizes, blocks, psi):
+    def __init__(self, left_sizes, right_sizes, blocks, psi, warm=None):
+        """warm: optional {(side, k): (n x n) device tensor of eigenvectors as rows from a previous solve} (warm start)."""
         L = _capi.lib()
         self.left_sizes, self.right_sizes, self.blocks = list(left_sizes), list(right_sizes), list(blocks)
         ls, rs = _i32(left_sizes), _i32(right_sizes)
@@ -182,7 +183,15 @@ class ReducedDensityMatrices:
         bil, bir = _i32([b[0] for b in blocks]), _i32([b[1] for b in blocks])
         self._handle = C.c_void_p()
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        _capi.check(L.dmrgx_rdm_create(C.byref(sl), C.byref(sr), len(blocks), bil, bir, C.c_void_p(psi.data_ptr()), st, C.byref(self._handle)))
+        if warm:
+            ptrs = (C.c_void_p * (2 * len(blocks)))()
+            for (side, k), t in warm.items():
+                assert t.is_contiguous() and t.dtype == torch.float64 and t.shape == (self.size(side, k),) * 2
+                ptrs[2 * k + side] = t.data_ptr()
+            _capi.check(L.dmrgx_rdm_create_warm(C.byref(sl), C.byref(sr), len(blocks), bil, bir, C.c_void_p(psi.data_ptr()),
+                                                C.cast(ptrs, C.c_void_p), st, C.byref(self._handle)))
+        else:
+            _capi.check(L.dmrgx_rdm_create(C.byref(sl), C.byref(sr), len(blocks), bil, bir, C.c_void_p(psi.data_ptr()), st, C.byref(self._handle)))
         n = C.c_int32(0)
         _capi.check(L.dmrgx_rdm_info(self._handle, C.byref(n)))
         self.sweeps = n.value

@@ -202,6 +202,13 @@ typedef struct dmrgx_rdm dmrgx_rdm;
 dmrgx_status dmrgx_rdm_create(const dmrgx_sectors* left, const dmrgx_sectors* right, int32_t nblocks,
                               const int32_t* block_il, const int32_t* block_ir, const double* psi_dev,
                               void* stream, dmrgx_rdm** out);
+/* The same with a warm start: v0_rows[2*k + side] is NULL or a device pointer to an n x n row-major ORTHOGONAL matrix whose
+ * rows approximately diagonalise that block's density matrix (the rows written by dmrgx_rdm_eigenvectors(count = n) at the
+ * previous visit of the same block).  The matrix is transformed into that basis before the Jacobi iteration; results do
+ * not depend on v0_rows, only the number of Jacobi sweeps does. */
+dmrgx_status dmrgx_rdm_create_warm(const dmrgx_sectors* left, const dmrgx_sectors* right, int32_t nblocks,
+                                   const int32_t* block_il, const int32_t* block_ir, const double* psi_dev,
+                                   const double* const* v0_rows, void* stream, dmrgx_rdm** out);
 /* host_out[0..n) = eigenvalues of block k's matrix, descending (n = sector size on that side). */
 dmrgx_status dmrgx_rdm_eigenvalues(const dmrgx_rdm* rdm, int32_t side, int32_t k, double* host_out);
 /* dst_dev[r*ld + i], r < count: the eigenvector of the r-th largest eigenvalue as a ROW (a row of RotMatT,

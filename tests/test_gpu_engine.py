@@ -125,8 +125,9 @@ def test_checkpoint_restart_continues_the_run(tmp_path):
     only on the restored global step index).  The checkpoint has the reference's directory layout."""
     # -wavefunction_guess 0: with the reference's random start vectors every step depends only on the restored blocks and the
     # global step index, so the continuation is bit-identical (a transformed start vector would need the previous step's
-    # ground state, which a checkpoint does not carry: the first step after a restart then starts from a random vector)
-    model = ["-Lx", 6, "-Ly", 2, "-J1", 1, "-Jz1", 1, "-J2", 0.5, "-Jz2", 0.5, "-mwarmup", 24, "-H_eps_tol", 1e-12, "-wavefunction_guess", 0]
+    # ground state, which a checkpoint does not carry: the first step after a restart then starts from a random vector;
+    # likewise -rdm_warm_start 0: the eigenbases of the previous visit are not part of a checkpoint)
+    model = ["-Lx", 6, "-Ly", 2, "-J1", 1, "-Jz1", 1, "-J2", 0.5, "-Jz2", 0.5, "-mwarmup", 24, "-H_eps_tol", 1e-12, "-wavefunction_guess", 0, "-rdm_warm_start", 0]
     (tmp_path / "a").mkdir(); (tmp_path / "b1").mkdir(); (tmp_path / "b2").mkdir()
     rows_a, run_a, _ = run_engine(tmp_path / "a", *model, "-nsweeps", 2)
     rows_b1, _, _ = run_engine(tmp_path / "b1", *model, "-nsweeps", 1, "-scratch_dir", str(tmp_path / "scratch1"))
@@ -140,7 +141,7 @@ def test_checkpoint_restart_continues_the_run(tmp_path):
     sweep = dict(ln.split() for ln in open(last / "Sweep.dat") if ln.strip())
     assert int(sweep["LoopIdx"]) == 1 and int(sweep["sys_ninit"]) == 6 and int(sweep["num_sites"]) == 12
     # restart: the model comes from Hamiltonian.dat (a deliberately wrong -Lx on the command line is overridden)
-    rows_b2, run_b2, _ = run_engine(tmp_path / "b2", "-Lx", 2, "-Ly", 2, "-mwarmup", 24, "-H_eps_tol", 1e-12, "-nsweeps", 1, "-wavefunction_guess", 0,
+    rows_b2, run_b2, _ = run_engine(tmp_path / "b2", "-Lx", 2, "-Ly", 2, "-mwarmup", 24, "-H_eps_tol", 1e-12, "-nsweeps", 1, "-wavefunction_guess", 0, "-rdm_warm_start", 0,
                                     "-restart_dir", str(sdir), "-scratch_dir", str(tmp_path / "scratch2"))
     n1 = len(rows_b1)
     assert rows_a[:n1] and [r["GSEnergy"] for r in rows_a[:n1]] == [r["GSEnergy"] for r in rows_b1]

@@ -457,3 +457,46 @@ def test_apply_degenerate_layouts_vs_dense_kron(mods):
     assert np.abs(yd.cpu().numpy() - Hsb @ x).max() <= 1e-13 * max(1.0, np.abs(Hsb @ x).max())
     for p in plans:
         p.destroy()
+
+
+def test_rdm_warm_start_same_results_fewer_sweeps(mods):
+    """dmrgx_rdm_create_warm: starting the block-Jacobi iteration in the eigenbasis of a nearby state (the previous visit of
+    the block in a DMRG sweep) gives the same spectra and eigenvectors -- checked against LAPACK -- in fewer sweeps; a
+    useless (random orthogonal) basis is still correct."""
+    sbm, wl, _ = mods
+    rng = np.random.default_rng(3)
+    lsz, rsz = [40, 130, 77, 5], [64, 33, 150, 9]
+    blocks = [(0, 3), (1, 2), (2, 1), (3, 0)]
+    N = sum(lsz[a] * rsz[b] for a, b in blocks)
+    # a state with a decaying Schmidt spectrum (like a DMRG ground state), and a small perturbation of it
+    parts = []
+    for a, b in blocks:
+        U, _ = np.linalg.qr(rng.standard_normal((lsz[a], lsz[a])))
+        V, _ = np.linalg.qr(rng.standard_normal((rsz[b], rsz[b])))
+        k = min(lsz[a], rsz[b])
+        s = np.exp(-0.35 * np.arange(k)) * rng.uniform(0.5, 1.0, k)
+        parts.append((U[:, :k] * s) @ V[:, :k].T)
+    psi0 = np.concatenate([p.ravel() for p in parts]); psi0 /= np.linalg.norm(psi0)
+    psi1 = psi0 + 1e-4 * rng.standard_normal(N) * np.abs(psi0).max(); psi1 /= np.linalg.norm(psi1)
+    cold0 = sbm.ReducedDensityMatrices(lsz, rsz, blocks, torch.from_numpy(psi0).cuda())
+    warm = {(side, k): cold0.eigenvectors(side, k, cold0.size(side, k)).contiguous() for k in range(len(blocks)) for side in (0, 1)}
+    d1 = torch.from_numpy(psi1).cuda()
+    cold1 = sbm.ReducedDensityMatrices(lsz, rsz, blocks, d1)
+    warm1 = sbm.ReducedDensityMatrices(lsz, rsz, blocks, d1, warm=warm)
+    junk = {key: torch.from_numpy(np.linalg.qr(rng.standard_normal(tuple(t.shape)))[0]).cuda().contiguous() for key, t in warm.items()}
+    junk1 = sbm.ReducedDensityMatrices(lsz, rsz, blocks, d1, warm=junk)
+    assert warm1.sweeps < cold1.sweeps - 2, (warm1.sweeps, cold1.sweeps)
+    off = 0
+    for k, (a, b) in enumerate(blocks):
+        Psi = psi1[off:off + lsz[a] * rsz[b]].reshape(lsz[a], rsz[b]); off += lsz[a] * rsz[b]
+        for side, rho in ((0, Psi @ Psi.T), (1, Psi.T @ Psi)):
+            w_ref = np.linalg.eigvalsh(rho)[::-1]
+            n = rho.shape[0]
+            for r in (warm1, junk1):
+                w = r.eigenvalues(side, k)
+                assert np.abs(w - w_ref).max() <= 3e-15 * n * np.abs(w_ref).max() + 1e-17
+                U = r.eigenvectors(side, k, n).cpu().numpy()
+                assert np.abs(U @ U.T - np.eye(n)).max() < 1e-13
+                assert np.abs(U @ rho @ U.T - np.diag(w)).max() < 1e-11 * np.linalg.norm(rho) + 1e-16
+    for r in (cold0, cold1, warm1, junk1):
+        r.destroy()
