@@ -113,12 +113,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         sys.exit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    # Rehearsal mode (tests only): DMRGX_BENCH_REHEARSAL=1 runs the N > 1 control flow with all ranks on cuda:0 and the
+    # collectives staged through gloo on the host -- RCCL needs one GPU per rank, the one-GPU test box has one.
+    rehearsal = os.environ.get("DMRGX_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from __graft_entry__ import load_package
     load_package()
@@ -129,7 +137,7 @@ def main():
     sb = synthetic_superblock(args.workload)
     plan = KronPlan(sb, device=f"cuda:{local_rank}", world_size=world, rank=rank)
     info = plan.info
-    hooks = collectives.torch_hooks(dist, rank, world) if world > 1 else {}
+    hooks = (collectives.host_staged_hooks(dist, rank, world) if rehearsal else collectives.torch_hooks(dist, rank, world)) if world > 1 else {}
 
     def barrier():
         torch.cuda.synchronize()
@@ -147,7 +155,7 @@ def main():
     plan.timing(False)
     assert stats.n_matvec == args.steps, (stats.n_matvec, args.steps)
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms4, napp = plan.timing_read()

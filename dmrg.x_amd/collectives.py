@@ -32,3 +32,26 @@ def torch_hooks(dist, rank, world):
         return 0
 
     return {"allgather": allgather, "allreduce": allreduce}
+
+
+def host_staged_hooks(dist, rank, world):
+    """The same two hooks with the payload staged through host memory (backend gloo): for rehearsing the N > 1 control
+    flow with several ranks on ONE GPU (tests); never used for measurements."""
+    device = torch.device("cuda", torch.cuda.current_device())
+
+    def allgather(user, full_ptr, seg_stride, stream):
+        full = _view(full_ptr, seg_stride * world, device)
+        mine = full[rank * seg_stride:(rank + 1) * seg_stride].cpu()
+        out = torch.empty(seg_stride * world, dtype=torch.float64)
+        dist.all_gather_into_tensor(out, mine)
+        full.copy_(out)
+        return 0
+
+    def allreduce(user, buf_ptr, count, stream):
+        v = _view(buf_ptr, count, device)
+        h = v.cpu()
+        dist.all_reduce(h)
+        v.copy_(h)
+        return 0
+
+    return {"allgather": allgather, "allreduce": allreduce}

@@ -197,3 +197,22 @@ def test_rccl_hooks_single_rank():
     p = subprocess.run([sys.executable, script], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     out = p.stdout.decode()
     assert p.returncode == 0 and "rccl hooks ok" in out, out[-3000:]
+
+
+def test_bench_multi_rank_control_flow_rehearsal():
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one process per rank), rehearsed with two ranks
+    on the one GPU and host-staged collectives: striped plans, hooks, barrier + max-over-ranks timing, one JSON line from
+    rank 0 with whole-job throughput."""
+    import sys
+    env = dict(os.environ, DMRGX_BENCH_REHEARSAL="1", PYTHONPATH=ROOT)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29651",
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "24", "--warmup", "8", "--workload", "cfg2"]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 24 and d["warmup"] == 8 and d["scaling"] == "strong" and d["unit"] == "MatMults/s"
+    assert d["value"] > 0 and abs(d["value"] * d["ms_per_step"] / 1e3 - 1.0) < 1e-9
+    assert d["cpu_baseline"] is None and "sweep" not in d and d["roofline"]["achieved"] > 0
+    assert "2 GPU" in d["config"]["parallelism"]
