@@ -19,16 +19,24 @@ def _view(ptr, n, device):
 
 def torch_hooks(dist, rank, world):
     device = torch.device("cuda", torch.cuda.current_device())
+    views = {}          # (pointer, length) -> tensor view: the eigensolver calls back with the same few buffers every step
+
+    def view(ptr, n):
+        key = (int(ptr), int(n))
+        t = views.get(key)
+        if t is None:
+            t = views[key] = _view(ptr, n, device)
+        return t
 
     def allgather(user, full_ptr, seg_stride, stream):
-        full = _view(full_ptr, seg_stride * world, device)
+        full = view(full_ptr, seg_stride * world)
         # out-of-place send buffer: a copy of this rank's segment (a few MB over HBM) instead of relying on aliasing rules
         # of the in-place form
         dist.all_gather_into_tensor(full, full[rank * seg_stride:(rank + 1) * seg_stride].clone())
         return 0
 
     def allreduce(user, buf_ptr, count, stream):
-        dist.all_reduce(_view(buf_ptr, count, device))
+        dist.all_reduce(view(buf_ptr, count))
         return 0
 
     return {"allgather": allgather, "allreduce": allreduce}
