@@ -53,14 +53,20 @@ def oracle_shell_from_superblock(sb, target=0.0):
 
 
 # ---- independent exact diagonalisation of the lattice model (correlator known answers) -------------------------------
-def lattice_ground_state(ham):
+def lattice_ground_state(ham, spin="1/2"):
     """Dense ED of the whole lattice in the site basis (site 0 = most significant factor), from the model's own term
-    list.  Returns (E0, psi, site_op) where site_op(op, i) is the 2^N x 2^N matrix of a single-site operator."""
+    list.  Returns (E0, psi, site_op) where site_op(op, i) is the d^N x d^N matrix of a single-site operator
+    (single-site matrices of src/DMRGBlock.cpp:1131-1215 for spin 1/2 and spin 1)."""
     import scipy.sparse as sp
     from oracle.qn import OpSm, OpSz, OpSp
     N = ham.NumSites()
-    sz = sp.csr_matrix(np.array([[0.5, 0.0], [0.0, -0.5]]))
-    spl = sp.csr_matrix(np.array([[0.0, 1.0], [0.0, 0.0]]))
+    if spin == "1":
+        sz = sp.csr_matrix(np.diag([1.0, 0.0, -1.0]))
+        spl = sp.csr_matrix(np.sqrt(2.0) * np.array([[0.0, 1.0, 0.0], [0.0, 0.0, 1.0], [0.0, 0.0, 0.0]]))
+    else:
+        sz = sp.csr_matrix(np.array([[0.5, 0.0], [0.0, -0.5]]))
+        spl = sp.csr_matrix(np.array([[0.0, 1.0], [0.0, 0.0]]))
+    d = sz.shape[0]
     single = {OpSz: sz, OpSp: spl, OpSm: spl.T.tocsr()}
     cache = {}
 
@@ -68,11 +74,11 @@ def lattice_ground_state(ham):
         if (op, i) not in cache:
             m = sp.identity(1, format="csr")
             for s in range(N):
-                m = sp.kron(m, single[op] if s == i else sp.identity(2, format="csr"), format="csr")
+                m = sp.kron(m, single[op] if s == i else sp.identity(d, format="csr"), format="csr")
             cache[(op, i)] = m
         return cache[(op, i)]
 
-    H = sp.csr_matrix((2 ** N, 2 ** N))
+    H = sp.csr_matrix((d ** N, d ** N))
     for t in ham.H(N):
         H = H + t.a * (site_op(t.Iop, t.Isite) @ site_op(t.Jop, t.Jsite))
     w, v = np.linalg.eigh(H.toarray())

@@ -173,6 +173,21 @@ def test_transformed_start_vector_saves_matmults_not_accuracy(tmp_path):
     assert run_g["LastSweepMatMults"] * 2 < run_r["LastSweepMatMults"], (run_g["LastSweepMatMults"], run_r["LastSweepMatMults"])
 
 
+def test_spin_one_chain_matches_exact_diagonalisation(tmp_path):
+    """-spin 1 (three states per site, Sz = diag(1,0,-1), S+ = sqrt(2)(|0><1| + |1><2|): src/DMRGBlock.cpp:1141-1156,1200-1215)
+    on a 6-site Heisenberg chain, m large enough to be exact: energy and correlators against dense ED of the 3^6 lattice."""
+    rows, run, _ = run_engine(tmp_path, "-spin", 1, "-Lx", 6, "-Ly", 1, "-heisenberg", 1, "-mwarmup", 100, "-nsweeps", 1, "-H_eps_tol", 1e-13)
+    ham = J1J2XXZModel_SquareLattice(Lx=6, Ly=1, heisenberg=1.0)
+    e0, psi, site_op = lattice_ground_state(ham, spin="1")
+    assert abs(run["GSEnergy"] - e0) <= 1e-10 * abs(e0), (run["GSEnergy"], e0)
+    corr = json.load(open(str(tmp_path) + "/Correlations.json"))
+    for c, v in zip(corr["info"], corr["values"][-1]):
+        P = None
+        for (op, i) in parse_desc2(c["desc2"]):
+            P = site_op(op, i) if P is None else P @ site_op(op, i)
+        assert abs(v - float(psi @ (P @ psi))) <= 1e-9, c["name"]
+
+
 def test_driver_fails_loudly_on_bad_options(tmp_path):
     out = subprocess.run([EXE, "-Lx", "3", "-Ly", "1", "-mwarmup", "8", "-data_dir", str(tmp_path) + "/"], capture_output=True, text=True, timeout=60)
     assert out.returncode != 0 and "must be even" in out.stderr
