@@ -173,6 +173,17 @@ def test_transformed_start_vector_saves_matmults_not_accuracy(tmp_path):
     assert run_g["LastSweepMatMults"] * 2 < run_r["LastSweepMatMults"], (run_g["LastSweepMatMults"], run_r["LastSweepMatMults"])
 
 
+@pytest.mark.parametrize("flag,kw", [("-BCopen", dict(BCopen=True)), ("-BCperiodic", dict(BCperiodic=True))])
+def test_boundary_condition_options_match_exact_diagonalisation(tmp_path, flag, kw):
+    """-BCopen / -BCperiodic (src/Hamiltonians.cpp:28-45; the default is the cylinder): 4x2 J1-J2 lattice with all four
+    couplings, exact at m = 32, against dense ED built from the same option set."""
+    rows, run, _ = run_engine(tmp_path, "-Lx", 4, "-Ly", 2, "-J1", 1, "-Jz1", 0.8, "-J2", 0.4, "-Jz2", 0.3, flag, 1,
+                              "-mwarmup", 32, "-nsweeps", 1, "-H_eps_tol", 1e-13)
+    ham = J1J2XXZModel_SquareLattice(Lx=4, Ly=2, J1=1, Jz1=0.8, J2=0.4, Jz2=0.3, **kw)
+    e0, _, _ = lattice_ground_state(ham)
+    assert abs(run["GSEnergy"] - e0) <= 1e-10 * abs(e0), (run["GSEnergy"], e0)
+
+
 def test_spin_one_chain_matches_exact_diagonalisation(tmp_path):
     """-spin 1 (three states per site, Sz = diag(1,0,-1), S+ = sqrt(2)(|0><1| + |1><2|): src/DMRGBlock.cpp:1141-1156,1200-1215)
     on a 6-site Heisenberg chain, m large enough to be exact: energy and correlators against dense ED of the 3^6 lattice."""
