@@ -51,6 +51,19 @@ int main()
             Mat m = (op == "Sz") ? blocks[name].Sz(site) : blocks[name].Sp(site);
             ierr = m->set(row, col, val);
             printf("rc %d\n", ierr);
+        } else if (cmd == "copy") {              /* shallow copy: the new block shares the operator handles */
+            std::string a, b; is >> a >> b;
+            blocks[b] = blocks[a];
+            printf("rc 0\n");
+        } else if (cmd == "destroy") {
+            std::string name; is >> name;
+            ierr = blocks[name].Destroy();
+            printf("rc %d\n", ierr);
+        } else if (cmd == "nnz") {               /* number of stored cells of Sz(site) as seen through this block object */
+            std::string name; PetscInt site; is >> name >> site;
+            long n = -1;
+            try { Mat m = blocks[name].Sz(site); n = m ? (long)m->cells.size() : -1; } catch (const std::exception&) { n = -2; }
+            printf("nnz %ld\n", n);
         } else if (cmd == "save") {
             std::string name, dir; is >> name >> dir;
             ierr = blocks[name].SaveToDisk(dir);

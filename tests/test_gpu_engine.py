@@ -184,6 +184,22 @@ def test_boundary_condition_options_match_exact_diagonalisation(tmp_path, flag, 
     assert abs(run["GSEnergy"] - e0) <= 1e-10 * abs(e0), (run["GSEnergy"], e0)
 
 
+def test_container_smoke_of_the_reference(tmp_path):
+    """tests/UnitTests_DMRGBlockContainer.cpp:11-26 of the reference: the default 4x4 lattice with
+    -mwarmup 20 -msweeps 20,30,40 -maxnsweeps 3,3,3 must run through (the reference checks no value); here also: the
+    energy never rises when m grows and every file of the run is valid JSON."""
+    rows, run, timings = run_engine(tmp_path, "-mwarmup", 20, "-msweeps", "20,30,40", "-maxnsweeps", "3,3,3")
+    assert run["Sweeps"] and run["Sweeps"][0] == 20 and run["Sweeps"][-1] == 40 and 3 <= len(run["Sweeps"]) <= 9
+    centre = [r["GSEnergy"] for r in rows if r["NSites_Sys"] == r["NSites_Env"] and r["LoopType"] == "Sweep"]
+    assert len(centre) == len(run["Sweeps"])
+    by_m = {}
+    for m, e in zip(run["Sweeps"], centre):
+        by_m[m] = min(e, by_m.get(m, 0.0))
+    assert by_m[40] <= by_m[30] + 1e-9 <= by_m[20] + 2e-9
+    for name in ("EntanglementSpectra.json", "Correlations.json", "Timings.json"):
+        json.load(open(str(tmp_path) + "/" + name))
+
+
 def test_spin_one_chain_matches_exact_diagonalisation(tmp_path):
     """-spin 1 (three states per site, Sz = diag(1,0,-1), S+ = sqrt(2)(|0><1| + |1><2|): src/DMRGBlock.cpp:1141-1156,1200-1215)
     on a 6-site Heisenberg chain, m large enough to be exact: energy and correlators against dense ED of the 3^6 lattice."""

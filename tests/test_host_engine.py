@@ -137,3 +137,20 @@ def test_engine_block_checkpoint_round_trip(tmp_path):
     open(os.path.join(d1, "BlockInfo.dat"), "w").write(txt)
     out = tool([f"load D {d1}"])
     assert out[-1] != "rc 0"
+
+
+def test_engine_block_shallow_copy_semantics():
+    """tests/UnitTests_DMRGBlock.cpp:26-73 of the reference: a copied block shares the operator handles of the original and
+    passes the same checks; Destroy() on the copy releases the matrices of the original too."""
+    f = json.load(open(os.path.join(GOLD, "block_fixture.json")))
+    d = dict(nsites=f["nsites"], qn_list=f["qn_list"], qn_size=f["qn_size"], Sz={"0": f["valid"]["SetSz0"], "1": f["valid"]["SetSz1"]},
+             Sp={"0": f["valid"]["SetSp0"], "1": f["valid"]["SetSp1"]})
+    setup = block_lines("B", d)
+    out = tool(setup + ["copy B C", "check C", "dump C", "nnz B 0", "destroy C", "nnz B 0"])
+    rcs = [ln for ln in out if ln.startswith("rc ")]
+    assert rcs[len(setup)] == "rc 0" and rcs[len(setup) + 1] == "rc 0"          # copy, check C
+    first = tool(setup + ["dump B"])
+    end = [i for i, ln in enumerate(out) if ln == "end"][0]
+    assert parse_dump(out[:end + 1]) == parse_dump(first)                        # the copy shows the same operators
+    nn = [ln for ln in out if ln.startswith("nnz ")]
+    assert int(nn[0].split()[1]) > 0 and int(nn[1].split()[1]) <= 0             # ... and its Destroy() emptied the original's
