@@ -285,13 +285,24 @@ void ggemm_schedule(std::vector<GTile>& tiles, int unit)
         i = j;
     }
     std::stable_sort(cl.begin(), cl.end(), [](const Cl& a, const Cl& b) { return a.cost > b.cost; });
-    std::vector<std::vector<GTile>> bins(NX);
+    // clusters go to the least-loaded XCD, heaviest first (LPT) ...
+    std::vector<std::vector<Cl>> binc(NX);
     int64_t load[NX] = {0};
     for (const Cl& c : cl) {
         int best = 0;
         for (int x = 1; x < NX; ++x) if (load[x] < load[best]) best = x;
         load[best] += c.cost;
-        for (size_t t = c.begin; t < c.end; ++t) bins[best].push_back(tiles[t]);
+        binc[best].push_back(c);
+    }
+    // ... and inside an XCD the clusters with the LONGEST tiles run first, whatever their total: the launch ends when the
+    // last tile ends, so the tail should be made of the shortest tiles, not of a small cluster of long ones
+    static const bool by_tile = !(getenv("DMRGX_SCHED_TOTAL"));
+    std::vector<std::vector<GTile>> bins(NX);
+    for (int x = 0; x < NX; ++x) {
+        // (coarse buckets of 16 k-steps, stable: clusters of similar tile length keep the LPT order, which keeps the clusters
+        //  of one group -- same operands -- close together)
+        if (by_tile) std::stable_sort(binc[x].begin(), binc[x].end(), [&](const Cl& a, const Cl& b) { return (tiles[a.begin].pad >> 4) > (tiles[b.begin].pad >> 4); });
+        for (const Cl& c : binc[x]) for (size_t t = c.begin; t < c.end; ++t) bins[x].push_back(tiles[t]);
     }
     size_t len = 0;
     for (auto& b : bins) len = std::max(len, b.size());
