@@ -30,6 +30,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 
 // partial[(chunk*DOT_CHUNK + i) * DOT_BLOCKS + block] = sum_e V[(v0+i)*ldv + e] * w[e]   (i < DOT_CHUNK)
 // the last chunk's slot `nv` holds w.w
+template <bool VEC2>                     // VEC2: n even and 16-byte aligned rows -> one 16-byte load per lane and vector
 __global__ void __launch_bounds__(DOT_THREADS)
 multi_dot_kernel(const double* __restrict__ V, int64_t ldv, int nv, const double* __restrict__ w, int64_t n, double* __restrict__ partial)
 {
@@ -38,13 +39,26 @@ multi_dot_kernel(const double* __restrict__ V, int64_t ldv, int nv, const double
     double acc[DOT_CHUNK];
 #pragma unroll
     for (int i = 0; i < DOT_CHUNK; ++i) acc[i] = 0.0;
-    for (int64_t e = (int64_t)blockIdx.x * DOT_THREADS + threadIdx.x; e < n; e += (int64_t)gridDim.x * DOT_THREADS) {
-        const double wv = w[e];
+    if (VEC2) {
+        const double2* __restrict__ w2 = reinterpret_cast<const double2*>(w);
+        for (int64_t e = (int64_t)blockIdx.x * DOT_THREADS + threadIdx.x; e < n / 2; e += (int64_t)gridDim.x * DOT_THREADS) {
+            const double2 wv = w2[e];
 #pragma unroll
-        for (int i = 0; i < DOT_CHUNK; ++i) {
-            const int v = v0 + i;
-            if (v < nv) acc[i] += V[(int64_t)v * ldv + e] * wv;
-            else if (v == nv) acc[i] += wv * wv;
+            for (int i = 0; i < DOT_CHUNK; ++i) {
+                const int v = v0 + i;
+                if (v < nv) { const double2 x = reinterpret_cast<const double2*>(V + (int64_t)v * ldv)[e]; acc[i] += x.x * wv.x + x.y * wv.y; }
+                else if (v == nv) acc[i] += wv.x * wv.x + wv.y * wv.y;
+            }
+        }
+    } else {
+        for (int64_t e = (int64_t)blockIdx.x * DOT_THREADS + threadIdx.x; e < n; e += (int64_t)gridDim.x * DOT_THREADS) {
+            const double wv = w[e];
+#pragma unroll
+            for (int i = 0; i < DOT_CHUNK; ++i) {
+                const int v = v0 + i;
+                if (v < nv) acc[i] += V[(int64_t)v * ldv + e] * wv;
+                else if (v == nv) acc[i] += wv * wv;
+            }
         }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -148,6 +162,7 @@ axpy_dot_kernel(const double* __restrict__ V, int64_t ldv, int nv, const double*
 // (c[nv] = w.w; V orthonormal and c = V^T w the tiny refinement coefficients, so there is no cancellation): every
 // workgroup recomputes beta^2 from the nv+1 reduced dots -- no separate reduction pass, no extra all-reduce and no extra
 // launch -- and workgroup 0 records it in beta2_out (the step's row of the projected matrix).
+template <bool VEC2>
 __global__ void __launch_bounds__(DOT_THREADS)
 axpy_normalise_kernel(const double* __restrict__ V, int64_t ldv, int nv, const double* __restrict__ c, const double* __restrict__ w,
                       double* __restrict__ dst, int64_t n, double* __restrict__ beta2_out, double* __restrict__ hacc)
@@ -161,10 +176,21 @@ axpy_normalise_kernel(const double* __restrict__ V, int64_t ldv, int nv, const d
     s2 = s2 > 0.0 ? s2 : 0.0;
     if (blockIdx.x == 0 && threadIdx.x == 0 && beta2_out) *beta2_out = s2;
     const double inv = s2 > 1e-290 ? 1.0 / sqrt(s2) : 0.0;
-    for (int64_t e = (int64_t)blockIdx.x * DOT_THREADS + threadIdx.x; e < n; e += (int64_t)gridDim.x * DOT_THREADS) {
-        double x = w[e];
-        for (int i = 0; i < nv; ++i) x -= cs[i] * V[(int64_t)i * ldv + e];
-        dst[e] = x * inv;
+    if (VEC2) {
+        const double2* __restrict__ w2 = reinterpret_cast<const double2*>(w);
+        double2* __restrict__ d2 = reinterpret_cast<double2*>(dst);
+        for (int64_t e = (int64_t)blockIdx.x * DOT_THREADS + threadIdx.x; e < n / 2; e += (int64_t)gridDim.x * DOT_THREADS) {
+            double2 x = w2[e];
+            for (int i = 0; i < nv; ++i) { const double2 v = reinterpret_cast<const double2*>(V + (int64_t)i * ldv)[e]; x.x -= cs[i] * v.x; x.y -= cs[i] * v.y; }
+            x.x *= inv; x.y *= inv;
+            d2[e] = x;
+        }
+    } else {
+        for (int64_t e = (int64_t)blockIdx.x * DOT_THREADS + threadIdx.x; e < n; e += (int64_t)gridDim.x * DOT_THREADS) {
+            double x = w[e];
+            for (int i = 0; i < nv; ++i) x -= cs[i] * V[(int64_t)i * ldv + e];
+            dst[e] = x * inv;
+        }
     }
 }
 
@@ -305,6 +331,7 @@ extern "C" dmrgx_status dmrgx_eigs_lowest(dmrgx_kron_plan* plan, const dmrgx_eig
     DMRGX_HIP(hipMemsetAsync(dW.p, 0, dW.bytes, st));
     if (dist) DMRGX_HIP(hipMemsetAsync(dX.p, 0, dX.bytes, st));
 
+    const bool vec2 = (n % 2 == 0);                     // all vectors are whole allocations (256-byte aligned) of stride n
     const int nblk = DOT_BLOCKS;      // (scaling the grid down with n was measured slower even at n = 1.6e5: these passes are latency-bound)
     auto allreduce = [&](double* buf, int64_t count) -> dmrgx_status {
         if (!dist) return DMRGX_OK;
@@ -313,7 +340,8 @@ extern "C" dmrgx_status dmrgx_eigs_lowest(dmrgx_kron_plan* plan, const dmrgx_eig
     // dots of w against V[0..nv) plus w.w  -> c1[0..nv]
     auto multi_dot = [&](int nv) -> dmrgx_status {
         const int chunks = (nv + 1 + DOT_CHUNK - 1) / DOT_CHUNK;
-        hipLaunchKernelGGL(multi_dot_kernel, dim3(nblk, chunks), dim3(DOT_THREADS), 0, st, V, n, nv, w, n, dPartial.as<double>());
+        if (vec2) hipLaunchKernelGGL(multi_dot_kernel<true>, dim3(nblk, chunks), dim3(DOT_THREADS), 0, st, V, n, nv, w, n, dPartial.as<double>());
+        else hipLaunchKernelGGL(multi_dot_kernel<false>, dim3(nblk, chunks), dim3(DOT_THREADS), 0, st, V, n, nv, w, n, dPartial.as<double>());
         DMRGX_HIP(hipGetLastError());
         hipLaunchKernelGGL(reduce_partials_kernel, dim3(nv + 1), dim3(DOT_THREADS), 0, st, dPartial.as<double>(), c1, nv + 1, nblk);
         DMRGX_HIP(hipGetLastError());
@@ -386,7 +414,8 @@ extern "C" dmrgx_status dmrgx_eigs_lowest(dmrgx_kron_plan* plan, const dmrgx_eig
                 DMRGX_HIP(hipMemcpyAsync(c2, c1, (size_t)(nv + 1) * sizeof(double), hipMemcpyDeviceToDevice, st));
             }
             // beta^2 = w'.w' - |c2|^2 ; v_{j+1} = (w' - V c2) / beta
-            hipLaunchKernelGGL(axpy_normalise_kernel, dim3(nblk), dim3(DOT_THREADS), 0, st, V, n, nv, c2, w, vec(j + 1), n, Hrow(j) + m + 1, Hrow(j));
+            if (vec2) hipLaunchKernelGGL(axpy_normalise_kernel<true>, dim3(nblk), dim3(DOT_THREADS), 0, st, V, n, nv, c2, w, vec(j + 1), n, Hrow(j) + m + 1, Hrow(j));
+            else hipLaunchKernelGGL(axpy_normalise_kernel<false>, dim3(nblk), dim3(DOT_THREADS), 0, st, V, n, nv, c2, w, vec(j + 1), n, Hrow(j) + m + 1, Hrow(j));
             DMRGX_HIP(hipGetLastError());
             // A start vector supplied by the caller (the sweep engine's transformed ground state) is usually within a few
             // Lanczos steps of convergence: look at the Ritz pair every 4 steps instead of only at the end of the cycle.
