@@ -1,0 +1,347 @@
+// Batched Householder QR with explicit Q^T -- see hqr.h.  Two kernels per panel of 32 columns:
+//
+//   hqr_panel_*_kernel   one workgroup per matrix factors the n_rem x 32 panel (32 reflectors, one after the other) and leaves
+//                        the reflectors V (explicit unit lower trapezoid) and the compact-WY factor T:
+//                        H_0 .. H_31 = I - V T V^T.  Panels of up to 1024 rows live in registers (hqr_panel_regs_kernel),
+//                        longer ones in the L2-resident V scratch (hqr_panel_kernel).
+//   hqr_trailing_kernel  C <- (I - V T^T V^T) C for the columns right of the panel and for the n columns of the
+//                        identity half; one workgroup per 64 columns, two passes over the column strip (W = V^T C reduced
+//                        over eight waves, then C -= V (T^T W)); V rows are wave-uniform operands of the FMAs.
+//
+// Q^T = H_k .. H_1 I is accumulated forwards in the identity half, next to the factorisation (every panel updates all n of
+// its columns, rows r0 and below): 2 n^3 flops on top of the 4/3 n^3 of the factorisation, no second sweep over the panels.
+#include "hqr.h"
+
+namespace dmrgx {
+namespace {
+
+constexpr int HR_THREADS = 512, HR_WAVES = HR_THREADS / 64, HR_MAX_ROWS = 1024;     // register-resident panels
+constexpr int HQ_THREADS = 1024, HQ_WAVES = HQ_THREADS / 64, HQ_LDS_ROWS = 480, HQ_LDS_STRIDE = 33;
+static_assert(HQR_MAX_N <= HQ_LDS_ROWS * HQ_LDS_STRIDE, "the reflector of the global-memory path is kept in the panel's LDS");
+
+__global__ void __launch_bounds__(HQ_THREADS)
+hqr_panel_kernel(const HqrMat* __restrict__ mats, double* __restrict__ buf, int r0)
+{
+    __shared__ double pl[HQ_LDS_ROWS * HQ_LDS_STRIDE];     // the panel (LDS path) or the current reflector (global path)
+    __shared__ double vsm[HQ_LDS_ROWS];                    // the current reflector (LDS path)
+    __shared__ double red[32][33];
+    __shared__ double Tm[32][33];
+    __shared__ double wz[32], wred[HQ_WAVES];
+    const HqrMat m = mats[blockIdx.x];
+    if (m.n - r0 <= HR_MAX_ROWS) return;                    // those panels belong to hqr_panel_regs_kernel
+    const int n = m.n, nrem = n - r0, pw = min(32, nrem), ldb = 2 * n;
+    const int tid = threadIdx.x, c = tid & 31, rg = tid >> 5, lane = tid & 63, wave = tid >> 6;
+    const double* B = buf + m.b_off + (int64_t)r0 * ldb + r0;
+    double* Vg = buf + m.v_off;
+    const bool in_lds = nrem <= HQ_LDS_ROWS;
+    double* P = in_lds ? pl : Vg;
+    const int ps = in_lds ? HQ_LDS_STRIDE : 32;
+    double* v = in_lds ? vsm : pl;
+
+    for (int i = rg; i < nrem; i += 32) P[i * ps + c] = (c < pw) ? B[(int64_t)i * ldb + c] : 0.0;
+    for (int e = tid; e < 32 * 33; e += HQ_THREADS) (&Tm[0][0])[e] = 0.0;
+    __syncthreads();
+
+    for (int j = 0; j < pw; ++j) {
+        // ---- the reflector of column j:  H = I - tau v v^T,  v_j = 1,  H x = beta e_j
+        double s = 0.0;
+        for (int i = j + 1 + tid; i < nrem; i += HQ_THREADS) { const double x = P[i * ps + j]; s += x * x; }
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+        if (lane == 0) wred[wave] = s;
+        __syncthreads();
+        double sigma = 0.0;
+        for (int w = 0; w < HQ_WAVES; ++w) sigma += wred[w];
+        const double alpha = P[j * ps + j];
+        double beta = alpha, tau = 0.0, scale = 0.0;
+        if (sigma > 0.0) {
+            const double nrm = sqrt(alpha * alpha + sigma);
+            beta = alpha >= 0.0 ? -nrm : nrm;
+            tau = (beta - alpha) / beta;
+            scale = 1.0 / (alpha - beta);
+        }
+        __syncthreads();                                   // everyone holds alpha and sigma before column j is rewritten
+        for (int i = j + tid; i < nrem; i += HQ_THREADS) {
+            if (i == j) { v[i] = 1.0; P[j * ps + j] = beta; }
+            else { const double vi = P[i * ps + j] * scale; v[i] = vi; P[i * ps + j] = vi; }
+        }
+        __syncthreads();
+        // ---- one pass gives w_c = v^T P[:,c] for the columns right of j and z_c = V[:,c]^T v for the reflectors left of it
+        double acc = 0.0;
+        if (c != j) for (int i = j + rg; i < nrem; i += 32) acc += v[i] * P[i * ps + c];
+        red[rg][c] = acc;
+        __syncthreads();
+        if (tid < 32) { double t = 0.0; for (int g = 0; g < 32; ++g) t += red[g][tid]; wz[tid] = t; }
+        __syncthreads();
+        if (c > j && c < pw) {
+            const double tw = tau * wz[c];
+            for (int i = j + rg; i < nrem; i += 32) P[i * ps + c] -= tw * v[i];
+        }
+        if (tid < 32) Tm[tid][j] = tid < j ? wz[tid] : (tid == j ? tau : 0.0);      // column j of S: z above the diagonal, tau on it
+        __syncthreads();
+    }
+    // ---- explicit V (unit diagonal, zeros above it and right of the panel) and T for the trailing update
+    for (int i = rg; i < nrem; i += 32) {
+        double x = 0.0;
+        if (c < pw) x = (i > c) ? P[i * ps + c] : (i == c ? 1.0 : 0.0);
+        Vg[(int64_t)i * 32 + c] = x;
+    }
+    for (int e = tid; e < 32 * 32; e += HQ_THREADS) buf[m.t_off + e] = Tm[e >> 5][e & 31];
+}
+
+// Register-resident panel factorisation (n_rem <= 64 RR): 512 threads as 64 row blocks x 8 column blocks, thread (rb, cb)
+// keeps the rows rb, rb+64, .. of the four panel columns 4cb..4cb+3 in registers, so one reflector element read from LDS
+// feeds eight FMAs (the first version, one column per thread, was bound by LDS reads of the reflector).  Three barriers
+// per column: the norm of the next column is accumulated while the current reflector is applied, and column j of T is
+// finished one iteration late.  One instantiation per size class, launched only when the class is populated.
+// a(lane) + a(lane ^ 8) + .. over lane bits 3, 4, 5 without the LDS crossbar: DPP row rotate, then the gfx950 row / half swaps
+// (v_permlane16_swap: odd rows of the first operand <-> even rows of the second; v_permlane32_swap: upper half <-> lower half;
+// with both operands equal, result[0] + result[1] = own + partner in every lane).
+__device__ __forceinline__ double sum_lane_bits_345(double a)
+{
+    int lo = __double2loint(a), hi = __double2hiint(a);
+    a += __hiloint2double(__builtin_amdgcn_update_dpp(0, hi, 0x128, 0xf, 0xf, false), __builtin_amdgcn_update_dpp(0, lo, 0x128, 0xf, 0xf, false));   // row_ror:8
+    lo = __double2loint(a); hi = __double2hiint(a);
+    auto l16 = __builtin_amdgcn_permlane16_swap((unsigned)lo, (unsigned)lo, false, false);
+    auto h16 = __builtin_amdgcn_permlane16_swap((unsigned)hi, (unsigned)hi, false, false);
+    a = __hiloint2double((int)h16[0], (int)l16[0]) + __hiloint2double((int)h16[1], (int)l16[1]);
+    lo = __double2loint(a); hi = __double2hiint(a);
+    auto l32 = __builtin_amdgcn_permlane32_swap((unsigned)lo, (unsigned)lo, false, false);
+    auto h32 = __builtin_amdgcn_permlane32_swap((unsigned)hi, (unsigned)hi, false, false);
+    return __hiloint2double((int)h32[0], (int)l32[0]) + __hiloint2double((int)h32[1], (int)l32[1]);
+}
+
+__device__ __forceinline__ double sel4(const double (&x)[4], int q) { return q == 0 ? x[0] : (q == 1 ? x[1] : (q == 2 ? x[2] : x[3])); }
+
+template <int RR>
+__global__ void __launch_bounds__(HR_THREADS)
+hqr_panel_regs_kernel(const HqrMat* __restrict__ mats, double* __restrict__ buf, int r0)
+{
+    __shared__ double vsm[64 * RR];
+    __shared__ double red[HR_WAVES][32];
+    __shared__ double Tm[32][33];
+    __shared__ double sred[HR_WAVES], piv[1];
+    const HqrMat m = mats[blockIdx.x];
+    const int nrem = m.n - r0;
+    if (nrem <= (RR > 4 ? 32 * RR : 0) || nrem > 64 * RR) return;          // another size class (or nothing left)
+    const int pw = min(32, nrem), ldb = 2 * m.n;
+    const int tid = threadIdx.x, cb = tid & 7, rb = tid >> 3, lane = tid & 63, wave = tid >> 6;
+    const double* B = buf + m.b_off + (int64_t)r0 * ldb + r0 + 4 * cb;
+    double p[RR][4];
+#pragma unroll
+    for (int k = 0; k < RR; ++k) {
+        const int i = rb + 64 * k;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) p[k][q] = (i < nrem && 4 * cb + q < pw) ? B[(int64_t)i * ldb + q] : 0.0;
+    }
+    for (int e = tid; e < 32 * 33; e += HR_THREADS) (&Tm[0][0])[e] = 0.0;
+    {   // norm and pivot of column 0
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < RR; ++k) { const int i = rb + 64 * k; if (i > 0) s += p[k][0] * p[k][0]; }
+        s = sum_lane_bits_345(s);
+        if (lane == 0) sred[wave] = s;
+        if (tid == 0) piv[0] = p[0][0];
+    }
+    __syncthreads();
+    for (int j = 0; j < pw; ++j) {
+        double sigma = 0.0;
+#pragma unroll
+        for (int w = 0; w < HR_WAVES; ++w) sigma += sred[w];
+        const double alpha = piv[0];
+        double tau = 0.0, scale = 0.0;
+        if (sigma > 0.0) {
+            const double nrm = sqrt(alpha * alpha + sigma);
+            const double beta = alpha >= 0.0 ? -nrm : nrm;
+            tau = (beta - alpha) / beta;
+            scale = 1.0 / (alpha - beta);
+        }
+        const int k0 = j >> 6, cbj = j >> 2, qj = j & 3;     // registers k < k0 hold rows above j
+        if (cb == cbj) {                                    // the reflector: zeros above row j, 1 on it, x * scale below
+#pragma unroll
+            for (int k = 0; k < RR; ++k) {
+                if (k < k0) continue;
+                const int i = rb + 64 * k;
+                const double vi = (i < j) ? 0.0 : (i == j ? 1.0 : sel4(p[k], qj) * scale);
+                if (i > j) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) p[k][q] = (q == qj) ? vi : p[k][q];
+                }
+                vsm[i] = vi;
+            }
+        }
+        __syncthreads();
+        // ---- one pass gives w_c = v^T P[:,c] for the columns right of j and z_c = V[:,c]^T v for the reflectors left of it
+        double vr[RR], acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < RR; ++k) {
+            vr[k] = (k >= k0) ? vsm[rb + 64 * k] : 0.0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] += vr[k] * p[k][q];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            acc[q] = sum_lane_bits_345(acc[q]);
+            if (lane < 8) red[wave][4 * cb + q] = acc[q];
+        }
+        __syncthreads();
+        double tw[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            double wc = 0.0;
+#pragma unroll
+            for (int w = 0; w < HR_WAVES; ++w) wc += red[w][4 * cb + q];
+            const int col = 4 * cb + q;
+            if (tid < 8) Tm[col][j] = col < j ? wc : (col == j ? tau : 0.0);      // column j of S: z above the diagonal, tau on it
+            tw[q] = (col > j && col < pw) ? tau * wc : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < RR; ++k) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) p[k][q] -= tw[q] * vr[k];
+        }
+        if (j + 1 < pw) {                                   // norm and pivot of the next column, while it is in hand
+            const int q1 = (j + 1) & 3, cb1 = (j + 1) >> 2;
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < RR; ++k) {
+                const int i = rb + 64 * k;
+                const double x = sel4(p[k], q1);
+                if (i > j + 1) s += x * x; else if (i == j + 1 && cb == cb1) piv[0] = x;
+            }
+            s = sum_lane_bits_345(s);
+            if (lane == cb1) sred[wave] = s;
+        }
+        __syncthreads();
+    }
+    double* Vg = buf + m.v_off;
+#pragma unroll
+    for (int k = 0; k < RR; ++k) {
+        const int i = rb + 64 * k;
+        if (i < nrem) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const int c = 4 * cb + q; Vg[(int64_t)i * 32 + c] = (c < pw) ? (i > c ? p[k][q] : (i == c ? 1.0 : 0.0)) : 0.0; }
+        }
+    }
+    for (int e = tid; e < 32 * 32; e += HR_THREADS) buf[m.t_off + e] = Tm[e >> 5][e & 31];
+}
+
+constexpr int TR_THREADS = 512, TR_WAVES = TR_THREADS / 64, TR_COLS = 64, TR_UNROLL = 4;
+
+__global__ void __launch_bounds__(TR_THREADS)
+hqr_trailing_kernel(const HqrMat* __restrict__ mats, double* __restrict__ buf, const double* __restrict__ vt, int r0)
+{
+    __shared__ double racc[TR_WAVES][16][TR_COLS];
+    __shared__ double Ts[32 * 32];
+    const HqrMat m = mats[blockIdx.y];
+    if (r0 >= m.n) return;
+    const int n = m.n, nrem = n - r0, pw = min(32, nrem), ldb = 2 * n;
+    const int nA = (n - r0 - pw + TR_COLS - 1) / TR_COLS, nI = (n + TR_COLS - 1) / TR_COLS;
+    const int t = blockIdx.x;
+    if (t >= nA + nI) return;
+    int col0, cend;
+    if (t < nA) { col0 = r0 + pw + t * TR_COLS; cend = n; }
+    else { col0 = n + (t - nA) * TR_COLS; cend = 2 * n; }
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool valid = col0 + lane < cend;
+    double* C = buf + m.b_off + (int64_t)r0 * ldb + (valid ? col0 + lane : col0);
+    const double keep = valid ? 1.0 : 0.0;
+    const double* V = vt + m.v_off;
+    for (int e = threadIdx.x; e < 32 * 32; e += TR_THREADS) Ts[e] = vt[m.t_off + e];
+
+    double acc[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) acc[k] = 0.0;
+    int i = wave;
+    for (; i + (TR_UNROLL - 1) * TR_WAVES < nrem; i += TR_UNROLL * TR_WAVES) {
+        double cv[TR_UNROLL];
+#pragma unroll
+        for (int u = 0; u < TR_UNROLL; ++u) cv[u] = C[(int64_t)(i + u * TR_WAVES) * ldb] * keep;
+#pragma unroll
+        for (int u = 0; u < TR_UNROLL; ++u) {
+            const double* vr = V + (int64_t)(i + u * TR_WAVES) * 32;
+#pragma unroll
+            for (int k = 0; k < 32; ++k) acc[k] += vr[k] * cv[u];
+        }
+    }
+    for (; i < nrem; i += TR_WAVES) {
+        const double cv = C[(int64_t)i * ldb] * keep;
+        const double* vr = V + (int64_t)i * 32;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) acc[k] += vr[k] * cv;
+    }
+    // ---- W0 = sum over the eight waves (two halves of 16 reflectors through 64 KB of LDS), then W = T^T W0 in place (as a solve)
+    double w[32];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) racc[wave][kk][lane] = acc[16 * h + kk];
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            double s = 0.0;
+#pragma unroll
+            for (int q = 0; q < TR_WAVES; ++q) s += racc[q][kk][lane];
+            w[16 * h + kk] = s;
+        }
+    }
+    // W = T^T W0 with T^-1 = S' (unit... S' = strict upper part of S + diag(1/tau)), i.e. forward substitution in registers:
+    // w_k = tau_k (w0_k - sum_{l<k} z_l[k] w_l); the right-looking form keeps the 32 - k updates of a step independent
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+        w[k] *= Ts[k * 32 + k];
+#pragma unroll
+        for (int l = k + 1; l < 32; ++l) w[l] -= Ts[k * 32 + l] * w[k];
+    }
+    // ---- C -= V W
+    i = wave;
+    for (; i + (TR_UNROLL - 1) * TR_WAVES < nrem; i += TR_UNROLL * TR_WAVES) {
+        double cv[TR_UNROLL];
+#pragma unroll
+        for (int u = 0; u < TR_UNROLL; ++u) cv[u] = C[(int64_t)(i + u * TR_WAVES) * ldb];
+#pragma unroll
+        for (int u = 0; u < TR_UNROLL; ++u) {
+            const double* vr = V + (int64_t)(i + u * TR_WAVES) * 32;
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < 32; ++k) s += vr[k] * w[k];
+            if (valid) C[(int64_t)(i + u * TR_WAVES) * ldb] = cv[u] - s;
+        }
+    }
+    for (; i < nrem; i += TR_WAVES) {
+        const double cv = C[(int64_t)i * ldb];
+        const double* vr = V + (int64_t)i * 32;
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) s += vr[k] * w[k];
+        if (valid) C[(int64_t)i * ldb] = cv - s;
+    }
+}
+
+}  // namespace
+
+dmrgx_status hqr_batched(const std::vector<HqrMat>& mats, const HqrMat* d_mats, double* buf, hipStream_t st)
+{
+    int max_n = 0;
+    for (const HqrMat& m : mats) {
+        if (m.n < 0 || m.n > HQR_MAX_N) DMRGX_FAIL(DMRGX_ERR_ARG, "hqr: matrix of order %d (supported: 0..%d)", m.n, HQR_MAX_N);
+        max_n = std::max(max_n, m.n);
+    }
+    const unsigned nm = (unsigned)mats.size();
+    if (nm == 0) return DMRGX_OK;
+    for (int r0 = 0; r0 < max_n; r0 += 32) {
+        const int nrem = max_n - r0, pw = std::min(32, nrem);
+        const unsigned tiles = (unsigned)((max_n - r0 - pw + TR_COLS - 1) / TR_COLS + (max_n + TR_COLS - 1) / TR_COLS);
+        bool cls[4] = {false, false, false, false};          // size classes present at this panel: <=256, <=512, <=1024, longer
+        for (const HqrMat& m : mats) { const int r = m.n - r0; if (r > 0) cls[r <= 256 ? 0 : (r <= 512 ? 1 : (r <= HR_MAX_ROWS ? 2 : 3))] = true; }
+        if (cls[3]) hipLaunchKernelGGL(hqr_panel_kernel, dim3(nm), dim3(HQ_THREADS), 0, st, d_mats, buf, r0);
+        if (cls[2]) hipLaunchKernelGGL(hqr_panel_regs_kernel<16>, dim3(nm), dim3(HR_THREADS), 0, st, d_mats, buf, r0);
+        if (cls[1]) hipLaunchKernelGGL(hqr_panel_regs_kernel<8>, dim3(nm), dim3(HR_THREADS), 0, st, d_mats, buf, r0);
+        if (cls[0]) hipLaunchKernelGGL(hqr_panel_regs_kernel<4>, dim3(nm), dim3(HR_THREADS), 0, st, d_mats, buf, r0);
+        hipLaunchKernelGGL(hqr_trailing_kernel, dim3(tiles, nm), dim3(TR_THREADS), 0, st, d_mats, buf, (const double*)buf, r0);
+        DMRGX_HIP(hipGetLastError());
+    }
+    return DMRGX_OK;
+}
+
+}  // namespace dmrgx

@@ -10,6 +10,7 @@
 // on the host (caller), which fetches spectra with dmrgx_rdm_eigenvalues and asks for the kept eigenvectors with
 // dmrgx_rdm_eigenvectors (== FillRotation_BlockDiag, :2006-2057).
 #include "ggemm.h"
+#include "hqr.h"
 #include <algorithm>
 #include <cmath>
 #include <memory>
@@ -308,6 +309,35 @@ __global__ void __launch_bounds__(256) colnorm_kernel(const ColNormTask* __restr
     if (rg == 0 && col < t.ncols) out[t.out_off + col] = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
 }
 
+// Preconditioner input: B = [ P^T A P | I ] (n x 2n) with P the permutation that sorts the diagonal of A downwards
+__global__ void __launch_bounds__(256) qr_gather_kernel(const MatDesc* __restrict__ mats, const HqrMat* __restrict__ qm, const int32_t* __restrict__ perm,
+                                                         const int64_t* __restrict__ perm_off, double* __restrict__ buf)
+{
+    const MatDesc m = mats[blockIdx.y];
+    const HqrMat q = qm[blockIdx.y];
+    const int n = q.n;
+    const int32_t* pm = perm + perm_off[blockIdx.y];
+    const int64_t tot = (int64_t)n * 2 * n;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < tot; e += (int64_t)gridDim.x * 256) {
+        const int i = (int)(e / (2 * n)), j = (int)(e % (2 * n));
+        buf[q.b_off + e] = j < n ? buf[m.a_off + (int64_t)pm[i] * m.npad + pm[j]] : (j - n == i ? 1.0 : 0.0);
+    }
+}
+
+// Preconditioner output: E (n x n, rows = the new basis in the original index order):  E[r][perm[j]] = Q^T[r][j]
+__global__ void __launch_bounds__(256) qr_scatter_kernel(const HqrMat* __restrict__ qm, const int32_t* __restrict__ perm, const int64_t* __restrict__ perm_off,
+                                                          const int64_t* __restrict__ e_off, double* __restrict__ buf)
+{
+    const HqrMat q = qm[blockIdx.y];
+    const int n = q.n;
+    const int32_t* pm = perm + perm_off[blockIdx.y];
+    const int64_t tot = (int64_t)n * n;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < tot; e += (int64_t)gridDim.x * 256) {
+        const int r = (int)(e / n), j = (int)(e % n);
+        buf[e_off[blockIdx.y] + (int64_t)r * n + pm[j]] = buf[q.b_off + (int64_t)r * 2 * n + n + j];
+    }
+}
+
 // dst[r*ld + i] = V[i*npad + perm[r]]
 __global__ void gather_vec_kernel(const double* __restrict__ V, int npad, int n, const int32_t* __restrict__ perm, int count, double* __restrict__ dst, int64_t ld)
 {
@@ -393,8 +423,28 @@ extern "C" dmrgx_status dmrgx_rdm_create_warm(const dmrgx_sectors* left, const d
     const int64_t rq_base = total; total += dtot;            // Rayleigh quotients, same indexing as the diagonals
     const int64_t w_base = total; total += 2 * N;            // W = Psi^T V_L (n_R x n_L) and Psi V_R (n_L x n_R) per block
     // warm start: per matrix with a previous eigenbasis E (rows), W = E A and E^T (n x n each)
+    // QR preconditioner (default on; DMRGX_RDM_QR=0 restores the plain / caller-warm-started solver for comparison): its
+    // basis replaces the caller's v0_rows, which then only remain a hint
+    static const bool use_qr = !(getenv("DMRGX_RDM_QR") && atoi(getenv("DMRGX_RDM_QR")) == 0);
+    std::vector<const double*> warm_src(nm, nullptr);
+    std::vector<HqrMat> qmats(nm, HqrMat{0, 0, 0, 0, 0});
+    std::vector<int64_t> qe_off(nm, 0), qperm_off(nm, 0);
+    int64_t qperm_tot = 0;
+    bool any_qr = false;
+    for (int mi = 0; mi < nm; ++mi) {
+        const int64_t n = P->mats[mi].n;
+        if (use_qr && n >= 2 && n <= HQR_MAX_N) {
+            qmats[mi].n = (int32_t)n;
+            qmats[mi].b_off = total; total += 2 * n * n;
+            qmats[mi].v_off = total; total += 32 * n;
+            qmats[mi].t_off = total; total += 32 * 32;
+            qe_off[mi] = total; total += n * n;
+            qperm_off[mi] = qperm_tot; qperm_tot += n;
+            any_qr = true;
+        } else if (!use_qr && v0_rows && v0_rows[mi]) warm_src[mi] = v0_rows[mi];
+    }
     std::vector<int64_t> warm_w(nm, -1), warm_et(nm, -1);
-    if (v0_rows) for (int mi = 0; mi < nm; ++mi) if (v0_rows[mi]) { const int64_t nn = (int64_t)P->mats[mi].n * P->mats[mi].n; warm_w[mi] = total; total += nn; warm_et[mi] = total; total += nn; }
+    for (int mi = 0; mi < nm; ++mi) if (warm_src[mi] || qmats[mi].n) { const int64_t nn = (int64_t)P->mats[mi].n * P->mats[mi].n; warm_w[mi] = total; total += nn; warm_et[mi] = total; total += nn; }
     DMRGX_CHK(P->buf.alloc((size_t)total * sizeof(double)));
     double* buf = P->buf.as<double>();
     DevBuf d_pairs, d_tiles, d_doff, d_pstart;
@@ -445,21 +495,75 @@ extern "C" dmrgx_status dmrgx_rdm_create_warm(const dmrgx_sectors* left, const d
         DMRGX_HIP(hipStreamSynchronize(st));
     }
 
+    if (const char* dump = getenv("DMRGX_RDM_DUMP")) {      // developer aid: the density matrices of one call, for offline convergence studies
+        static int call = 0;
+        const char* which = getenv("DMRGX_RDM_DUMP_CALL");
+        if (call++ == (which ? atoi(which) : 0)) {
+            if (FILE* f = fopen(dump, "wb")) {
+                const int minn = getenv("DMRGX_RDM_DUMP_MINN") ? atoi(getenv("DMRGX_RDM_DUMP_MINN")) : 0;
+                int32_t hdr = 0;
+                for (int mi = 0; mi < nm; ++mi) hdr += P->mats[mi].n >= minn;
+                fwrite(&hdr, 4, 1, f);
+                for (int mi = 0; mi < nm; ++mi) {
+                    const MatDesc& m = P->mats[mi];
+                    if (m.n < minn) continue;
+                    std::vector<double> h((size_t)m.npad * m.npad);
+                    if (!h.empty()) DMRGX_HIP(hipMemcpy(h.data(), buf + m.a_off, h.size() * sizeof(double), hipMemcpyDeviceToHost));
+                    int32_t d[2] = {m.n, m.npad};
+                    fwrite(d, 4, 2, f);
+                    fwrite(h.data(), sizeof(double), h.size(), f);
+                }
+                fclose(f);
+            }
+        }
+    }
+
     // ---- warm start: A <- E A E^T, V <- E^T for matrices whose previous eigenbasis E (eigenvectors as rows) is supplied.
     //      In a settled DMRG sweep the basis of the previous visit nearly diagonalises the new density matrix (measured:
     //      off^2/total^2 ~ 1e-5 instead of 0.5), which saves the first ~3 of ~10 Jacobi sweeps; the rest is the linearly
     //      converging tail of near-degenerate small eigenvalues.  Any orthogonal E is valid.
-    if (v0_rows) {
+    if (any_qr) {
+        // diagonal of every matrix -> host, sort downwards, gather [P^T A P | I], factor, scatter Q^T back to the original order
+        std::vector<double> hd((size_t)dtot);
+        hipLaunchKernelGGL(diag_kernel, dim3(nm), dim3(256), 0, st, dm, (const double*)buf, buf, d_doff.as<int64_t>());
+        DMRGX_HIP(hipGetLastError());
+        DMRGX_HIP(hipMemcpyAsync(hd.data(), buf + diag_base, hd.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+        DMRGX_HIP(hipStreamSynchronize(st));
+        std::vector<int32_t> qperm((size_t)qperm_tot);
+        int max_n = 0;
+        for (int mi = 0; mi < nm; ++mi) {
+            const int n = qmats[mi].n;
+            if (!n) continue;
+            max_n = std::max(max_n, n);
+            const double* d = hd.data() + (diag_off[mi] - diag_base);
+            int32_t* pm = qperm.data() + qperm_off[mi];
+            std::iota(pm, pm + n, 0);
+            std::stable_sort(pm, pm + n, [&](int32_t a, int32_t b) { return d[a] > d[b]; });
+            warm_src[mi] = buf + qe_off[mi];
+        }
+        DevBuf d_qm, d_qperm, d_qpoff, d_qeoff;
+        DMRGX_CHK(upload(d_qm, qmats, st)); DMRGX_CHK(upload(d_qperm, qperm, st)); DMRGX_CHK(upload(d_qpoff, qperm_off, st)); DMRGX_CHK(upload(d_qeoff, qe_off, st));
+        const unsigned gx = (unsigned)std::min<int64_t>(512, ((int64_t)max_n * 2 * max_n + 255) / 256);
+        hipLaunchKernelGGL(qr_gather_kernel, dim3(gx, nm), dim3(256), 0, st, dm, d_qm.as<HqrMat>(), d_qperm.as<int32_t>(), d_qpoff.as<int64_t>(), buf);
+        DMRGX_HIP(hipGetLastError());
+        DMRGX_CHK(hqr_batched(qmats, d_qm.as<HqrMat>(), buf, st));
+        hipLaunchKernelGGL(qr_scatter_kernel, dim3(gx, nm), dim3(256), 0, st, d_qm.as<HqrMat>(), d_qperm.as<int32_t>(), d_qpoff.as<int64_t>(), d_qeoff.as<int64_t>(), buf);
+        DMRGX_HIP(hipGetLastError());
+        DMRGX_HIP(hipStreamSynchronize(st));      // tables are freed at scope exit
+    }
+    bool any_warm = false;
+    for (int mi = 0; mi < nm; ++mi) any_warm = any_warm || warm_src[mi];
+    if (any_warm) {
         std::vector<TrTile> tt;
         std::vector<GProd> p1, p2;
         std::vector<GGroup> g1, g2;
         std::vector<GTile> t1, t1b, t2, t2b;
         for (int mi = 0; mi < nm; ++mi) {
-            if (!v0_rows[mi]) continue;
+            if (!warm_src[mi]) continue;
             const MatDesc& m = P->mats[mi];
             const int32_t n = m.n;
             if (n == 0) continue;
-            const double* E = v0_rows[mi];
+            const double* E = warm_src[mi];
             double* Wt = buf + warm_w[mi];
             double* ET = buf + warm_et[mi];
             for (int ti = 0; ti < (n + 31) / 32; ++ti) for (int tj = 0; tj < (n + 31) / 32; ++tj)
@@ -484,7 +588,7 @@ extern "C" dmrgx_status dmrgx_rdm_create_warm(const dmrgx_sectors* left, const d
             DMRGX_CHK(ggemm_launch(db2.as<GTile>(), dg2.as<GGroup>(), dp2.as<GProd>(), (int32_t)t2b.size(), st, 1));
             DMRGX_CHK(ggemm_launch(dt2.as<GTile>(), dg2.as<GGroup>(), dp2.as<GProd>(), (int32_t)t2.size(), st, 0));
             for (int mi = 0; mi < nm; ++mi) {
-                if (!v0_rows[mi] || P->mats[mi].n == 0) continue;
+                if (!warm_src[mi] || P->mats[mi].n == 0) continue;
                 const MatDesc& m = P->mats[mi];
                 DMRGX_HIP(hipMemcpy2DAsync(buf + m.v_off, (size_t)m.npad * sizeof(double), buf + warm_et[mi], (size_t)m.n * sizeof(double),
                                            (size_t)m.n * sizeof(double), (size_t)m.n, hipMemcpyDeviceToDevice, st));

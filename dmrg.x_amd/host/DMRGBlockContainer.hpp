@@ -1039,7 +1039,7 @@ private:
     /* eigenbases of the density matrices at the previous visit of every block: warm start of the Jacobi eigensolver */
     struct WarmBasis { std::vector<int32_t> sizes; std::map<int32_t, std::shared_ptr<dmrgx_host::DevBuffer>> E; };
     std::map<std::pair<PetscInt, int>, WarmBasis> rdm_basis;
-    PetscBool use_rdm_warm = PETSC_TRUE;
+    PetscBool use_rdm_warm = PETSC_FALSE;
 };
 
 #endif

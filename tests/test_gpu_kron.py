@@ -459,10 +459,11 @@ def test_apply_degenerate_layouts_vs_dense_kron(mods):
         p.destroy()
 
 
-def test_rdm_warm_start_same_results_fewer_sweeps(mods):
-    """dmrgx_rdm_create_warm: starting the block-Jacobi iteration in the eigenbasis of a nearby state (the previous visit of
-    the block in a DMRG sweep) gives the same spectra and eigenvectors -- checked against LAPACK -- in fewer sweeps; a
-    useless (random orthogonal) basis is still correct."""
+def test_rdm_graded_spectrum_few_sweeps_and_warm_hints(mods):
+    """Density matrices with a decaying Schmidt spectrum (like a DMRG ground state): the QR-preconditioned block Jacobi
+    converges in a handful of sweeps (the unpreconditioned iteration needs 10-16 on such matrices), and
+    dmrgx_rdm_create_warm accepts any orthogonal starting basis -- the eigenbasis of a nearby state or a random one --
+    with the same spectra and eigenvectors, checked against LAPACK."""
     sbm, wl, _ = mods
     rng = np.random.default_rng(3)
     lsz, rsz = [40, 130, 77, 5], [64, 33, 150, 9]
@@ -485,7 +486,7 @@ def test_rdm_warm_start_same_results_fewer_sweeps(mods):
     warm1 = sbm.ReducedDensityMatrices(lsz, rsz, blocks, d1, warm=warm)
     junk = {key: torch.from_numpy(np.linalg.qr(rng.standard_normal(tuple(t.shape)))[0]).cuda().contiguous() for key, t in warm.items()}
     junk1 = sbm.ReducedDensityMatrices(lsz, rsz, blocks, d1, warm=junk)
-    assert warm1.sweeps < cold1.sweeps - 2, (warm1.sweeps, cold1.sweeps)
+    assert max(cold0.sweeps, cold1.sweeps, warm1.sweeps, junk1.sweeps) <= 6, (cold0.sweeps, cold1.sweeps, warm1.sweeps, junk1.sweeps)
     off = 0
     for k, (a, b) in enumerate(blocks):
         Psi = psi1[off:off + lsz[a] * rsz[b]].reshape(lsz[a], rsz[b]); off += lsz[a] * rsz[b]
