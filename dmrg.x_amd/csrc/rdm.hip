@@ -111,12 +111,22 @@ __device__ __forceinline__ void jacobi_rotation(double apq, double app, double a
 
 // Solve the JS x JS symmetric sub-problem of block pair (I,J) by cyclic Jacobi in LDS; R (row-major JS x JS) such
 // that R^T S R is diagonal is written to rbuf[pair].
+struct UpdTask { int32_t mat, p, q, kind; };     // p: pair index (kind 0) or row tile (kind 1); q: pair index (both local to mat)
+__device__ __forceinline__ void jacobi_update_body(double* sh, const MatDesc* __restrict__ mats, const int32_t* __restrict__ pair_start, const UpdTask t,
+                                                   double* __restrict__ buf, const double* __restrict__ rbuf, int round);
+
+// Workgroups [0, npairs): the sub-problems of round `round` (rotations to rbuf).  Workgroups past npairs: the eigenvector
+// updates V <- V R of the PREVIOUS round (vtasks, rbuf_prev, round_prev) -- nothing in this round depends on them, so they
+// fill the CUs that the latency-bound sub-solves leave idle instead of lengthening the update launch.
 __global__ void __launch_bounds__(SUB_THREADS)
-jacobi_sub_kernel(const MatDesc* __restrict__ mats, const PairRef* __restrict__ pairs, double* __restrict__ buf, double* __restrict__ rbuf, int round)
+jacobi_sub_kernel(const MatDesc* __restrict__ mats, const PairRef* __restrict__ pairs, int npairs, double* __restrict__ buf, double* __restrict__ rbuf, int round,
+                  const UpdTask* __restrict__ vtasks, const int32_t* __restrict__ pair_start, const double* __restrict__ rbuf_prev, int round_prev)
 {
-    __shared__ double S2[2][JS * JLD], R[JS * JLD];   // S is double-buffered: a round reads one copy and writes the other
+    __shared__ double sh[3 * JS * JLD];
     __shared__ double red0[SUB_THREADS / 64], red1[SUB_THREADS / 64];
-    double* S = S2[0];
+    if ((int)blockIdx.x >= npairs) { jacobi_update_body(sh, mats, pair_start, vtasks[blockIdx.x - npairs], buf, rbuf_prev, round_prev); return; }
+    double* S = sh;                                   // S is double-buffered: a round reads one copy and writes the other
+    double* R = sh + 2 * JS * JLD;
     const PairRef pr = pairs[blockIdx.x];
     const MatDesc m = mats[pr.mat];
     int I, J;
@@ -150,7 +160,7 @@ jacobi_sub_kernel(const MatDesc* __restrict__ mats, const PairRef* __restrict__ 
         // J_k^T . J_l to its block in registers -- one barrier per round, no serial parameter phase, no second pass
         // over S.  The same thread carries rows 2k, 2k+1 of R through J_l.
         const int k = tid / JB, l = tid % JB;
-        double* Sn = S2[1];
+        double* Sn = sh + JS * JLD;
         for (int rr = 0; rr < JS - 1; ++rr) {
             int pk, qk, pl, ql;
             jacobi_pair(rr, k, pk, qk);
@@ -199,13 +209,12 @@ __device__ __forceinline__ jd4 mfma_block(const double* L, const double* M, int 
 //                          column and the row update of the textbook formulation fuse into one pass over the upper
 //                          triangle, and A stays symmetric to the last bit;
 //   kind 1 (V, one-sided): rows [JS*t, JS*t+JS) x pair-block Q:      V[t,Q] <- V[t,Q] . R_Q
-struct UpdTask { int32_t mat, p, q, kind; };     // p: pair index (kind 0) or row tile (kind 1); q: pair index (both local to mat)
-__global__ void __launch_bounds__(256)
-jacobi_update_kernel(const MatDesc* __restrict__ mats, const int32_t* __restrict__ pair_start, const UpdTask* __restrict__ tasks,
-                     double* __restrict__ buf, const double* __restrict__ rbuf, int round)
+__device__ __forceinline__ void jacobi_update_body(double* sh, const MatDesc* __restrict__ mats, const int32_t* __restrict__ pair_start, const UpdTask t,
+                                                   double* __restrict__ buf, const double* __restrict__ rbuf, int round)
 {
-    __shared__ double X[JS * JLD], RQ[JS * JLD], RP[JS * JLD];
-    const UpdTask t = tasks[blockIdx.x];
+    double* X = sh;
+    double* RQ = sh + JS * JLD;
+    double* RP = sh + 2 * JS * JLD;
     const MatDesc m = mats[t.mat];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
     int IQ, JQ, IP = 0, JP = 0;
@@ -244,6 +253,14 @@ jacobi_update_kernel(const MatDesc* __restrict__ mats, const int32_t* __restrict
             M[(int64_t)cq(i) * m.npad + rp(j)] = X[j * JLD + i];
         }
     }
+}
+
+__global__ void __launch_bounds__(256)
+jacobi_update_kernel(const MatDesc* __restrict__ mats, const int32_t* __restrict__ pair_start, const UpdTask* __restrict__ tasks,
+                     double* __restrict__ buf, const double* __restrict__ rbuf, int round)
+{
+    __shared__ double sh[3 * JS * JLD];
+    jacobi_update_body(sh, mats, pair_start, tasks[blockIdx.x], buf, rbuf, round);
 }
 
 // per matrix and block of the grid: out[(mat*NORM_BLOCKS + b)*2] = partial sum of squares off the diagonal, [..+1] = on it
@@ -402,7 +419,7 @@ extern "C" dmrgx_status dmrgx_rdm_create_warm(const dmrgx_sectors* left, const d
     const int64_t psiT_off = total; total += N;
     const int nm = (int)P->mats.size();
     std::vector<PairRef> pairs;
-    std::vector<UpdTask> tiles;
+    std::vector<UpdTask> tiles, vtiles;      // A updates (on the critical path of a round) / V updates (ride along with the next round's sub-solves)
     std::vector<int32_t> pair_start(nm);
     int max_nb = 2;
     for (int mi = 0; mi < nm; ++mi) {
@@ -412,9 +429,9 @@ extern "C" dmrgx_status dmrgx_rdm_create_warm(const dmrgx_sectors* left, const d
         const int np = m.nb / 2;
         for (int j = 0; j < np; ++j) pairs.push_back(PairRef{mi, j});
         for (int p = 0; p < np; ++p) for (int q = p; q < np; ++q) tiles.push_back(UpdTask{mi, p, q, 0});     // upper triangle; the kernel mirrors
-        for (int t = 0; t < m.npad / JS; ++t) for (int q = 0; q < np; ++q) tiles.push_back(UpdTask{mi, t, q, 1});
+        for (int t = 0; t < m.npad / JS; ++t) for (int q = 0; q < np; ++q) vtiles.push_back(UpdTask{mi, t, q, 1});
     }
-    const int64_t rbuf_off = total; total += (int64_t)pairs.size() * JS * JS;
+    const int64_t rbuf_off = total, rbuf_len = (int64_t)pairs.size() * JS * JS; total += 2 * rbuf_len;    // two slots: round r and r-1
     const int64_t norm_off = total; total += 2 * nm * NORM_BLOCKS;
     std::vector<int64_t> diag_off(nm);
     int64_t dtot = 0;
@@ -447,10 +464,11 @@ extern "C" dmrgx_status dmrgx_rdm_create_warm(const dmrgx_sectors* left, const d
     for (int mi = 0; mi < nm; ++mi) if (warm_src[mi] || qmats[mi].n) { const int64_t nn = (int64_t)P->mats[mi].n * P->mats[mi].n; warm_w[mi] = total; total += nn; warm_et[mi] = total; total += nn; }
     DMRGX_CHK(P->buf.alloc((size_t)total * sizeof(double)));
     double* buf = P->buf.as<double>();
-    DevBuf d_pairs, d_tiles, d_doff, d_pstart;
+    DevBuf d_pairs, d_tiles, d_vtiles, d_doff, d_pstart;
     DMRGX_CHK(upload(P->d_mats, P->mats, st));
     DMRGX_CHK(upload(d_pairs, pairs, st));
     DMRGX_CHK(upload(d_tiles, tiles, st));
+    DMRGX_CHK(upload(d_vtiles, vtiles, st));
     DMRGX_CHK(upload(d_pstart, pair_start, st));
     for (auto& v : diag_off) v += diag_base;
     DMRGX_CHK(upload(d_doff, diag_off, st));
@@ -600,7 +618,8 @@ extern "C" dmrgx_status dmrgx_rdm_create_warm(const dmrgx_sectors* left, const d
     // ---- batched block Jacobi ------------------------------------------------------------------------------------
     std::vector<double> norms((size_t)2 * nm * NORM_BLOCKS);
     const int rounds = std::max(1, max_nb - 1);
-    int sweep = 0;
+    int sweep = 0, slot = 0, prev_round = 0;
+    bool pending_v = false;
     for (; sweep < 30; ++sweep) {
         hipLaunchKernelGGL(offnorm_kernel, dim3(NORM_BLOCKS, nm), dim3(256), 0, st, dm, buf, buf + norm_off);
         DMRGX_HIP(hipGetLastError());
@@ -620,10 +639,19 @@ extern "C" dmrgx_status dmrgx_rdm_create_warm(const dmrgx_sectors* left, const d
         if (trace) fprintf(stderr, "[rdm] sweep %d: max off^2/total^2 = %.3e\n", sweep, worst);
         if (conv) break;
         for (int r = 0; r < rounds; ++r) {
-            hipLaunchKernelGGL(jacobi_sub_kernel, dim3((unsigned)pairs.size()), dim3(SUB_THREADS), 0, st, dm, d_pairs.as<PairRef>(), buf, buf + rbuf_off, r);
-            hipLaunchKernelGGL(jacobi_update_kernel, dim3((unsigned)tiles.size()), dim3(256), 0, st, dm, d_pstart.as<int32_t>(), d_tiles.as<UpdTask>(), buf, buf + rbuf_off, r);
+            double* rcur = buf + rbuf_off + slot * rbuf_len;
+            const double* rprev = buf + rbuf_off + (slot ^ 1) * rbuf_len;
+            hipLaunchKernelGGL(jacobi_sub_kernel, dim3((unsigned)(pairs.size() + (pending_v ? vtiles.size() : 0))), dim3(SUB_THREADS), 0, st, dm, d_pairs.as<PairRef>(),
+                               (int)pairs.size(), buf, rcur, r, d_vtiles.as<UpdTask>(), d_pstart.as<int32_t>(), rprev, prev_round);
+            hipLaunchKernelGGL(jacobi_update_kernel, dim3((unsigned)tiles.size()), dim3(256), 0, st, dm, d_pstart.as<int32_t>(), d_tiles.as<UpdTask>(), buf, (const double*)rcur, r);
             DMRGX_HIP(hipGetLastError());
+            pending_v = !vtiles.empty(); prev_round = r; slot ^= 1;
         }
+    }
+    if (pending_v) {      // the eigenvector update of the very last round
+        hipLaunchKernelGGL(jacobi_update_kernel, dim3((unsigned)vtiles.size()), dim3(256), 0, st, dm, d_pstart.as<int32_t>(), d_vtiles.as<UpdTask>(), buf,
+                           (const double*)(buf + rbuf_off + (slot ^ 1) * rbuf_len), prev_round);
+        DMRGX_HIP(hipGetLastError());
     }
     P->sweeps = sweep;
     if (sweep >= 30) DMRGX_FAIL(DMRGX_ERR_NOTCONV, "rdm_create: block Jacobi did not converge in 30 sweeps");
