@@ -5,7 +5,7 @@ ARCH       ?= gfx950
 PKG        := dmrg.x_amd
 CSRC       := $(PKG)/csrc
 HIPFLAGS   := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude -I$(CSRC) -Wall -Wno-unused-function
-HIP_SRCS   := $(CSRC)/lib.hip $(CSRC)/ggemm.hip $(CSRC)/kron_plan.hip $(CSRC)/eigs.hip $(CSRC)/rdm.hip $(CSRC)/hqr.hip $(CSRC)/rotate.hip
+HIP_SRCS   := $(CSRC)/lib.hip $(CSRC)/pool.hip $(CSRC)/ggemm.hip $(CSRC)/kron_plan.hip $(CSRC)/eigs.hip $(CSRC)/rdm.hip $(CSRC)/hqr.hip $(CSRC)/rotate.hip
 HIP_OBJS   := $(HIP_SRCS:.hip=.o)
 
 HOST       := $(PKG)/host

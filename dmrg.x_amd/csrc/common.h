@@ -1,6 +1,7 @@
 // Internal helpers shared by the HIP translation units of libdmrgx_hip.so (not part of the ABI).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdint>
@@ -36,6 +37,12 @@ void set_error(const char* fmt, ...);
 // Stripe rule of the multi-GPU layout: rank w owns columns [stripe_cut(n,W,w), stripe_cut(n,W,w+1)) of a KronBlock.
 inline int32_t stripe_cut(int32_t n, int32_t W, int32_t w) { return (int32_t)(((int64_t)n * w) / W); }
 
+// Pooled device memory and a fill kernel (pool.hip): pool_free never synchronises, recycling is stream-ordered.
+hipError_t pool_malloc(void** out, size_t bytes);
+hipError_t pool_free(void* p);
+hipError_t zero_async(void* p, size_t bytes, hipStream_t st);
+hipError_t h2d_async(void* dst, const void* src, size_t bytes, hipStream_t st);   // pinned-ring staged, never blocks on the copy
+
 // RAII device buffer owned by a plan.
 struct DevBuf {
     void* p = nullptr;
@@ -47,19 +54,19 @@ struct DevBuf {
     dmrgx_status alloc(size_t n) {
         release();
         if (n == 0) return DMRGX_OK;
-        hipError_t e = hipMalloc(&p, n);
+        hipError_t e = pool_malloc(&p, n);
         if (e != hipSuccess) { p = nullptr; set_error("hipMalloc(%zu) failed: %s", n, hipGetErrorString(e)); return DMRGX_ERR_MEM; }
         bytes = n;
         return DMRGX_OK;
     }
-    void release() { if (p) { (void)hipFree(p); p = nullptr; bytes = 0; } }
+    void release() { if (p) { (void)pool_free(p); p = nullptr; bytes = 0; } }
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
 template <class T>
 dmrgx_status upload(DevBuf& buf, const std::vector<T>& host, hipStream_t st) {
     DMRGX_CHK(buf.alloc(host.size() * sizeof(T)));
-    if (!host.empty()) DMRGX_HIP(hipMemcpyAsync(buf.p, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice, st));
+    if (!host.empty()) DMRGX_HIP(h2d_async(buf.p, host.data(), host.size() * sizeof(T), st));
     return DMRGX_OK;
 }
 

@@ -327,9 +327,9 @@ extern "C" dmrgx_status dmrgx_eigs_lowest(dmrgx_kron_plan* plan, const dmrgx_eig
     double* nrm = c2 + (MAX_NCV + 2);                             // [1]
     auto Hrow = [&](int j) { return dScal.as<double>() + (size_t)j * row; };
     auto vec = [&](int j) { return V + (size_t)j * n; };
-    DMRGX_HIP(hipMemsetAsync(dV.p, 0, dV.bytes, st));
-    DMRGX_HIP(hipMemsetAsync(dW.p, 0, dW.bytes, st));
-    if (dist) DMRGX_HIP(hipMemsetAsync(dX.p, 0, dX.bytes, st));
+    DMRGX_HIP(zero_async(dV.p, dV.bytes, st));
+    DMRGX_HIP(zero_async(dW.p, dW.bytes, st));
+    if (dist) DMRGX_HIP(zero_async(dX.p, dX.bytes, st));
 
     const bool vec2 = (n % 2 == 0);                     // all vectors are whole allocations (256-byte aligned) of stride n
     const int nblk = DOT_BLOCKS;      // (scaling the grid down with n was measured slower even at n = 1.6e5: these passes are latency-bound)
@@ -391,7 +391,7 @@ extern "C" dmrgx_status dmrgx_eigs_lowest(dmrgx_kron_plan* plan, const dmrgx_eig
     double beta_m = 0.0, resid = 0.0, lambda = 0.0;
     std::vector<double> Qdev;
     while (true) {
-        DMRGX_HIP(hipMemsetAsync(Hrow(k), 0, (size_t)(m + 1 - k) * row * sizeof(double), st));
+        DMRGX_HIP(zero_async(Hrow(k), (size_t)(m + 1 - k) * row * sizeof(double), st));
         int jend = m;                                         // benchmark mode: stop after exactly max_matvec MatMults
         if (opts->max_matvec > 0) jend = std::min(m, k + std::max(0, opts->max_matvec - n_matvec));
         const bool capped = jend < m || (opts->max_matvec > 0 && n_matvec + (m - k) >= opts->max_matvec);
@@ -467,7 +467,7 @@ extern "C" dmrgx_status dmrgx_eigs_lowest(dmrgx_kron_plan* plan, const dmrgx_eig
         const int kk = std::max(1, std::min(m / 2, m - 1));
         Qdev.assign((size_t)m * kk, 0.0);
         for (int i = 0; i < m; ++i) for (int j = 0; j < kk; ++j) Qdev[(size_t)i * kk + j] = Q[(size_t)i * m + j];
-        DMRGX_HIP(hipMemcpyAsync(dQ.p, Qdev.data(), Qdev.size() * sizeof(double), hipMemcpyHostToDevice, st));
+        DMRGX_HIP(h2d_async(dQ.p, Qdev.data(), Qdev.size() * sizeof(double), st));
         hipLaunchKernelGGL(basis_rotate_kernel, dim3(1024, (kk + DOT_CHUNK - 1) / DOT_CHUNK), dim3(DOT_THREADS), 0, st,
                            V, n, m, dQ.as<double>(), kk, kk, dTmp.as<double>(), n, n);
         DMRGX_HIP(hipGetLastError());
@@ -481,7 +481,7 @@ extern "C" dmrgx_status dmrgx_eigs_lowest(dmrgx_kron_plan* plan, const dmrgx_eig
     // ---- eigenvector: psi = V_m Q[:,0], renormalised -------------------------------------------------------
     Qdev.assign((size_t)m, 0.0);
     for (int i = 0; i < m; ++i) Qdev[i] = Q[(size_t)i * m + 0];
-    DMRGX_HIP(hipMemcpyAsync(dQ.p, Qdev.data(), Qdev.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    DMRGX_HIP(h2d_async(dQ.p, Qdev.data(), Qdev.size() * sizeof(double), st));
     hipLaunchKernelGGL(basis_rotate_kernel, dim3(1024, 1), dim3(DOT_THREADS), 0, st, V, n, m, dQ.as<double>(), 1, 1, w, n, n);
     DMRGX_HIP(hipGetLastError());
     DMRGX_CHK(multi_dot(0));

@@ -607,7 +607,7 @@ extern "C" dmrgx_status dmrgx_kron_plan_create(const dmrgx_kron_desc* d, void* s
     P->world = W; P->rank = me;
     DMRGX_CHK(P->arena.alloc((size_t)std::max<int64_t>(arena_ops + arena_T + arena_slabs, 1) * sizeof(double)));
     P->n_red_tiles = (int32_t)B.red_tiles.size();
-    DMRGX_HIP(hipMemsetAsync(P->arena.p, 0, P->arena.bytes, st));
+    DMRGX_HIP(zero_async(P->arena.p, P->arena.bytes, st));
     {   // operator copies, one launch per accumulation round
         int32_t max_round = -1;
         for (auto& c : copies) max_round = std::max(max_round, c.round);

@@ -100,19 +100,19 @@ extern "C" dmrgx_status dmrgx_malloc(void** p, size_t bytes)
     if (!p) DMRGX_FAIL(DMRGX_ERR_ARG, "malloc: null argument");
     *p = nullptr;
     if (bytes == 0) return DMRGX_OK;
-    hipError_t e = hipMalloc(p, bytes);
+    hipError_t e = dmrgx::pool_malloc(p, bytes);
     if (e != hipSuccess) { *p = nullptr; DMRGX_FAIL(DMRGX_ERR_MEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); }
     return DMRGX_OK;
 }
-extern "C" dmrgx_status dmrgx_free(void* p) { if (p) DMRGX_HIP(hipFree(p)); return DMRGX_OK; }
+extern "C" dmrgx_status dmrgx_free(void* p) { if (p) DMRGX_HIP(dmrgx::pool_free(p)); return DMRGX_OK; }
 extern "C" dmrgx_status dmrgx_memcpy_h2d(void* d, const void* s, size_t n, void* st)
-{ if (n) DMRGX_HIP(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, (hipStream_t)st)); return DMRGX_OK; }
+{ if (n) DMRGX_HIP(dmrgx::h2d_async(d, s, n, (hipStream_t)st)); return DMRGX_OK; }
 extern "C" dmrgx_status dmrgx_memcpy_d2h(void* d, const void* s, size_t n, void* st)
 { if (n) { DMRGX_HIP(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, (hipStream_t)st)); DMRGX_HIP(hipStreamSynchronize((hipStream_t)st)); } return DMRGX_OK; }
 extern "C" dmrgx_status dmrgx_memcpy_d2d(void* d, const void* s, size_t n, void* st)
 { if (n) DMRGX_HIP(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, (hipStream_t)st)); return DMRGX_OK; }
 extern "C" dmrgx_status dmrgx_memset_zero(void* d, size_t n, void* st)
-{ if (n) DMRGX_HIP(hipMemsetAsync(d, 0, n, (hipStream_t)st)); return DMRGX_OK; }
+{ if (n) DMRGX_HIP(dmrgx::zero_async(d, n, (hipStream_t)st)); return DMRGX_OK; }
 extern "C" dmrgx_status dmrgx_stream_sync(void* st) { DMRGX_HIP(hipStreamSynchronize((hipStream_t)st)); return DMRGX_OK; }
 
 // ---- <x, y> on the device (correlators: VecDot of the reference, include/DMRGBlockContainer.hpp:2291) ------------------

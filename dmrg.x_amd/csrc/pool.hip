@@ -1,0 +1,127 @@
+// Device-memory pool and fill kernel of libdmrgx_hip.so.
+//
+// A sweep step creates and drops thousands of small device buffers (operator cells, task tables, work arrays).  hipFree
+// synchronises the device and hipMemsetAsync costs ~80 us of host time per call on this stack; together they kept the GPU
+// idle for half of a small-m step.  Freed blocks are therefore cached by size class and handed out again without touching
+// the driver.  Recycling is stream-ordered: every operation of the library that touches a block is enqueued on a stream, so
+// a block freed while work is still queued is only overwritten by work queued later ON THE SAME STREAM.  The engine and the
+// Python wrappers use one stream (the null stream); a caller that moves between streams synchronises in between
+// (dmrgx_stream_sync) -- see include/dmrgx.h.  DMRGX_POOL=0 disables caching (every free is a hipFree again).
+#include "common.h"
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <unordered_map>
+
+namespace dmrgx {
+namespace {
+
+struct Pool {
+    std::mutex mu;
+    std::map<size_t, std::vector<void*>> free_by_size;
+    std::unordered_map<void*, size_t> size_of;       // every block handed out or cached
+    size_t cached = 0;
+    const bool enabled = !(getenv("DMRGX_POOL") && atoi(getenv("DMRGX_POOL")) == 0);
+    const size_t cache_limit = (size_t)(getenv("DMRGX_POOL_LIMIT_GB") ? atof(getenv("DMRGX_POOL_LIMIT_GB")) : 96.0) << 30;
+
+    static size_t size_class(size_t n) {
+        if (n <= 512) return 512;
+        if (n <= ((size_t)1 << 20)) { size_t c = 512; while (c < n) c <<= 1; return c; }          // powers of two up to 1 MiB
+        const size_t step = n <= ((size_t)64 << 20) ? ((size_t)1 << 20) : ((size_t)16 << 20);       // then 1 MiB / 16 MiB steps
+        return (n + step - 1) / step * step;
+    }
+    void trim_locked() {                              // give everything cached back to the driver
+        (void)hipDeviceSynchronize();
+        for (auto& kv : free_by_size) for (void* p : kv.second) { size_of.erase(p); (void)hipFree(p); }
+        free_by_size.clear();
+        cached = 0;
+    }
+};
+Pool& pool() { static Pool* p = new Pool(); return *p; }    // leaked on purpose: no teardown order issues with the HIP runtime
+
+__global__ void __launch_bounds__(256) zero_kernel(uint64_t* __restrict__ p, size_t n)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = 0;
+}
+
+}  // namespace
+
+hipError_t pool_malloc(void** out, size_t bytes)
+{
+    Pool& P = pool();
+    *out = nullptr;
+    if (bytes == 0) return hipSuccess;
+    if (!P.enabled) return hipMalloc(out, bytes);
+    const size_t c = Pool::size_class(bytes);
+    std::lock_guard<std::mutex> lock(P.mu);
+    auto it = P.free_by_size.find(c);
+    if (it != P.free_by_size.end() && !it->second.empty()) {
+        *out = it->second.back();
+        it->second.pop_back();
+        P.cached -= c;
+        return hipSuccess;
+    }
+    hipError_t e = hipMalloc(out, c);
+    if (e != hipSuccess) {                            // out of memory with blocks cached: release them and try once more
+        (void)hipGetLastError();
+        P.trim_locked();
+        e = hipMalloc(out, c);
+    }
+    if (e == hipSuccess) P.size_of[*out] = c;
+    else *out = nullptr;
+    return e;
+}
+
+hipError_t pool_free(void* p)
+{
+    if (!p) return hipSuccess;
+    Pool& P = pool();
+    if (!P.enabled) return hipFree(p);
+    std::lock_guard<std::mutex> lock(P.mu);
+    auto it = P.size_of.find(p);
+    if (it == P.size_of.end()) return hipFree(p);     // not ours
+    P.free_by_size[it->second].push_back(p);
+    P.cached += it->second;
+    if (P.cached > P.cache_limit) P.trim_locked();
+    return hipSuccess;
+}
+
+// Host -> device copies of task tables and small operands: staged through a pinned ring so that the copy is a true
+// asynchronous DMA (a hipMemcpyAsync from pageable memory blocks the host for ~20 us per call).  The ring is reused after a
+// device-wide synchronisation at wrap-around, i.e. once every H2D_RING_BYTES of uploads.
+namespace {
+constexpr size_t H2D_RING_BYTES = (size_t)64 << 20, H2D_MAX_STAGED = (size_t)4 << 20;
+struct Ring { std::mutex mu; char* base = nullptr; size_t head = 0; bool failed = false; };
+Ring& ring() { static Ring* r = new Ring(); return *r; }
+}  // namespace
+
+hipError_t h2d_async(void* dst, const void* src, size_t bytes, hipStream_t st)
+{
+    if (bytes == 0) return hipSuccess;
+    Ring& R = ring();
+    if (bytes <= H2D_MAX_STAGED && !R.failed) {
+        std::lock_guard<std::mutex> lock(R.mu);
+        if (!R.base) { if (hipHostMalloc((void**)&R.base, H2D_RING_BYTES, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); R.base = nullptr; R.failed = true; } }
+        if (R.base) {
+            const size_t need = (bytes + 255) & ~(size_t)255;
+            if (R.head + need > H2D_RING_BYTES) { hipError_t e = hipDeviceSynchronize(); if (e != hipSuccess) return e; R.head = 0; }
+            char* slot = R.base + R.head;
+            R.head += need;
+            memcpy(slot, src, bytes);
+            return hipMemcpyAsync(dst, slot, bytes, hipMemcpyHostToDevice, st);
+        }
+    }
+    return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st);
+}
+
+hipError_t zero_async(void* p, size_t bytes, hipStream_t st)
+{
+    if (bytes == 0) return hipSuccess;
+    if (((uintptr_t)p & 7) || (bytes & 7)) return hipMemsetAsync(p, 0, bytes, st);
+    const size_t n = bytes / 8;
+    const unsigned grid = (unsigned)std::min<size_t>(2048, (n + 255) / 256);
+    hipLaunchKernelGGL(zero_kernel, dim3(grid), dim3(256), 0, st, (uint64_t*)p, n);
+    return hipGetLastError();
+}
+
+}  // namespace dmrgx

@@ -692,7 +692,7 @@ extern "C" dmrgx_status dmrgx_rdm_create_warm(const dmrgx_sectors* left, const d
         DevBuf dp, dg, dt, db, dc;
         DMRGX_CHK(upload(dp, prods, st)); DMRGX_CHK(upload(dg, groups, st)); DMRGX_CHK(upload(dt, gt, st)); DMRGX_CHK(upload(db, gb, st));
         DMRGX_CHK(upload(dc, cn, st));
-        DMRGX_HIP(hipMemsetAsync(buf + rq_base, 0, (size_t)dtot * sizeof(double), st));
+        DMRGX_HIP(zero_async(buf + rq_base, (size_t)dtot * sizeof(double), st));
         DMRGX_CHK(ggemm_launch(db.as<GTile>(), dg.as<GGroup>(), dp.as<GProd>(), (int32_t)gb.size(), st, 1));
         DMRGX_CHK(ggemm_launch(dt.as<GTile>(), dg.as<GGroup>(), dp.as<GProd>(), (int32_t)gt.size(), st, 0));
         int maxc = 1;

@@ -139,7 +139,7 @@ extern "C" dmrgx_status dmrgx_rotate_ops(const dmrgx_sectors* old_sectors, const
     double* W = UT + ut_off[nn];
     {
         std::vector<dmrgx_axpy_task> tr(nn);
-        DMRGX_HIP(hipMemsetAsync(UT, 0, (size_t)ut_off[nn] * sizeof(double), st));
+        DMRGX_HIP(zero_async(UT, (size_t)ut_off[nn] * sizeof(double), st));
         for (int32_t a = 0; a < nn; ++a) {
             const int32_t nq = old_sectors->size[rot->old_sector[a]], m = rot->kept[a];
             tr[a] = dmrgx_axpy_task{UT + ut_off[a], nullptr, rot->rot_t[a], m, nq, nq, m, 1, 1.0};

@@ -202,10 +202,11 @@ typedef struct dmrgx_rdm dmrgx_rdm;
 dmrgx_status dmrgx_rdm_create(const dmrgx_sectors* left, const dmrgx_sectors* right, int32_t nblocks,
                               const int32_t* block_il, const int32_t* block_ir, const double* psi_dev,
                               void* stream, dmrgx_rdm** out);
-/* The same with a warm start: v0_rows[2*k + side] is NULL or a device pointer to an n x n row-major ORTHOGONAL matrix whose
+/* The same with a starting basis: v0_rows[2*k + side] is NULL or a device pointer to an n x n row-major ORTHOGONAL matrix whose
  * rows approximately diagonalise that block's density matrix (the rows written by dmrgx_rdm_eigenvectors(count = n) at the
- * previous visit of the same block).  The matrix is transformed into that basis before the Jacobi iteration; results do
- * not depend on v0_rows, only the number of Jacobi sweeps does. */
+ * previous visit of the same block).  Results do not depend on v0_rows, only the number of Jacobi sweeps can.  It is a
+ * hint: the default solver preconditions every matrix with one Householder-QR step on the sorted matrix (csrc/hqr.hip),
+ * which supersedes it; with DMRGX_RDM_QR=0 the matrix is transformed into the supplied basis before the iteration. */
 dmrgx_status dmrgx_rdm_create_warm(const dmrgx_sectors* left, const dmrgx_sectors* right, int32_t nblocks,
                                    const int32_t* block_il, const int32_t* block_ir, const double* psi_dev,
                                    const double* const* v0_rows, void* stream, dmrgx_rdm** out);
@@ -244,6 +245,10 @@ dmrgx_status dmrgx_rotate_ops(const dmrgx_sectors* old_sectors, const dmrgx_rota
                               const dmrgx_secop* src_ops, double* const* const* dst_blocks, void* stream);
 
 /* ---- device memory (so that the host engine needs no HIP headers) ------------------------------------------ */
+/* Blocks come from a size-class pool inside the library: dmrgx_free never synchronises the device, and a freed block is
+ * recycled in STREAM ORDER -- work already queued on it may still be running, the next owner's operations are queued
+ * behind it on the same stream.  A caller that frees on one stream and reuses on another calls dmrgx_stream_sync in
+ * between (the engine and the Python wrappers use a single stream).  DMRGX_POOL=0 makes every free a plain hipFree. */
 dmrgx_status dmrgx_malloc(void** dev_ptr, size_t bytes);
 dmrgx_status dmrgx_free(void* dev_ptr);
 dmrgx_status dmrgx_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes, void* stream);
