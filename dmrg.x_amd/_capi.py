@@ -120,6 +120,7 @@ SIGNATURES = {
     "dmrgx_stream_sync": (C.c_int32, [C.c_void_p]),
     "dmrgx_dgemm_batch": (C.c_int32, [C.c_int32, C.c_void_p, C.c_void_p]),
     "dmrgx_dot": (C.c_int32, [C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.c_void_p]),
+    "dmrgx_dot_async": (C.c_int32, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dmrgx_eigs_lowest": (C.c_int32, [C.c_void_p, C.POINTER(EigsOpts), C.POINTER(C.c_double), C.c_void_p,
                                       C.POINTER(EigsStats), C.c_void_p]),
 }

@@ -623,9 +623,7 @@ extern "C" dmrgx_status dmrgx_kron_plan_create(const dmrgx_kron_desc* d, void* s
             DMRGX_CHK(upload(d_ct, ct, st));
             hipLaunchKernelGGL(cell_copy_kernel, dim3((unsigned)ct.size()), dim3(256), 0, st, d_ct.as<CopyTile>(), d_tasks.as<CopyTask>(), P->arena.as<double>());
             DMRGX_HIP(hipGetLastError());
-            DMRGX_HIP(hipStreamSynchronize(st));   // d_ct is freed at scope exit
         }
-        DMRGX_HIP(hipStreamSynchronize(st));
     }
     P->nprods = (int32_t)B.prods.size(); P->ngroups = (int32_t)B.groups.size();
     P->ntiles1 = (int32_t)B.tiles1.size(); P->ntiles2 = (int32_t)B.tiles2.size();
@@ -647,7 +645,6 @@ extern "C" dmrgx_status dmrgx_kron_plan_create(const dmrgx_kron_desc* d, void* s
         P->nlayout = (int32_t)segs.size();
         DMRGX_CHK(upload(P->d_layout, segs, st));
     }
-    DMRGX_HIP(hipStreamSynchronize(st));
 
     dmrgx_kron_info& I = P->info;
     I.n_states = N; I.vec_len = (W == 1) ? N : (int64_t)W * seg_stride; I.local_offset = (int64_t)me * seg_stride;

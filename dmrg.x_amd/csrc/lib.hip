@@ -60,7 +60,6 @@ extern "C" dmrgx_status dmrgx_dgemm_nn(int32_t M, int32_t N, int32_t K, const do
     DMRGX_CHK(upload(db, big, st));
     DMRGX_CHK(ggemm_launch(db.as<GTile>(), dg.as<GGroup>(), dp.as<GProd>(), (int32_t)big.size(), st, 1));
     DMRGX_CHK(ggemm_launch(dt.as<GTile>(), dg.as<GGroup>(), dp.as<GProd>(), (int32_t)tiles.size(), st, 0));
-    DMRGX_HIP(hipStreamSynchronize(st));   // tables are freed on return
     return DMRGX_OK;
 }
 
@@ -91,7 +90,6 @@ extern "C" dmrgx_status dmrgx_dgemm_batch(int32_t count, const dmrgx_gemm_task* 
     DMRGX_CHK(upload(db, big, st));
     DMRGX_CHK(ggemm_launch(db.as<GTile>(), dg.as<GGroup>(), dp.as<GProd>(), (int32_t)big.size(), st, 1));
     DMRGX_CHK(ggemm_launch(dt.as<GTile>(), dg.as<GGroup>(), dp.as<GProd>(), (int32_t)tiles.size(), st, 0));
-    DMRGX_HIP(hipStreamSynchronize(st));   // tables are freed on return
     return DMRGX_OK;
 }
 
@@ -131,6 +129,28 @@ __global__ void __launch_bounds__(VDOT_THREADS) vdot_partial_kernel(const double
 }
 }  // namespace
 }  // namespace dmrgx
+
+namespace dmrgx {
+namespace {
+__global__ void __launch_bounds__(64) vdot_final_kernel(const double* __restrict__ partial, double* __restrict__ out)
+{
+    if (threadIdx.x == 0) { double t = 0.0; for (int k = 0; k < VDOT_BLOCKS; ++k) t += partial[k]; out[0] = t; }    // same order as the host sum of dmrgx_dot
+}
+}  // namespace
+}  // namespace dmrgx
+
+extern "C" dmrgx_status dmrgx_dot_async(int64_t n, const double* x_dev, const double* y_dev, double* dev_out, void* stream)
+{
+    if (n < 0 || !dev_out || (n > 0 && (!x_dev || !y_dev))) DMRGX_FAIL(DMRGX_ERR_ARG, "dot_async: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (n == 0) { DMRGX_HIP(zero_async(dev_out, sizeof(double), st)); return DMRGX_OK; }
+    DevBuf part;                                      // returned to the pool on exit; recycling is stream-ordered
+    DMRGX_CHK(part.alloc(dmrgx::VDOT_BLOCKS * sizeof(double)));
+    hipLaunchKernelGGL(dmrgx::vdot_partial_kernel, dim3(dmrgx::VDOT_BLOCKS), dim3(dmrgx::VDOT_THREADS), 0, st, x_dev, y_dev, n, part.as<double>());
+    hipLaunchKernelGGL(dmrgx::vdot_final_kernel, dim3(1), dim3(64), 0, st, (const double*)part.as<double>(), dev_out);
+    DMRGX_HIP(hipGetLastError());
+    return DMRGX_OK;
+}
 
 extern "C" dmrgx_status dmrgx_dot(int64_t n, const double* x_dev, const double* y_dev, double* host_out, void* stream)
 {

@@ -111,7 +111,9 @@ hipError_t h2d_async(void* dst, const void* src, size_t bytes, hipStream_t st)
             return hipMemcpyAsync(dst, slot, bytes, hipMemcpyHostToDevice, st);
         }
     }
-    return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st);
+    // large or unstaged: the source must outlive the copy and the callers drop it on return
+    hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st);
+    return e != hipSuccess ? e : hipStreamSynchronize(st);
 }
 
 hipError_t zero_async(void* p, size_t bytes, hipStream_t st)

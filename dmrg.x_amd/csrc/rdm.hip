@@ -510,7 +510,6 @@ extern "C" dmrgx_status dmrgx_rdm_create_warm(const dmrgx_sectors* left, const d
         DMRGX_CHK(upload(dp, prods, st)); DMRGX_CHK(upload(dg, groups, st)); DMRGX_CHK(upload(dt, gt, st)); DMRGX_CHK(upload(db, gb, st));
         DMRGX_CHK(ggemm_launch(db.as<GTile>(), dg.as<GGroup>(), dp.as<GProd>(), (int32_t)gb.size(), st, 1));
         DMRGX_CHK(ggemm_launch(dt.as<GTile>(), dg.as<GGroup>(), dp.as<GProd>(), (int32_t)gt.size(), st, 0));
-        DMRGX_HIP(hipStreamSynchronize(st));
     }
 
     if (const char* dump = getenv("DMRGX_RDM_DUMP")) {      // developer aid: the density matrices of one call, for offline convergence studies
@@ -567,7 +566,6 @@ extern "C" dmrgx_status dmrgx_rdm_create_warm(const dmrgx_sectors* left, const d
         DMRGX_CHK(hqr_batched(qmats, d_qm.as<HqrMat>(), buf, st));
         hipLaunchKernelGGL(qr_scatter_kernel, dim3(gx, nm), dim3(256), 0, st, d_qm.as<HqrMat>(), d_qperm.as<int32_t>(), d_qpoff.as<int64_t>(), d_qeoff.as<int64_t>(), buf);
         DMRGX_HIP(hipGetLastError());
-        DMRGX_HIP(hipStreamSynchronize(st));      // tables are freed at scope exit
     }
     bool any_warm = false;
     for (int mi = 0; mi < nm; ++mi) any_warm = any_warm || warm_src[mi];
@@ -611,7 +609,6 @@ extern "C" dmrgx_status dmrgx_rdm_create_warm(const dmrgx_sectors* left, const d
                 DMRGX_HIP(hipMemcpy2DAsync(buf + m.v_off, (size_t)m.npad * sizeof(double), buf + warm_et[mi], (size_t)m.n * sizeof(double),
                                            (size_t)m.n * sizeof(double), (size_t)m.n, hipMemcpyDeviceToDevice, st));
             }
-            DMRGX_HIP(hipStreamSynchronize(st));      // tables are freed at scope exit
         }
     }
 
@@ -720,7 +717,6 @@ extern "C" dmrgx_status dmrgx_rdm_create_warm(const dmrgx_sectors* left, const d
         allperm.insert(allperm.end(), real.begin(), real.end());
     }
     DMRGX_CHK(upload(P->d_perm, allperm, st));
-    DMRGX_HIP(hipStreamSynchronize(st));
     *out = P.release();
     return DMRGX_OK;
 }

@@ -89,7 +89,6 @@ extern "C" dmrgx_status dmrgx_cells_axpy(int32_t n, const dmrgx_axpy_task* tasks
         DMRGX_CHK(upload(d_tl, tl, st));
         hipLaunchKernelGGL(cells_axpy_kernel, dim3((unsigned)tl.size()), dim3(256), 0, st, d_tl.as<AxTile>(), d_tasks.as<AxTask>());
         DMRGX_HIP(hipGetLastError());
-        DMRGX_HIP(hipStreamSynchronize(st));
     }
     return DMRGX_OK;
 }
@@ -191,6 +190,5 @@ extern "C" dmrgx_status dmrgx_rotate_ops(const dmrgx_sectors* old_sectors, const
     DMRGX_CHK(ggemm_launch(d2.as<GTile>(), dg.as<GGroup>(), dp.as<GProd>(), (int32_t)tA.size(), st, 0));
     DMRGX_CHK(ggemm_launch(d3.as<GTile>(), dg.as<GGroup>(), dp.as<GProd>(), (int32_t)tBb.size(), st, 1));
     DMRGX_CHK(ggemm_launch(d4.as<GTile>(), dg.as<GGroup>(), dp.as<GProd>(), (int32_t)tB.size(), st, 0));
-    DMRGX_HIP(hipStreamSynchronize(st));     // tables and the workspace are released on return
     return DMRGX_OK;
 }

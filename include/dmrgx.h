@@ -157,7 +157,7 @@ dmrgx_status dmrgx_dgemm_nn(int32_t M, int32_t N, int32_t K, const double* A, in
                             const double* B, int64_t ldb, double* C, int64_t ldc, void* stream);
 /* The same for `count` independent products in one grouped launch (operator products per sector block, correlators:
  * the MatMatMult calls of include/DMRGBlockContainer.hpp:2378-2395).  accumulate != 0: C += A*B.  Outputs must not
- * overlap. */
+ * overlap.  Both GEMM entry points are asynchronous on `stream` (the task array itself is consumed before returning). */
 typedef struct {
     int32_t M, N, K, accumulate;
     const double* A; int64_t lda;
@@ -259,6 +259,9 @@ dmrgx_status dmrgx_stream_sync(void* stream);
 /* *host_out = <x, y> (device vectors, fixed summation order); replaces VecDot in the correlator path
  * (include/DMRGBlockContainer.hpp:2287-2293).  Synchronises the stream. */
 dmrgx_status dmrgx_dot(int64_t n, const double* x_dev, const double* y_dev, double* host_out, void* stream);
+/* The same without the synchronisation: the sum (same summation order) is written to dev_out[0] in stream order -- lets a
+ * caller queue many expectation values and fetch them with one dmrgx_memcpy_d2h. */
+dmrgx_status dmrgx_dot_async(int64_t n, const double* x_dev, const double* y_dev, double* dev_out, void* stream);
 
 #ifdef __cplusplus
 }

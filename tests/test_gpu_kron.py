@@ -342,7 +342,11 @@ def test_device_dot_product(pkg):
         assert L.dmrgx_dot(n, xd.data_ptr(), yd.data_ptr(), C.byref(out2), None) == 0
         assert out1.value == out2.value
         assert abs(out1.value - float(x @ y)) <= 1e-12 * np.sqrt(n) * max(1.0, abs(float(x @ y)))
+        dev = torch.full((3,), -1.0, dtype=torch.float64, device="cuda")      # queued form: same bits, written in stream order
+        assert L.dmrgx_dot_async(n, xd.data_ptr(), yd.data_ptr(), dev.data_ptr() + 8, None) == 0
+        assert dev.cpu().tolist() == [-1.0, out1.value, -1.0]
     assert L.dmrgx_dot(-1, None, None, C.byref(out1), None) == 62
+    assert L.dmrgx_dot_async(5, None, None, None, None) == 62
 
 
 def test_dgemm_batch_matches_numpy(pkg):
