@@ -186,9 +186,24 @@ extern "C" dmrgx_status dmrgx_rotate_ops(const dmrgx_sectors* old_sectors, const
     DevBuf dp, dg, d1, d2, d3, d4;
     DMRGX_CHK(upload(dp, prods, st)); DMRGX_CHK(upload(dg, groups, st));
     DMRGX_CHK(upload(d1, tAb, st)); DMRGX_CHK(upload(d2, tA, st)); DMRGX_CHK(upload(d3, tBb, st)); DMRGX_CHK(upload(d4, tB, st));
+    static const bool trace = getenv("DMRGX_ROT_TRACE") != nullptr;      // developer aid: flops and time of the two stages
+    hipEvent_t ev[3];
+    if (trace) { for (auto& e : ev) DMRGX_HIP(hipEventCreate(&e)); DMRGX_HIP(hipEventRecord(ev[0], st)); }
     DMRGX_CHK(ggemm_launch(d1.as<GTile>(), dg.as<GGroup>(), dp.as<GProd>(), (int32_t)tAb.size(), st, 1));
     DMRGX_CHK(ggemm_launch(d2.as<GTile>(), dg.as<GGroup>(), dp.as<GProd>(), (int32_t)tA.size(), st, 0));
+    if (trace) DMRGX_HIP(hipEventRecord(ev[1], st));
     DMRGX_CHK(ggemm_launch(d3.as<GTile>(), dg.as<GGroup>(), dp.as<GProd>(), (int32_t)tBb.size(), st, 1));
     DMRGX_CHK(ggemm_launch(d4.as<GTile>(), dg.as<GGroup>(), dp.as<GProd>(), (int32_t)tB.size(), st, 0));
+    if (trace) {
+        DMRGX_HIP(hipEventRecord(ev[2], st));
+        DMRGX_HIP(hipEventSynchronize(ev[2]));
+        double fa = 0, fb = 0;
+        for (const GGroup& g : groups) for (int32_t q = g.prod_begin + g.n_axpy; q < g.prod_end; ++q) ((&g - groups.data()) < (ptrdiff_t)wrefs.size() ? fa : fb) += 2.0 * g.M * g.N * prods[q].K;
+        float ma = 0, mb = 0;
+        DMRGX_HIP(hipEventElapsedTime(&ma, ev[0], ev[1])); DMRGX_HIP(hipEventElapsedTime(&mb, ev[1], ev[2]));
+        fprintf(stderr, "[rotate] %d ops: stage A %.2f GF %.3f ms (%.1f TF/s, tiles %zu+%zu big), stage B %.2f GF %.3f ms (%.1f TF/s, tiles %zu+%zu big)\n", nops,
+                fa * 1e-9, ma, fa / (ma * 1e9), tA.size(), tAb.size(), fb * 1e-9, mb, fb / (mb * 1e9), tB.size(), tBb.size());
+        for (auto& e : ev) (void)hipEventDestroy(e);
+    }
     return DMRGX_OK;
 }
