@@ -62,6 +62,10 @@ class AxpyTask(C.Structure):
                 ("nr", C.c_int32), ("nc", C.c_int32), ("transposed", C.c_int32), ("alpha", C.c_double)]
 
 
+class Dot2dTask(C.Structure):
+    _fields_ = [("a", C.c_void_p), ("lda", C.c_int64), ("b", C.c_void_p), ("ldb", C.c_int64), ("nr", C.c_int32), ("nc", C.c_int32), ("out", C.c_int32), ("pad", C.c_int32)]
+
+
 class GemmTask(C.Structure):
     _fields_ = [("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("accumulate", C.c_int32),
                 ("A", C.c_void_p), ("lda", C.c_int64), ("B", C.c_void_p), ("ldb", C.c_int64), ("C", C.c_void_p), ("ldc", C.c_int64)]
@@ -121,6 +125,7 @@ SIGNATURES = {
     "dmrgx_dgemm_batch": (C.c_int32, [C.c_int32, C.c_void_p, C.c_void_p]),
     "dmrgx_dot": (C.c_int32, [C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.c_void_p]),
     "dmrgx_dot_async": (C.c_int32, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dmrgx_dot2d_batch": (C.c_int32, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dmrgx_eigs_lowest": (C.c_int32, [C.c_void_p, C.POINTER(EigsOpts), C.POINTER(C.c_double), C.c_void_p,
                                       C.POINTER(EigsStats), C.c_void_p]),
 }

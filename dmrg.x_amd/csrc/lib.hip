@@ -1,5 +1,6 @@
 // libdmrgx_hip.so: library-level entry points (error reporting, device probe, plain GEMM wrapper).
 #include "ggemm.h"
+#include <algorithm>
 
 namespace dmrgx {
 static thread_local std::string g_last_error;
@@ -168,5 +169,68 @@ extern "C" dmrgx_status dmrgx_dot(int64_t n, const double* x_dev, const double* 
     double t = 0.0;
     for (double v : h) t += v;          // fixed order: reproducible
     *host_out = t;
+    return DMRGX_OK;
+}
+
+// ---- many Frobenius inner products in one launch (correlators of operators living on one block: <psi|P (x) 1|psi> =
+//      sum_k <P[IL(k)], X_k X_k^T>_F, so a table of correlators is one batch of 2-D dot products against the Gram blocks) -----
+namespace dmrgx {
+namespace {
+struct Dot2dPiece { const double* a; const double* b; int64_t lda, ldb; int32_t nr, nc; };
+__global__ void __launch_bounds__(256) dot2d_partial_kernel(const Dot2dPiece* __restrict__ pieces, double* __restrict__ partial)
+{
+    __shared__ double red[4];
+    const Dot2dPiece t = pieces[blockIdx.x];
+    double s = 0.0;
+    const int64_t tot = (int64_t)t.nr * t.nc;
+    for (int64_t e = threadIdx.x; e < tot; e += 256) { const int64_t i = e / t.nc, j = e % t.nc; s += t.a[i * t.lda + j] * t.b[i * t.ldb + j]; }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+// out[outs[o]] = sum of partial[first[o] .. first[o+1]) in piece order
+__global__ void __launch_bounds__(256) dot2d_final_kernel(const double* __restrict__ partial, const int32_t* __restrict__ outs, const int32_t* __restrict__ first, int nout, double* __restrict__ out)
+{
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    if (o >= nout) return;
+    double s = 0.0;
+    for (int q = first[o]; q < first[o + 1]; ++q) s += partial[q];
+    out[outs[o]] = s;
+}
+}  // namespace
+}  // namespace dmrgx
+
+extern "C" dmrgx_status dmrgx_dot2d_batch(int32_t count, const dmrgx_dot2d_task* tasks, double* dev_out, void* stream)
+{
+    if (count < 0 || (count > 0 && (!tasks || !dev_out))) DMRGX_FAIL(DMRGX_ERR_ARG, "dot2d_batch: bad argument");
+    if (count == 0) return DMRGX_OK;
+    hipStream_t st = (hipStream_t)stream;
+    // pieces of at most ~64k elements, grouped by output index (stable: task order inside an output is kept)
+    std::vector<int32_t> order(count);
+    for (int32_t i = 0; i < count; ++i) {
+        const dmrgx_dot2d_task& t = tasks[i];
+        if (t.nr < 0 || t.nc < 0 || t.out < 0 || (t.nr && t.nc && (!t.a || !t.b || t.lda < t.nc || t.ldb < t.nc))) DMRGX_FAIL(DMRGX_ERR_ARG, "dot2d_batch: bad task %d", i);
+        order[i] = i;
+    }
+    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return tasks[x].out < tasks[y].out; });
+    std::vector<dmrgx::Dot2dPiece> pieces;
+    std::vector<int32_t> outs, first;
+    for (int32_t r = 0; r < count; ++r) {
+        const dmrgx_dot2d_task& t = tasks[order[r]];
+        if (outs.empty() || outs.back() != t.out) { outs.push_back(t.out); first.push_back((int32_t)pieces.size()); }
+        if (t.nr == 0 || t.nc == 0) continue;
+        const int32_t rows_per = std::max<int32_t>(1, 65536 / t.nc);
+        for (int32_t r0 = 0; r0 < t.nr; r0 += rows_per)
+            pieces.push_back(dmrgx::Dot2dPiece{t.a + (int64_t)r0 * t.lda, t.b + (int64_t)r0 * t.ldb, t.lda, t.ldb, std::min(rows_per, t.nr - r0), t.nc});
+    }
+    first.push_back((int32_t)pieces.size());
+    DevBuf dp, dpart, douts, dfirst;
+    DMRGX_CHK(dpart.alloc(std::max<size_t>(pieces.size(), 1) * sizeof(double)));
+    DMRGX_CHK(upload(dp, pieces, st)); DMRGX_CHK(upload(douts, outs, st)); DMRGX_CHK(upload(dfirst, first, st));
+    if (!pieces.empty()) hipLaunchKernelGGL(dmrgx::dot2d_partial_kernel, dim3((unsigned)pieces.size()), dim3(256), 0, st, dp.as<dmrgx::Dot2dPiece>(), dpart.as<double>());
+    hipLaunchKernelGGL(dmrgx::dot2d_final_kernel, dim3((unsigned)((outs.size() + 255) / 256)), dim3(256), 0, st, (const double*)dpart.as<double>(), douts.as<int32_t>(), dfirst.as<int32_t>(),
+                       (int)outs.size(), dev_out);
+    DMRGX_HIP(hipGetLastError());
     return DMRGX_OK;
 }

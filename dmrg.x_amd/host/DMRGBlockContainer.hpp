@@ -115,6 +115,7 @@ public:
         ierr = PetscOptionsGetBool(NULL, NULL, "-debug_check_symmetry", &debug_symm, NULL); CHKERRQ(ierr);
         ierr = PetscOptionsGetBool(NULL, NULL, "-wavefunction_guess", &use_guess, NULL); CHKERRQ(ierr);
         ierr = PetscOptionsGetBool(NULL, NULL, "-rdm_warm_start", &use_rdm_warm, NULL); CHKERRQ(ierr);
+        ierr = PetscOptionsGetBool(NULL, NULL, "-corr_batch", &use_corr_batch, NULL); CHKERRQ(ierr);
 
         PetscBool opt = PETSC_FALSE;
         ierr = PetscOptionsGetString(NULL, NULL, "-scratch_dir", path, PETSC_MAX_PATH_LEN, &opt); CHKERRQ(ierr);
@@ -792,9 +793,100 @@ public:
         const PetscInt nkb = KronBlocks.size();
         dmrgx_host::DevBuffer dev_vals(std::max<size_t>(measurements.size(), 1), dmrgx_host::DevBuffer::device_only_t{});
         std::vector<char> queued(measurements.size(), 0);
-        PetscLogDouble tc0, tc1, t_one = 0, t_two = 0; PetscInt n_one = 0, n_two = 0;
+        PetscLogDouble tc0, tc1, t_one = 0, t_two = 0, t_batch = 0; PetscInt n_one = 0, n_two = 0, n_batch = 0;
+        /* ---- system-block correlators of one or two operators (magnetisations, neighbour pairs: the bulk of the table), batched:
+                <psi| P (x) 1 |psi> = sum_k < P[IL(k)], X_k X_k^T >_F
+           so the Gram blocks G_k = X_k X_k^T are formed once (one grouped GEMM), all operator pairs are multiplied in one
+           grouped GEMM per chunk, and all expectation values are one batch of 2-D inner products. */
+        std::vector<char> done(measurements.size(), 0);
+        if (use_corr_batch) {
+            PetscTime(&tc0);
+            std::vector<int64_t> g_off((size_t)nkb + 1, 0);
+            for (PetscInt k = 0; k < nkb; ++k) { const int64_t nl = L.Magnetization.Sizes(KronBlocks.LeftIdx(k)); g_off[(size_t)k + 1] = g_off[(size_t)k] + nl * nl; }
+            dmrgx_host::DevBuffer xt((size_t)std::max<PetscInt>(gsv_r->n, 1), dmrgx_host::DevBuffer::device_only_t{});
+            dmrgx_host::DevBuffer gram((size_t)std::max<int64_t>(g_off[(size_t)nkb], 1), dmrgx_host::DevBuffer::device_only_t{});
+            {
+                if (dmrgx_memset_zero(xt.dev_uninitialised(), (size_t)gsv_r->n * sizeof(double), nullptr)) SETERRQ1(mpi_comm, 1, "%s", dmrgx_last_error());
+                std::vector<dmrgx_axpy_task> tr; std::vector<dmrgx_gemm_task> gt;
+                const double* x = gsv_r->buf->dev_ro();
+                for (PetscInt k = 0; k < nkb; ++k) {
+                    const int32_t nl = (int32_t)L.Magnetization.Sizes(KronBlocks.LeftIdx(k)), nr = (int32_t)R.Magnetization.Sizes(KronBlocks.RightIdx(k));
+                    if (nl == 0 || nr == 0) continue;
+                    double* xtk = xt.dev_uninitialised() + KronBlocks.Offsets(k);
+                    dmrgx_axpy_task t; t.dst = xtk; t.dst_base = nullptr; t.src = x + KronBlocks.Offsets(k); t.ldd = nl; t.lds = nr; t.nr = nr; t.nc = nl; t.transposed = 1; t.alpha = 1.0;
+                    tr.push_back(t);
+                    gt.push_back(dmrgx_gemm_task{nl, nl, nr, 0, x + KronBlocks.Offsets(k), nr, xtk, nl, gram.dev_uninitialised() + g_off[(size_t)k], nl});
+                }
+                if (!tr.empty() && dmrgx_cells_axpy((int32_t)tr.size(), tr.data(), nullptr)) SETERRQ1(mpi_comm, 1, "dmrgx_cells_axpy: %s", dmrgx_last_error());
+                if (!gt.empty() && dmrgx_dgemm_batch((int32_t)gt.size(), gt.data(), nullptr)) SETERRQ1(mpi_comm, 1, "dmrgx_dgemm_batch: %s", dmrgx_last_error());
+            }
+            const std::vector<int32_t> lsz = L.Magnetization.Sizes32();
+            const int32_t ns = (int32_t)lsz.size();
+            auto cell_at = [](const Mat& M, int32_t q) -> const dmrgx_host::MatCell* { for (const dmrgx_host::MatCell& c : M->cells) if (c.q == q) return &c; return nullptr; };
+            std::vector<dmrgx_gemm_task> ptasks;
+            std::vector<dmrgx_dot2d_task> dtasks;
+            std::vector<std::shared_ptr<dmrgx_host::DevBuffer>> arenas;      /* pair products of the current chunk */
+            int64_t chunk_elems = 0;
+            const int64_t chunk_limit = (int64_t)1 << 28;                     /* 2 GiB of products per chunk */
+            auto flush = [&]() -> PetscErrorCode {
+                if (!ptasks.empty() && dmrgx_dgemm_batch((int32_t)ptasks.size(), ptasks.data(), nullptr)) SETERRQ1(mpi_comm, 1, "dmrgx_dgemm_batch: %s", dmrgx_last_error());
+                if (!dtasks.empty() && dmrgx_dot2d_batch((int32_t)dtasks.size(), dtasks.data(), dev_vals.dev_uninitialised(), nullptr)) SETERRQ1(mpi_comm, 1, "dmrgx_dot2d_batch: %s", dmrgx_last_error());
+                ptasks.clear(); dtasks.clear(); arenas.clear(); chunk_elems = 0;
+                return 0;
+            };
+            for (size_t ic = 0; ic < measurements.size(); ++ic) {
+                const Correlator& c = measurements[ic];
+                if (!c.EnvOps.empty() || c.SysOps.empty() || c.SysOps.size() > 2) continue;
+                int shift = 0;
+                for (const Op& o : c.SysOps) shift += int(o.OpType);
+                if (shift != 0) continue;                                       /* left to the general loop: it records the zero */
+                Mat A, B;
+                ierr = CalculateOperatorProduct(L, {c.SysOps[0]}, A, cacheL, true); CHKERRQ(ierr);
+                if (c.SysOps.size() == 2) { ierr = CalculateOperatorProduct(L, {c.SysOps[1]}, B, cacheL, true); CHKERRQ(ierr); }
+                bool any = false;
+                std::shared_ptr<dmrgx_host::DevBuffer> arena;
+                int64_t cursor = 0;
+                if (B) {
+                    int64_t total = 0;
+                    for (PetscInt k = 0; k < nkb; ++k) { const int64_t nl = lsz[(size_t)KronBlocks.LeftIdx(k)]; total += nl * nl; }
+                    if (chunk_elems + total > chunk_limit) { ierr = flush(); CHKERRQ(ierr); }
+                    arena = std::make_shared<dmrgx_host::DevBuffer>((size_t)std::max<int64_t>(total, 1), dmrgx_host::DevBuffer::device_only_t{});
+                    arenas.push_back(arena);
+                    chunk_elems += total;
+                }
+                for (PetscInt k = 0; k < nkb; ++k) {
+                    const int32_t q = (int32_t)KronBlocks.LeftIdx(k), nl = lsz[(size_t)q];
+                    if (nl == 0 || R.Magnetization.Sizes(KronBlocks.RightIdx(k)) == 0) continue;
+                    const double* gk = gram.dev_ro() + g_off[(size_t)k];
+                    if (!B) {
+                        const dmrgx_host::MatCell* a = cell_at(A, q);
+                        if (!a || A->shift != 0) continue;
+                        dtasks.push_back(dmrgx_dot2d_task{a->buf->dev_ro() + a->off, a->ld, gk, nl, nl, nl, (int32_t)c.idx, 0});
+                        any = true;
+                    } else {
+                        const int32_t qa = q + A->shift;                    /* (A B)[q -> q] = A[q -> qa] B[qa -> q] */
+                        if (qa < 0 || qa >= ns) continue;
+                        const dmrgx_host::MatCell* a = cell_at(A, q);
+                        const dmrgx_host::MatCell* b = cell_at(B, qa);
+                        if (!a || !b || a->nc == 0) continue;
+                        double* pc = arena->dev_uninitialised() + cursor;
+                        cursor += (int64_t)nl * nl;
+                        ptasks.push_back(dmrgx_gemm_task{nl, nl, a->nc, 0, a->buf->dev_ro() + a->off, a->ld, b->buf->dev_ro() + b->off, b->ld, pc, nl});
+                        dtasks.push_back(dmrgx_dot2d_task{pc, nl, gk, nl, nl, nl, (int32_t)c.idx, 0});
+                        any = true;
+                    }
+                }
+                done[ic] = 1;
+                if (any) queued[(size_t)c.idx] = 1; else CorrValues[c.idx] = 0.0;
+                ++n_batch;
+            }
+            ierr = flush(); CHKERRQ(ierr);
+            PetscTime(&tc1);
+            t_batch = tc1 - tc0;
+        }
         for (size_t ic = 0; ic < measurements.size(); ++ic) {
             const Correlator& c = measurements[ic];
+            if (done[ic]) continue;
             PetscTime(&tc0);
             int shift = 0;
             for (const Op& o : c.SysOps) shift += int(o.OpType);
@@ -838,7 +930,7 @@ public:
             if (!hv.empty() && dmrgx_memcpy_d2h(hv.data(), dev_vals.dev_ro(), hv.size() * sizeof(double), nullptr)) SETERRQ1(mpi_comm, 1, "%s", dmrgx_last_error());
             for (size_t i = 0; i < hv.size(); ++i) if (queued[i]) CorrValues[i] = hv[i];
         }
-        if (!mpi_rank && verbose) printf("  * Calc. of Correlators: %lld on the system block %.6f s, %lld across the cut %.6f s\n", LLD(n_one), t_one, LLD(n_two), t_two);
+        if (!mpi_rank && verbose) printf("  * Calc. of Correlators: %lld batched through the Gram blocks %.6f s, %lld more on the system block %.6f s, %lld across the cut %.6f s\n", LLD(n_batch), t_batch, LLD(n_one), t_one, LLD(n_two), t_two);
         if (need_sm && !l_had) { ierr = L.DestroySm(); CHKERRQ(ierr); }
         if (need_sm && !r_had && R.HasSm()) { ierr = R.DestroySm(); CHKERRQ(ierr); }
         if (!mpi_rank && fp_corr) {
@@ -1052,6 +1144,7 @@ private:
     struct WarmBasis { std::vector<int32_t> sizes; std::map<int32_t, std::shared_ptr<dmrgx_host::DevBuffer>> E; };
     std::map<std::pair<PetscInt, int>, WarmBasis> rdm_basis;
     PetscBool use_rdm_warm = PETSC_FALSE;
+    PetscBool use_corr_batch = PETSC_TRUE;      /* -corr_batch 0: every correlator through its own MatMult + dot, as the reference does */
 };
 
 #endif

@@ -262,6 +262,12 @@ dmrgx_status dmrgx_dot(int64_t n, const double* x_dev, const double* y_dev, doub
 /* The same without the synchronisation: the sum (same summation order) is written to dev_out[0] in stream order -- lets a
  * caller queue many expectation values and fetch them with one dmrgx_memcpy_d2h. */
 dmrgx_status dmrgx_dot_async(int64_t n, const double* x_dev, const double* y_dev, double* dev_out, void* stream);
+/* Many 2-D (Frobenius) inner products in one launch: dev_out[t.out] = sum over the tasks with that `out` of
+ * sum_ij a[i*lda + j] * b[i*ldb + j]; outputs that no task names are left untouched.  Fixed summation order.  With the
+ * Gram blocks G_k = X_k X_k^T of the state this evaluates <psi|P (x) 1|psi> = sum_k <P[IL(k)], G_k> for a whole table of
+ * system-block correlators at once (the MatMult + VecDot pairs of include/DMRGBlockContainer.hpp:2287-2293). */
+typedef struct { const double* a; int64_t lda; const double* b; int64_t ldb; int32_t nr, nc, out, pad; } dmrgx_dot2d_task;
+dmrgx_status dmrgx_dot2d_batch(int32_t count, const dmrgx_dot2d_task* tasks, double* dev_out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -350,6 +350,39 @@ def test_device_dot_product(pkg):
     assert L.dmrgx_dot_async(5, None, None, None, None) == 62
 
 
+def test_dot2d_batch_matches_numpy(pkg):
+    """dmrgx_dot2d_batch: strided Frobenius inner products grouped by output index (large blocks are cut into pieces),
+    untouched outputs keep their value, results reproducible bit for bit."""
+    import ctypes as C
+    import torch
+    from dmrgx_amd import _capi
+    L = _capi.lib()
+    rng = np.random.default_rng(11)
+    shapes = [(5, 7, 0), (300, 301, 2), (64, 1, 2), (1, 900, 4), (0, 3, 5), (700, 650, 0)]
+    tasks = (_capi.Dot2dTask * len(shapes))()
+    keep, want = [], {}
+    for i, (nr, nc, out) in enumerate(shapes):
+        A, B = rng.standard_normal((nr, nc + 3)), rng.standard_normal((nr, nc + 5))
+        a, b = torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda()
+        keep += [a, b]
+        tasks[i].a, tasks[i].lda, tasks[i].b, tasks[i].ldb = a.data_ptr(), nc + 3, b.data_ptr(), nc + 5
+        tasks[i].nr, tasks[i].nc, tasks[i].out = nr, nc, out
+        want[out] = want.get(out, 0.0) + float((A[:, :nc] * B[:, :nc]).sum())
+    res = []
+    for _ in range(2):
+        dev = torch.full((6,), -7.0, dtype=torch.float64, device="cuda")
+        assert L.dmrgx_dot2d_batch(len(shapes), tasks, dev.data_ptr(), None) == 0
+        res.append(dev.cpu().numpy())
+    assert np.array_equal(res[0], res[1])
+    for o in range(6):
+        if o in want:
+            assert abs(res[0][o] - want[o]) <= 1e-11 * max(1.0, abs(want[o]))
+        else:
+            assert res[0][o] == -7.0
+    tasks[0].lda = 2
+    assert L.dmrgx_dot2d_batch(len(shapes), tasks, dev.data_ptr(), None) == 62
+
+
 def test_dgemm_batch_matches_numpy(pkg):
     """dmrgx_dgemm_batch: ragged independent products (and an accumulate task) in one grouped launch."""
     import ctypes as C
