@@ -743,7 +743,7 @@ extern "C" dmrgx_status dmrgx_kron_plan_timing_read(dmrgx_kron_plan* P, double* 
 extern "C" dmrgx_status dmrgx_kron_plan_destroy(dmrgx_kron_plan* plan)
 {
     if (!plan) return DMRGX_OK;
-    (void)hipDeviceSynchronize();
+    // no synchronisation: the blocks go back to the pool and are recycled in stream order (pool.hip)
     delete plan;
     return DMRGX_OK;
 }

@@ -752,7 +752,7 @@ extern "C" dmrgx_status dmrgx_rdm_info(const dmrgx_rdm* R, int32_t* n_sweeps)
 extern "C" dmrgx_status dmrgx_rdm_destroy(dmrgx_rdm* R)
 {
     if (!R) return DMRGX_OK;
-    (void)hipDeviceSynchronize();
+    // no synchronisation: the blocks go back to the pool and are recycled in stream order (pool.hip)
     delete R;
     return DMRGX_OK;
 }
