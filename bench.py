@@ -79,17 +79,18 @@ def engine_run(opts, timeout=300):
 
 def sweep_legs():
     """The other two parts of BASELINE.json's metric, measured on the real engine (real Hamiltonian, real sweeps):
-    sites/sec per sweep on configs[1] (J1-J2 8x4 cylinder, J2 = 0.5, m = 512) and the E0 relative error on configs[0]
+    sites/sec per sweep on configs[3] -- the lattice and m the north star quotes (J1-J2 20x8 cylinder, J2 = 0.5, m = 2048: it
+    fits one MI355X, about a minute) -- and on configs[1] (J1-J2 8x4, m = 512), and the E0 relative error on configs[0]
     (Heisenberg 16x1 chain, m = 64, 2 sweeps) against exact diagonalisation."""
-    out = {}
-    run = engine_run(["-Lx", 8, "-Ly", 4, "-J1", 1, "-Jz1", 1, "-J2", 0.5, "-Jz2", 0.5, "-mwarmup", 512, "-nsweeps", 1])
-    out["sites_per_s"] = run["LastSweepSteps"] / run["LastSweepSeconds"]
-    out["config"] = "configs[1]: J1-J2 8x4 cylinder, J2=0.5, m=512, one finite-system sweep after warm-up (real engine run)"
-    out["sweep_steps"] = run["LastSweepSteps"]
-    out["sweep_seconds"] = run["LastSweepSeconds"]
-    out["sweep_matmults"] = run["LastSweepMatMults"]
-    out["matmults_per_s_in_sweep"] = run["LastSweepMatMults"] / run["LastSweepSeconds"]
-    out["gs_energy"] = run["GSEnergy"]
+    def leg(run, config):
+        return {"sites_per_s": run["LastSweepSteps"] / run["LastSweepSeconds"], "config": config, "sweep_steps": run["LastSweepSteps"],
+                "sweep_seconds": run["LastSweepSeconds"], "sweep_matmults": run["LastSweepMatMults"],
+                "matmults_per_s_in_sweep": run["LastSweepMatMults"] / run["LastSweepSeconds"], "gs_energy": run["GSEnergy"]}
+    j1j2 = ["-J1", 1, "-Jz1", 1, "-J2", 0.5, "-Jz2", 0.5, "-nsweeps", 1]
+    out = leg(engine_run(["-Lx", 20, "-Ly", 8, "-mwarmup", 2048, *j1j2], timeout=900),
+              "configs[3] on one GPU: J1-J2 20x8 cylinder (160 sites), J2=0.5, m=2048, one finite-system sweep after warm-up (real engine run)")
+    out["configs_1"] = leg(engine_run(["-Lx", 8, "-Ly", 4, "-mwarmup", 512, *j1j2]),
+                           "configs[1]: J1-J2 8x4 cylinder, J2=0.5, m=512, one finite-system sweep after warm-up (real engine run)")
     e_ed = -6.9117371455751
     run1 = engine_run(["-Lx", 16, "-Ly", 1, "-heisenberg", 1, "-mwarmup", 64, "-nsweeps", 2, "-H_eps_tol", 1e-12])
     out["e0_rel_err"] = abs(run1["GSEnergy"] - e_ed) / abs(e_ed)

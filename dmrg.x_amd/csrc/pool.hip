@@ -8,6 +8,7 @@
 // Python wrappers use one stream (the null stream); a caller that moves between streams synchronises in between
 // (dmrgx_stream_sync) -- see include/dmrgx.h.  DMRGX_POOL=0 disables caching (every free is a hipFree again).
 #include "common.h"
+#include <chrono>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -22,13 +23,17 @@ struct Pool {
     std::unordered_map<void*, size_t> size_of;       // every block handed out or cached
     size_t cached = 0;
     const bool enabled = !(getenv("DMRGX_POOL") && atoi(getenv("DMRGX_POOL")) == 0);
-    const size_t cache_limit = (size_t)(getenv("DMRGX_POOL_LIMIT_GB") ? atof(getenv("DMRGX_POOL_LIMIT_GB")) : 96.0) << 30;
+    const size_t cache_limit = (size_t)(getenv("DMRGX_POOL_LIMIT_GB") ? atof(getenv("DMRGX_POOL_LIMIT_GB")) : 64.0) << 30;
 
     static size_t size_class(size_t n) {
         if (n <= 512) return 512;
         if (n <= ((size_t)1 << 20)) { size_t c = 512; while (c < n) c <<= 1; return c; }          // powers of two up to 1 MiB
-        const size_t step = n <= ((size_t)64 << 20) ? ((size_t)1 << 20) : ((size_t)16 << 20);       // then 1 MiB / 16 MiB steps
-        return (n + step - 1) / step * step;
+        // above: eight classes per octave (12.5 % steps), so that arenas whose size drifts a little from one sweep step to the
+        // next fall into the same class and are interchangeable
+        size_t oct = (size_t)1 << 20;
+        while ((oct << 1) < n) oct <<= 1;                   // oct < n <= 2 oct
+        const size_t step = oct / 8;
+        return oct + (n - oct + step - 1) / step * step;
     }
     void trim_locked() {                              // give everything cached back to the driver
         (void)hipDeviceSynchronize();
@@ -54,14 +59,21 @@ hipError_t pool_malloc(void** out, size_t bytes)
     if (!P.enabled) return hipMalloc(out, bytes);
     const size_t c = Pool::size_class(bytes);
     std::lock_guard<std::mutex> lock(P.mu);
-    auto it = P.free_by_size.find(c);
-    if (it != P.free_by_size.end() && !it->second.empty()) {
+    // best fit: the smallest cached block that holds the request; large requests may take a block up to 25 % larger (the
+    // arenas of a sweep change size a little from step to step, and a driver allocation of a GiB costs ~15 ms)
+    const size_t slack = c >= ((size_t)1 << 20) ? c / 4 : 0;
+    for (auto it = P.free_by_size.lower_bound(c); it != P.free_by_size.end() && it->first <= c + slack; ++it) {
+        if (it->second.empty()) continue;
         *out = it->second.back();
         it->second.pop_back();
-        P.cached -= c;
+        P.cached -= it->first;
         return hipSuccess;
     }
+    static const bool trace = getenv("DMRGX_POOL_TRACE") != nullptr;     // developer aid: driver allocations that miss the cache
+    const auto t0 = std::chrono::steady_clock::now();
     hipError_t e = hipMalloc(out, c);
+    if (trace && c >= ((size_t)8 << 20)) fprintf(stderr, "[pool] hipMalloc %.1f MiB: %.3f ms (cached %.1f GiB)\n", c / 1048576.0,
+                                                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), P.cached / 1073741824.0);
     if (e != hipSuccess) {                            // out of memory with blocks cached: release them and try once more
         (void)hipGetLastError();
         P.trim_locked();

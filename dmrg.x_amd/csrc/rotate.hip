@@ -14,6 +14,7 @@
 // device form of the explicit KronSum that builds an enlarged block's H (reference src/DMRGKron.cpp:612 ->
 // KronSumFillMatrix :1440-1446 restricted to  H_old (x) 1 + sum_t a_t O_i (x) s_site).
 #include "ggemm.h"
+#include <chrono>
 #include <algorithm>
 #include <map>
 
@@ -97,6 +98,7 @@ extern "C" dmrgx_status dmrgx_rotate_ops(const dmrgx_sectors* old_sectors, const
                                          const dmrgx_secop* src_ops, double* const* const* dst_blocks, void* stream)
 {
     hipStream_t st = (hipStream_t)stream;
+    const auto h0 = std::chrono::steady_clock::now();
     if (!old_sectors || !rot || nops < 0 || (nops > 0 && (!src_ops || !dst_blocks))) DMRGX_FAIL(DMRGX_ERR_ARG, "rotate_ops: null argument");
     const int32_t nn = rot->n_new;
     if (nn <= 0 || !rot->old_sector || !rot->kept || !rot->rot_t) DMRGX_FAIL(DMRGX_ERR_ARG, "rotate_ops: empty rotation");
@@ -182,11 +184,16 @@ extern "C" dmrgx_status dmrgx_rotate_ops(const dmrgx_sectors* old_sectors, const
         groups.push_back(GGroup{dst_blocks[o][a], mp, m, mp, pb, (int32_t)prods.size(), 0, 0});
         ggemm_append_tiles_mixed(tBb, tB, (int32_t)groups.size() - 1, m, mp, cost);
     }
+    const auto h1 = std::chrono::steady_clock::now();
     ggemm_schedule(tA); ggemm_schedule(tAb, 2); ggemm_schedule(tB); ggemm_schedule(tBb, 2);
+    const auto h2 = std::chrono::steady_clock::now();
     DevBuf dp, dg, d1, d2, d3, d4;
     DMRGX_CHK(upload(dp, prods, st)); DMRGX_CHK(upload(dg, groups, st));
     DMRGX_CHK(upload(d1, tAb, st)); DMRGX_CHK(upload(d2, tA, st)); DMRGX_CHK(upload(d3, tBb, st)); DMRGX_CHK(upload(d4, tB, st));
+    const auto h3 = std::chrono::steady_clock::now();
     static const bool trace = getenv("DMRGX_ROT_TRACE") != nullptr;      // developer aid: flops and time of the two stages
+    if (trace) fprintf(stderr, "[rotate] host: tables %.3f ms, schedule %.3f ms, uploads %.3f ms\n", std::chrono::duration<double, std::milli>(h1 - h0).count(),
+                       std::chrono::duration<double, std::milli>(h2 - h1).count(), std::chrono::duration<double, std::milli>(h3 - h2).count());
     hipEvent_t ev[3];
     if (trace) { for (auto& e : ev) DMRGX_HIP(hipEventCreate(&e)); DMRGX_HIP(hipEventRecord(ev[0], st)); }
     DMRGX_CHK(ggemm_launch(d1.as<GTile>(), dg.as<GGroup>(), dp.as<GProd>(), (int32_t)tAb.size(), st, 1));
