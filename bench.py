@@ -74,7 +74,18 @@ def engine_run(opts, timeout=300):
         r = subprocess.run([exe, *[str(o) for o in opts], "-data_dir", d + "/"], capture_output=True, text=True, timeout=timeout)
         if r.returncode != 0:
             raise RuntimeError("sweep engine failed: " + (r.stdout + r.stderr)[-1000:])
-        return json.load(open(os.path.join(d, "DMRGRun.json")))
+        run = json.load(open(os.path.join(d, "DMRGRun.json")))
+        # per-sweep totals from the reference-format step tables (DMRGSteps.json: LoopType/LoopIdx, Timings.json: Total, MatMults)
+        steps = json.load(open(os.path.join(d, "DMRGSteps.json")))["table"]
+        times = json.load(open(os.path.join(d, "Timings.json")))["table"]
+        per = {}
+        for st, tm in zip(steps, times):
+            if st[1] != "Sweep":
+                continue
+            e = per.setdefault(int(st[2]), {"steps": 0, "seconds": 0.0, "matmults": 0})
+            e["steps"] += 1; e["seconds"] += float(tm[1]); e["matmults"] += int(tm[7])
+        run["PerSweep"] = [per[k] for k in sorted(per)]
+        return run
 
 
 def sweep_legs():
@@ -86,10 +97,12 @@ def sweep_legs():
         return {"sites_per_s": run["LastSweepSteps"] / run["LastSweepSeconds"], "config": config, "sweep_steps": run["LastSweepSteps"],
                 "sweep_seconds": run["LastSweepSeconds"], "sweep_matmults": run["LastSweepMatMults"],
                 "matmults_per_s_in_sweep": run["LastSweepMatMults"] / run["LastSweepSeconds"], "gs_energy": run["GSEnergy"]}
-    j1j2 = ["-J1", 1, "-Jz1", 1, "-J2", 0.5, "-Jz2", 0.5, "-nsweeps", 1]
-    out = leg(engine_run(["-Lx", 20, "-Ly", 8, "-mwarmup", 2048, *j1j2], timeout=900),
-              "configs[3] on one GPU: J1-J2 20x8 cylinder (160 sites), J2=0.5, m=2048, one finite-system sweep after warm-up (real engine run)")
-    out["configs_1"] = leg(engine_run(["-Lx", 8, "-Ly", 4, "-mwarmup", 512, *j1j2]),
+    j1j2 = ["-J1", 1, "-Jz1", 1, "-J2", 0.5, "-Jz2", 0.5]
+    run3 = engine_run(["-Lx", 20, "-Ly", 8, "-mwarmup", 2048, *j1j2, "-nsweeps", 2], timeout=1200)
+    out = leg(run3, "configs[3] on one GPU: J1-J2 20x8 cylinder (160 sites), J2=0.5, m=2048, warm-up + two finite-system sweeps (real engine "
+                    "run); sites_per_s is the second sweep, the first one (environment blocks still from the warm-up) is listed beside it")
+    out["per_sweep"] = [{"sites_per_s": p["steps"] / p["seconds"], "matmults_per_s": p["matmults"] / p["seconds"], **p} for p in run3["PerSweep"]]
+    out["configs_1"] = leg(engine_run(["-Lx", 8, "-Ly", 4, "-mwarmup", 512, *j1j2, "-nsweeps", 1]),
                            "configs[1]: J1-J2 8x4 cylinder, J2=0.5, m=512, one finite-system sweep after warm-up (real engine run)")
     e_ed = -6.9117371455751
     run1 = engine_run(["-Lx", 16, "-Ly", 1, "-heisenberg", 1, "-mwarmup", 64, "-nsweeps", 2, "-H_eps_tol", 1e-12])
