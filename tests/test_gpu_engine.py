@@ -119,6 +119,18 @@ def test_correlators_match_exact_diagonalisation(tmp_path):
     assert abs(bond - e0) <= 1e-10 * abs(e0) and abs(run["GSEnergy"] - e0) <= 1e-10 * abs(e0)
 
 
+def test_batched_correlators_equal_the_per_correlator_route(tmp_path):
+    """The Gram-block batch (<psi|P (x) 1|psi> = sum_k <P, X_k X_k^T>, default) and the reference's route (one MatMult + dot per
+    correlator, -corr_batch 0) give the same table on a J1-J2 lattice whose warm-up truncates (6x2, m = 24)."""
+    model = ["-Lx", 6, "-Ly", 2, "-J1", 1, "-Jz1", 1, "-J2", 0.5, "-Jz2", 0.5, "-mwarmup", 24, "-nsweeps", 1, "-H_eps_tol", 1e-12]
+    run_engine(tmp_path / "a", *model)
+    run_engine(tmp_path / "b", *model, "-corr_batch", 0)
+    ca, cb = (json.load(open(str(tmp_path / d) + "/Correlations.json")) for d in ("a", "b"))
+    assert [c["name"] for c in ca["info"]] == [c["name"] for c in cb["info"]] and len(ca["values"]) == len(cb["values"]) == 2
+    va, vb = np.array(ca["values"], dtype=float), np.array(cb["values"], dtype=float)
+    assert np.abs(va).max() > 0.1 and np.abs(va - vb).max() <= 1e-12
+
+
 def test_checkpoint_restart_continues_the_run(tmp_path):
     """one sweep + restart from its checkpoint + one sweep reproduces, step for step and bit for bit, the
     second sweep of an uninterrupted two-sweep run (blocks are restored exactly, the eigensolver's start vectors depend

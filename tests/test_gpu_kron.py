@@ -350,6 +350,32 @@ def test_device_dot_product(pkg):
     assert L.dmrgx_dot_async(5, None, None, None, None) == 62
 
 
+def test_device_pool_recycles_blocks_in_stream_order(pkg):
+    """dmrgx_malloc / dmrgx_free: a freed block is handed out again without touching the driver (same address for the same size
+    class, a slightly smaller large request may take it too), and work queued before the free is not disturbed by the next
+    owner's work queued after it (stream order)."""
+    import ctypes as C
+    import torch
+    from dmrgx_amd import _capi
+    L = _capi.lib()
+    p1, p2 = C.c_void_p(), C.c_void_p()
+    n = 3 << 20                                                  # 3 Mi doubles = 24 MiB
+    assert L.dmrgx_malloc(C.byref(p1), n * 8) == 0 and p1.value
+    host = np.arange(n, dtype=np.float64)
+    assert L.dmrgx_memcpy_h2d(p1, host.ctypes.data, n * 8, None) == 0
+    out = torch.empty(n, dtype=torch.float64, device="cuda")
+    assert L.dmrgx_memcpy_d2d(out.data_ptr(), p1, n * 8, None) == 0     # queued reader of the block ...
+    assert L.dmrgx_free(p1) == 0                                            # ... freed while that copy may still be pending
+    assert L.dmrgx_malloc(C.byref(p2), (n - 1000) * 8) == 0                # a slightly smaller request: best fit takes the cached block
+    assert p2.value == p1.value
+    assert L.dmrgx_memset_zero(p2, (n - 1000) * 8, None) == 0              # next owner's work, queued behind the copy
+    assert np.array_equal(out.cpu().numpy(), host)
+    back = np.ones(16)
+    assert L.dmrgx_memcpy_d2h(back.ctypes.data, p2, 16 * 8, None) == 0 and not back.any()
+    assert L.dmrgx_free(p2) == 0
+    assert L.dmrgx_malloc(C.byref(p1), 0) == 0 and not p1.value            # zero bytes: null, no error
+
+
 def test_dot2d_batch_matches_numpy(pkg):
     """dmrgx_dot2d_batch: strided Frobenius inner products grouped by output index (large blocks are cut into pieces),
     untouched outputs keep their value, results reproducible bit for bit."""
