@@ -212,9 +212,7 @@ __device__ __forceinline__ jd4 mfma_block(const double* L, const double* M, int 
 __device__ __forceinline__ void jacobi_update_body(double* sh, const MatDesc* __restrict__ mats, const int32_t* __restrict__ pair_start, const UpdTask t,
                                                    double* __restrict__ buf, const double* __restrict__ rbuf, int round)
 {
-    double* X = sh;
-    double* RQ = sh + JS * JLD;
-    double* RP = sh + 2 * JS * JLD;
+    double* X = sh;                                   // the only LDS tile: R_Q and R_P^T go from global memory straight into MFMA fragments
     const MatDesc m = mats[t.mat];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
     int IQ, JQ, IP = 0, JP = 0;
@@ -225,21 +223,30 @@ __device__ __forceinline__ void jacobi_update_body(double* sh, const MatDesc* __
     double* M = buf + (t.kind == 0 ? m.a_off : m.v_off);
     auto cq = [&](int j) { return j < JB ? IQ * JB + j : JQ * JB + j - JB; };
     auto rp = [&](int i) { return t.kind == 0 ? (i < JB ? IP * JB + i : JP * JB + i - JB) : t.p * JS + i; };
+    const int l15 = lane & 15, l4 = lane >> 4;
+    // fragments (as in mfma_block): B operand of X . R_Q is R_Q[k][16 wc + l15]; A operand of R_P^T . Y is R_P[k][16 wr + l15]
+    double bq[JS / 4], ap[JS / 4];
+#pragma unroll
+    for (int g = 0; g < JS / 4; ++g) {
+        bq[g] = Rq[(4 * g + l4) * JS + 16 * wc + l15];
+        ap[g] = (t.kind == 0) ? Rp[(4 * g + l4) * JS + 16 * wr + l15] : 0.0;
+    }
     for (int e = tid; e < JS * JS; e += 256) {
         const int i = e / JS, j = e % JS;
         X[i * JLD + j] = M[(int64_t)rp(i) * m.npad + cq(j)];
-        RQ[i * JLD + j] = Rq[e];
-        if (t.kind == 0) RP[j * JLD + i] = Rp[e];                 // RP = R_P^T
     }
     __syncthreads();
-    const int l15 = lane & 15, l4 = lane >> 4;
-    jd4 acc = mfma_block(X, RQ, wr, wc, lane);                    // X . R_Q
+    jd4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int g = 0; g < JS / 4; ++g) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(X[(16 * wr + l15) * JLD + 4 * g + l4], bq[g], acc, 0, 0, 0);      // X . R_Q
     if (t.kind == 0) {
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < 4; ++r) X[(16 * wr + l4 + 4 * r) * JLD + 16 * wc + l15] = acc[r];
         __syncthreads();
-        acc = mfma_block(RP, X, wr, wc, lane);                    // R_P^T . (X . R_Q)
+        acc = (jd4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int g = 0; g < JS / 4; ++g) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[g], X[(4 * g + l4) * JLD + 16 * wc + l15], acc, 0, 0, 0);  // R_P^T . (X . R_Q)
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) M[(int64_t)rp(16 * wr + l4 + 4 * r) * m.npad + cq(16 * wc + l15)] = acc[r];
@@ -259,7 +266,7 @@ __global__ void __launch_bounds__(256)
 jacobi_update_kernel(const MatDesc* __restrict__ mats, const int32_t* __restrict__ pair_start, const UpdTask* __restrict__ tasks,
                      double* __restrict__ buf, const double* __restrict__ rbuf, int round)
 {
-    __shared__ double sh[3 * JS * JLD];
+    __shared__ double sh[JS * JLD];
     jacobi_update_body(sh, mats, pair_start, tasks[blockIdx.x], buf, rbuf, round);
 }
 
