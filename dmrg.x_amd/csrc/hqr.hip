@@ -11,6 +11,7 @@
 // Q^T = H_k .. H_1 I is accumulated forwards in the identity half, next to the factorisation (every panel updates all n of
 // its columns, rows r0 and below): 2 n^3 flops on top of the 4/3 n^3 of the factorisation, no second sweep over the panels.
 #include "hqr.h"
+#include <type_traits>
 
 namespace dmrgx {
 namespace {
@@ -157,16 +158,23 @@ hqr_panel_regs_kernel(const HqrMat* __restrict__ mats, double* __restrict__ buf,
         }
         const int k0 = j >> 6, cbj = j >> 2, qj = j & 3;     // registers k < k0 hold rows above j
         if (cb == cbj) {                                    // the reflector: zeros above row j, 1 on it, x * scale below
+            // qj is uniform over the workgroup: four copies with a compile-time column index instead of select chains
+            auto write_v = [&](auto Q) {
+                constexpr int q = decltype(Q)::value;
 #pragma unroll
-            for (int k = 0; k < RR; ++k) {
-                if (k < k0) continue;
-                const int i = rb + 64 * k;
-                const double vi = (i < j) ? 0.0 : (i == j ? 1.0 : sel4(p[k], qj) * scale);
-                if (i > j) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) p[k][q] = (q == qj) ? vi : p[k][q];
+                for (int k = 0; k < RR; ++k) {
+                    if (k < k0) continue;
+                    const int i = rb + 64 * k;
+                    const double vi = (i < j) ? 0.0 : (i == j ? 1.0 : p[k][q] * scale);
+                    if (i > j) p[k][q] = vi;
+                    vsm[i] = vi;
                 }
-                vsm[i] = vi;
+            };
+            switch (qj) {
+                case 0: write_v(std::integral_constant<int, 0>{}); break;
+                case 1: write_v(std::integral_constant<int, 1>{}); break;
+                case 2: write_v(std::integral_constant<int, 2>{}); break;
+                default: write_v(std::integral_constant<int, 3>{}); break;
             }
         }
         __syncthreads();
@@ -202,11 +210,20 @@ hqr_panel_regs_kernel(const HqrMat* __restrict__ mats, double* __restrict__ buf,
         if (j + 1 < pw) {                                   // norm and pivot of the next column, while it is in hand
             const int q1 = (j + 1) & 3, cb1 = (j + 1) >> 2;
             double s = 0.0;
+            auto norm_next = [&](auto Q) {
+                constexpr int q = decltype(Q)::value;
 #pragma unroll
-            for (int k = 0; k < RR; ++k) {
-                const int i = rb + 64 * k;
-                const double x = sel4(p[k], q1);
-                if (i > j + 1) s += x * x; else if (i == j + 1 && cb == cb1) piv[0] = x;
+                for (int k = 0; k < RR; ++k) {
+                    const int i = rb + 64 * k;
+                    const double x = p[k][q];
+                    if (i > j + 1) s += x * x; else if (i == j + 1 && cb == cb1) piv[0] = x;
+                }
+            };
+            switch (q1) {
+                case 0: norm_next(std::integral_constant<int, 0>{}); break;
+                case 1: norm_next(std::integral_constant<int, 1>{}); break;
+                case 2: norm_next(std::integral_constant<int, 2>{}); break;
+                default: norm_next(std::integral_constant<int, 3>{}); break;
             }
             s = sum_lane_bits_345(s);
             if (lane == cb1) sred[wave] = s;
@@ -225,7 +242,7 @@ hqr_panel_regs_kernel(const HqrMat* __restrict__ mats, double* __restrict__ buf,
     for (int e = tid; e < 32 * 32; e += HR_THREADS) buf[m.t_off + e] = Tm[e >> 5][e & 31];
 }
 
-constexpr int TR_THREADS = 512, TR_WAVES = TR_THREADS / 64, TR_COLS = 64, TR_UNROLL = 4;
+constexpr int TR_THREADS = 512, TR_WAVES = TR_THREADS / 64, TR_COLS = 64, TR_UNROLL = 8;
 
 __global__ void __launch_bounds__(TR_THREADS)
 hqr_trailing_kernel(const HqrMat* __restrict__ mats, double* __restrict__ buf, const double* __restrict__ vt, int r0)
@@ -261,6 +278,7 @@ hqr_trailing_kernel(const HqrMat* __restrict__ mats, double* __restrict__ buf, c
             const double* vr = V + (int64_t)(i + u * TR_WAVES) * 32;
 #pragma unroll
             for (int k = 0; k < 32; ++k) acc[k] += vr[k] * cv[u];
+            asm volatile("" ::: "memory");          // one reflector row (64 SGPRs) at a time: hoisting all of them spills
         }
     }
     for (; i < nrem; i += TR_WAVES) {
@@ -305,8 +323,11 @@ hqr_trailing_kernel(const HqrMat* __restrict__ mats, double* __restrict__ buf, c
             double s = 0.0;
 #pragma unroll
             for (int k = 0; k < 32; ++k) s += vr[k] * w[k];
-            if (valid) C[(int64_t)(i + u * TR_WAVES) * ldb] = cv[u] - s;
+            cv[u] -= s;
+            asm volatile("" ::: "memory");
         }
+#pragma unroll
+        for (int u = 0; u < TR_UNROLL; ++u) if (valid) C[(int64_t)(i + u * TR_WAVES) * ldb] = cv[u];
     }
     for (; i < nrem; i += TR_WAVES) {
         const double cv = C[(int64_t)i * ldb];
