@@ -11,6 +11,7 @@
 // dmrgx_rdm_eigenvectors (== FillRotation_BlockDiag, :2006-2057).
 #include "ggemm.h"
 #include "hqr.h"
+#include <chrono>
 #include <algorithm>
 #include <cmath>
 #include <memory>
@@ -403,6 +404,15 @@ extern "C" dmrgx_status dmrgx_rdm_create_warm(const dmrgx_sectors* left, const d
     std::unique_ptr<dmrgx_rdm> P(new (std::nothrow) dmrgx_rdm());
     if (!P) DMRGX_FAIL(DMRGX_ERR_MEM, "out of host memory");
     P->nblocks = nblocks;
+    static const bool stage_trace = getenv("DMRGX_RDM_TRACE") != nullptr;      // developer aid: wall time of every stage (synchronising)
+    auto t_prev = std::chrono::steady_clock::now();
+    auto stage = [&](const char* name) {
+        if (!stage_trace) return;
+        (void)hipStreamSynchronize(st);
+        const auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "[rdm] stage %-10s %8.3f ms\n", name, std::chrono::duration<double, std::milli>(t - t_prev).count());
+        t_prev = t;
+    };
     // ---- layout -------------------------------------------------------------------------------------------
     std::vector<int64_t> off(nblocks + 1, 0);
     int64_t total = 0;
@@ -483,6 +493,7 @@ extern "C" dmrgx_status dmrgx_rdm_create_warm(const dmrgx_sectors* left, const d
     hipLaunchKernelGGL(rdm_init_kernel, dim3(64, nm), dim3(256), 0, st, dm, buf);
     DMRGX_HIP(hipGetLastError());
 
+    stage("layout");
     // ---- Psi^T and the 2*nblocks Gram matrices in one grouped GEMM launch -------------------------------------
     {
         std::vector<TrTile> tt;
@@ -542,6 +553,7 @@ extern "C" dmrgx_status dmrgx_rdm_create_warm(const dmrgx_sectors* left, const d
         }
     }
 
+    stage("gram");
     // ---- warm start: A <- E A E^T, V <- E^T for matrices whose previous eigenbasis E (eigenvectors as rows) is supplied.
     //      In a settled DMRG sweep the basis of the previous visit nearly diagonalises the new density matrix (measured:
     //      off^2/total^2 ~ 1e-5 instead of 0.5), which saves the first ~3 of ~10 Jacobi sweeps; the rest is the linearly
@@ -574,6 +586,7 @@ extern "C" dmrgx_status dmrgx_rdm_create_warm(const dmrgx_sectors* left, const d
         hipLaunchKernelGGL(qr_scatter_kernel, dim3(gx, nm), dim3(256), 0, st, d_qm.as<HqrMat>(), d_qperm.as<int32_t>(), d_qpoff.as<int64_t>(), d_qeoff.as<int64_t>(), buf);
         DMRGX_HIP(hipGetLastError());
     }
+    stage("qr");
     bool any_warm = false;
     for (int mi = 0; mi < nm; ++mi) any_warm = any_warm || warm_src[mi];
     if (any_warm) {
@@ -619,6 +632,7 @@ extern "C" dmrgx_status dmrgx_rdm_create_warm(const dmrgx_sectors* left, const d
         }
     }
 
+    stage("transform");
     // ---- batched block Jacobi ------------------------------------------------------------------------------------
     std::vector<double> norms((size_t)2 * nm * NORM_BLOCKS);
     const int rounds = std::max(1, max_nb - 1);
@@ -666,6 +680,7 @@ extern "C" dmrgx_status dmrgx_rdm_create_warm(const dmrgx_sectors* left, const d
         hipLaunchKernelGGL(normalize_columns_kernel, dim3((max_npad + 63) / 64, nm), dim3(256), 0, st, dm, buf);
         DMRGX_HIP(hipGetLastError());
     }
+    stage("jacobi");
     // ---- eigenvalues as Rayleigh quotients of the renormalised eigenvectors: lambda = |Psi^T u|^2 (rho_L) / |Psi v|^2
     //      (rho_R).  Relative accuracy ~eps instead of the c*n*eps*||rho|| of the rotated diagonal, which matters for
     //      TruncErr = 1 - sum of kept eigenvalues (include/DMRGBlockContainer.hpp:1872-1875).
@@ -706,6 +721,7 @@ extern "C" dmrgx_status dmrgx_rdm_create_warm(const dmrgx_sectors* left, const d
         DMRGX_HIP(hipMemcpyAsync(rq.data(), buf + rq_base, rq.size() * sizeof(double), hipMemcpyDeviceToHost, st));
         DMRGX_HIP(hipStreamSynchronize(st));
     }
+    stage("rayleigh");
     // ---- sort descending on the host, remember the column of V for each rank ------------------------------------
     P->eig.resize(nm); P->perm.resize(nm); P->perm_off.resize(nm);
     std::vector<int32_t> allperm;
@@ -724,6 +740,7 @@ extern "C" dmrgx_status dmrgx_rdm_create_warm(const dmrgx_sectors* left, const d
         allperm.insert(allperm.end(), real.begin(), real.end());
     }
     DMRGX_CHK(upload(P->d_perm, allperm, st));
+    stage("sort");
     *out = P.release();
     return DMRGX_OK;
 }
