@@ -93,7 +93,7 @@ hqr_panel_kernel(const HqrMat* __restrict__ mats, double* __restrict__ buf, int 
 // keeps the rows rb, rb+64, .. of the four panel columns 4cb..4cb+3 in registers, so one reflector element read from LDS
 // feeds eight FMAs (the first version, one column per thread, was bound by LDS reads of the reflector).  Three barriers
 // per column: the norm of the next column is accumulated while the current reflector is applied, and column j of T is
-// finished one iteration late.  One instantiation per size class, launched only when the class is populated.
+// finished one iteration late.  One body per size class (rows per thread), selected per matrix inside one launch.
 // a(lane) + a(lane ^ 8) + .. over lane bits 3, 4, 5 without the LDS crossbar: DPP row rotate, then the gfx950 row / half swaps
 // (v_permlane16_swap: odd rows of the first operand <-> even rows of the second; v_permlane32_swap: upper half <-> lower half;
 // with both operands equal, result[0] + result[1] = own + partner in every lane).
@@ -114,16 +114,9 @@ __device__ __forceinline__ double sum_lane_bits_345(double a)
 __device__ __forceinline__ double sel4(const double (&x)[4], int q) { return q == 0 ? x[0] : (q == 1 ? x[1] : (q == 2 ? x[2] : x[3])); }
 
 template <int RR>
-__global__ void __launch_bounds__(HR_THREADS)
-hqr_panel_regs_kernel(const HqrMat* __restrict__ mats, double* __restrict__ buf, int r0)
+__device__ __forceinline__ void hqr_panel_regs_body(const HqrMat& m, double* __restrict__ buf, int r0, double* vsm, double (*red)[32], double (*Tm)[33], double* sred, double* piv)
 {
-    __shared__ double vsm[64 * RR];
-    __shared__ double red[HR_WAVES][32];
-    __shared__ double Tm[32][33];
-    __shared__ double sred[HR_WAVES], piv[1];
-    const HqrMat m = mats[blockIdx.x];
     const int nrem = m.n - r0;
-    if (nrem <= (RR > 4 ? 32 * RR : 0) || nrem > 64 * RR) return;          // another size class (or nothing left)
     const int pw = min(32, nrem), ldb = 2 * m.n;
     const int tid = threadIdx.x, cb = tid & 7, rb = tid >> 3, lane = tid & 63, wave = tid >> 6;
     const double* B = buf + m.b_off + (int64_t)r0 * ldb + r0 + 4 * cb;
@@ -240,6 +233,23 @@ hqr_panel_regs_kernel(const HqrMat* __restrict__ mats, double* __restrict__ buf,
         }
     }
     for (int e = tid; e < 32 * 32; e += HR_THREADS) buf[m.t_off + e] = Tm[e >> 5][e & 31];
+}
+
+// One launch for all size classes: kernels of one stream run one after the other, so a launch per class made a panel step cost
+// the SUM of the classes' latencies (matrices of several sizes are in flight in almost every step).
+__global__ void __launch_bounds__(HR_THREADS)
+hqr_panel_regs_kernel(const HqrMat* __restrict__ mats, double* __restrict__ buf, int r0)
+{
+    __shared__ double vsm[HR_MAX_ROWS];
+    __shared__ double red[HR_WAVES][32];
+    __shared__ double Tm[32][33];
+    __shared__ double sred[HR_WAVES], piv[1];
+    const HqrMat m = mats[blockIdx.x];
+    const int nrem = __builtin_amdgcn_readfirstlane(m.n - r0);
+    if (nrem <= 0 || nrem > HR_MAX_ROWS) return;          // nothing left, or a panel of hqr_panel_kernel
+    if (nrem <= 256) hqr_panel_regs_body<4>(m, buf, r0, vsm, red, Tm, sred, piv);
+    else if (nrem <= 512) hqr_panel_regs_body<8>(m, buf, r0, vsm, red, Tm, sred, piv);
+    else hqr_panel_regs_body<16>(m, buf, r0, vsm, red, Tm, sred, piv);
 }
 
 constexpr int TR_THREADS = 512, TR_WAVES = TR_THREADS / 64, TR_COLS = 64, TR_UNROLL = 8;
@@ -464,12 +474,10 @@ dmrgx_status hqr_batched(const std::vector<HqrMat>& mats, const HqrMat* d_mats, 
     for (int r0 = 0; r0 < max_n; r0 += 32) {
         const int nrem = max_n - r0, pw = std::min(32, nrem);
         const unsigned tiles = (unsigned)((max_n - r0 - pw + TR_COLS - 1) / TR_COLS + (max_n + TR_COLS - 1) / TR_COLS);
-        bool cls[4] = {false, false, false, false};          // size classes present at this panel: <=256, <=512, <=1024, longer
-        for (const HqrMat& m : mats) { const int r = m.n - r0; if (r > 0) cls[r <= 256 ? 0 : (r <= 512 ? 1 : (r <= HR_MAX_ROWS ? 2 : 3))] = true; }
-        if (cls[3]) hipLaunchKernelGGL(hqr_panel_kernel, dim3(nm), dim3(HQ_THREADS), 0, st, d_mats, buf, r0);
-        if (cls[2]) hipLaunchKernelGGL(hqr_panel_regs_kernel<16>, dim3(nm), dim3(HR_THREADS), 0, st, d_mats, buf, r0);
-        if (cls[1]) hipLaunchKernelGGL(hqr_panel_regs_kernel<8>, dim3(nm), dim3(HR_THREADS), 0, st, d_mats, buf, r0);
-        if (cls[0]) hipLaunchKernelGGL(hqr_panel_regs_kernel<4>, dim3(nm), dim3(HR_THREADS), 0, st, d_mats, buf, r0);
+        bool regs = false, longp = false;                    // panels of up to HR_MAX_ROWS rows (registers) / longer ones
+        for (const HqrMat& m : mats) { const int r = m.n - r0; if (r > HR_MAX_ROWS) longp = true; else if (r > 0) regs = true; }
+        if (longp) hipLaunchKernelGGL(hqr_panel_kernel, dim3(nm), dim3(HQ_THREADS), 0, st, d_mats, buf, r0);
+        if (regs) hipLaunchKernelGGL(hqr_panel_regs_kernel, dim3(nm), dim3(HR_THREADS), 0, st, d_mats, buf, r0);
         static const bool valu_update = getenv("DMRGX_HQR_VALU") != nullptr;      // developer aid: the plain-FMA block-reflector update
         if (valu_update) hipLaunchKernelGGL(hqr_trailing_kernel, dim3(tiles, nm), dim3(TR_THREADS), 0, st, d_mats, buf, (const double*)buf, r0);
         else hipLaunchKernelGGL(hqr_trailing_mfma_kernel, dim3(tiles, nm), dim3(TM_THREADS), 0, st, d_mats, buf, (const double*)buf, r0);
