@@ -85,7 +85,7 @@ public:
         if (num_states_in == PETSC_DEFAULT) { num_states = 1; for (PetscInt i = 0; i < num_sites; ++i) num_states *= loc_dim(); }
         else num_states = num_states_in;
         SzData.assign((size_t)num_sites, nullptr); SpData.assign((size_t)num_sites, nullptr); SmData.assign((size_t)num_sites, nullptr);
-        init = PETSC_TRUE; init_once = PETSC_TRUE; init_Sm = PETSC_FALSE;
+        init = PETSC_TRUE; init_once = PETSC_TRUE; init_Sm = PETSC_FALSE; ops_pruned = PETSC_FALSE; dead = PETSC_FALSE;
         if (!init_ops && num_sites > 0) {}
         else if (init_ops && num_sites == 1) {
             ierr = Magnetization.Initialize(mpi_comm, loc_qn_list(), loc_qn_size()); CHKERRQ(ierr);
@@ -195,8 +195,9 @@ public:
         PetscBool flg = PETSC_FALSE;
         PetscErrorCode ierr = PetscTestDirectory(dir.c_str(), 'r', &flg); CHKERRQ(ierr);
         if (!flg) SETERRQ1(mpi_comm, 1, "Directory %s does not exist. Please verify that -scratch_dir is specified correctly.", dir.c_str());
-        for (PetscInt i = 0; i < num_sites; ++i) { if (WriteOperatorFile(OpFilename(dir, "Sz", (size_t)i), SzData[(size_t)i])) SETERRQ1(mpi_comm, PETSC_ERR_FILE_OPEN, "cannot write %s", OpFilename(dir, "Sz", (size_t)i).c_str()); }
-        for (PetscInt i = 0; i < num_sites; ++i) { if (WriteOperatorFile(OpFilename(dir, "Sp", (size_t)i), SpData[(size_t)i])) SETERRQ1(mpi_comm, PETSC_ERR_FILE_OPEN, "cannot write %s", OpFilename(dir, "Sp", (size_t)i).c_str()); }
+        /* pruned site operators (PruneOperators) have no file; InitializeFromDisk restores them as absent */
+        for (PetscInt i = 0; i < num_sites; ++i) { if (!SzData[(size_t)i] && ops_pruned) continue; if (WriteOperatorFile(OpFilename(dir, "Sz", (size_t)i), SzData[(size_t)i])) SETERRQ1(mpi_comm, PETSC_ERR_FILE_OPEN, "cannot write %s", OpFilename(dir, "Sz", (size_t)i).c_str()); }
+        for (PetscInt i = 0; i < num_sites; ++i) { if (!SpData[(size_t)i] && ops_pruned) continue; if (WriteOperatorFile(OpFilename(dir, "Sp", (size_t)i), SpData[(size_t)i])) SETERRQ1(mpi_comm, PETSC_ERR_FILE_OPEN, "cannot write %s", OpFilename(dir, "Sp", (size_t)i).c_str()); }
         if (H) { if (WriteOperatorFile(OpFilename(dir, "H", 0), H)) SETERRQ1(mpi_comm, PETSC_ERR_FILE_OPEN, "cannot write %s", OpFilename(dir, "H", 0).c_str()); }
         {
             FILE* fp = fopen((dir + "BlockInfo.dat").c_str(), "w");
@@ -204,6 +205,7 @@ public:
             fprintf(fp, "%-30s %zu\n%-30s %zu\n%-30s %d\n%-30s %d\n%-30s %lld\n%-30s %lld\n%-30s %lld\n", "NumBytesPetscInt", sizeof(PetscInt),
                     "NumBytesPetscScalar", sizeof(PetscScalar), "PetscUseComplex", 0, "SpinTypeKey", (int)spin_type, "NumSites", LLD(num_sites),
                     "NumStates", LLD(num_states), "NumSectors", LLD(Magnetization.NumSectors()));
+            if (ops_pruned) fprintf(fp, "%-30s %d\n", "OpsPruned", 1);
             fclose(fp);
         }
         {
@@ -247,10 +249,18 @@ public:
         if ((long long)ql.size() != info["NumSectors"]) SETERRQ2(comm_in, 1, "QuantumNumbers.dat has %lld sectors, BlockInfo.dat says %lld.", LLD(ql.size()), info["NumSectors"]);
         PetscErrorCode ierr = Initialize(comm_in, (PetscInt)info["NumSites"], ql, qs, PETSC_FALSE); CHKERRQ(ierr);
         if (num_states != (PetscInt)info["NumStates"]) SETERRQ2(comm_in, 1, "Sector sizes add up to %lld states, BlockInfo.dat says %lld.", LLD(num_states), info["NumStates"]);
+        const bool pruned_on_disk = info.count("OpsPruned") && info["OpsPruned"] != 0;
         for (PetscInt i = 0; i < num_sites; ++i) {
+            if (pruned_on_disk) {       /* a checkpoint of a pruned block holds the resident site operators only */
+                PetscBool hz = PETSC_FALSE, hp = PETSC_FALSE;
+                ierr = PetscTestFile(OpFilename(dir, "Sz", (size_t)i).c_str(), 'r', &hz); CHKERRQ(ierr);
+                ierr = PetscTestFile(OpFilename(dir, "Sp", (size_t)i).c_str(), 'r', &hp); CHKERRQ(ierr);
+                if (!hz || !hp) { ops_pruned = PETSC_TRUE; continue; }
+            }
             if (ReadOperatorFile(OpFilename(dir, "Sz", (size_t)i), SzData[(size_t)i])) SETERRQ1(comm_in, PETSC_ERR_FILE_OPEN, "cannot read %s", OpFilename(dir, "Sz", (size_t)i).c_str());
             if (ReadOperatorFile(OpFilename(dir, "Sp", (size_t)i), SpData[(size_t)i])) SETERRQ1(comm_in, PETSC_ERR_FILE_OPEN, "cannot read %s", OpFilename(dir, "Sp", (size_t)i).c_str());
         }
+        if (pruned_on_disk) ops_pruned = PETSC_TRUE;
         {   /* a block without a Hamiltonian (fixtures) has no H file */
             PetscBool has_h = PETSC_FALSE;
             ierr = PetscTestFile(OpFilename(dir, "H", 0).c_str(), 'r', &has_h); CHKERRQ(ierr);
@@ -303,6 +313,7 @@ public:
         switch (OpType) { case OpSm: Op = &SmData; break; case OpSz: Op = &SzData; break; case OpSp: Op = &SpData; break;
             default: SETERRQ(mpi_comm, PETSC_ERR_ARG_WRONG, "Incorrect operator type."); }
         for (PetscInt i = 0; i < num_sites; ++i) {
+            if (!(*Op)[i] && ops_pruned) continue;       /* not resident: pruned by the sweep schedule (see PruneOperators) */
             if (!(*Op)[i]) SETERRQ2(mpi_comm, PETSC_ERR_ARG_CORRUPT, "%s[%lld] matrix not yet created.", OpToCStr(OpType), LLD(i));
             if ((*Op)[i]->N() != num_states)
                 SETERRQ4(mpi_comm, PETSC_ERR_ARG_WRONG, "%s[%lld] matrix dimension does not match the number of states. Expected %lld. Got %lld.",
@@ -313,6 +324,7 @@ public:
     PetscErrorCode CheckOperators() const
     {
         if (!init) SETERRQ(mpi_comm, PETSC_ERR_ARG_CORRUPT, "Block not yet initialized.");
+        if (dead) SETERRQ(mpi_comm, PETSC_ERR_ARG_WRONGSTATE, "The operators of this block were never computed: the sweep schedule marked it as a block that no later step reads.");
         PetscErrorCode ierr = CheckOperatorArray(OpSz); CHKERRQ(ierr);
         ierr = CheckOperatorArray(OpSp); CHKERRQ(ierr);
         if (init_Sm) { ierr = CheckOperatorArray(OpSm); CHKERRQ(ierr); }
@@ -353,6 +365,7 @@ public:
         const std::vector<Mat>* Op;
         switch (OpType) { case OpSm: Op = &SmData; break; case OpSz: Op = &SzData; break; case OpSp: Op = &SpData; break;
             default: SETERRQ(mpi_comm, PETSC_ERR_ARG_WRONG, "Incorrect operator type."); }
+        if (!(*Op)[isite] && ops_pruned) return 0;
         return MatCheckOperatorBlocks(OpType, (*Op)[isite]);
     }
     PetscErrorCode CheckOperatorBlocks() const
@@ -372,6 +385,7 @@ public:
         if (init_Sm) SETERRQ(mpi_comm, 1, "Sm was previously initialized. Call DestroySm() first.");
         PetscErrorCode ierr = CheckOperatorArray(OpSp); CHKERRQ(ierr);
         for (PetscInt i = 0; i < num_sites; ++i) {
+            if (!SpData[i]) { SmData[i] = nullptr; continue; }         /* pruned site */
             auto v = std::make_shared<dmrgx_host::SectorMat>();
             v->transpose_of = SpData[i]; v->shift = OpSm; v->sizes = SpData[i]->sizes;
             SmData[i] = v;
@@ -388,8 +402,33 @@ public:
         return 0;
     }
 
-    /** this block's operators <- RotMatT . Source's operators . RotMatT^T, all of them in one device call. */
-    PetscErrorCode RotateOperators(SpinBase& Source, const Mat& RotMatT_in)
+    /** Engine extension (the reference spills whole blocks to disk instead, src/DMRGBlock.cpp:1090-1103): releases the
+        Sz(i)/Sp(i) of every site with keep_sites[i] == 0.  A later access to a released operator fails loudly (null
+        handle: "Term refers to an operator that does not exist", "operator not resident"), it is never silently zero. */
+    PetscErrorCode PruneOperators(const std::vector<char>& keep_sites)
+    {
+        if (!init) return 0;
+        for (PetscInt i = 0; i < num_sites; ++i) {
+            if ((size_t)i < keep_sites.size() && keep_sites[(size_t)i]) continue;
+            if (SzData[i] || SpData[i]) ops_pruned = PETSC_TRUE;
+            SzData[i] = nullptr; SpData[i] = nullptr;         /* cells are shared_ptr views: the buffers go when the last view goes */
+            if (init_Sm) SmData[i] = nullptr;
+        }
+        return 0;
+    }
+    PetscInt NumResidentSites() const { PetscInt n = 0; for (PetscInt i = 0; i < num_sites; ++i) n += (SzData[i] && SpData[i]); return n; }
+    PetscBool OpsPruned() const { return ops_pruned; }
+    void SetOpsPruned() { ops_pruned = PETSC_TRUE; }
+    /** A block whose sector table is known (step records) but whose operators are never computed because no later step
+        of the sweep schedule reads them; any use as an input fails in CheckOperators. */
+    void MarkDead() { dead = PETSC_TRUE; ops_pruned = PETSC_TRUE; }
+    PetscBool Dead() const { return dead; }
+    PetscInt NumRotatedOps() const { return num_rotated_ops; }
+
+    /** this block's operators <- RotMatT . Source's operators . RotMatT^T, all of them in one device call.
+        keep_sites (engine extension, default: every site): only the site operators with keep_sites[i] != 0 that Source
+        holds are rotated; the others stay absent (see PruneOperators).  H is always rotated. */
+    PetscErrorCode RotateOperators(SpinBase& Source, const Mat& RotMatT_in, const std::vector<char>* keep_sites = nullptr)
     {
         if (!init) SETERRQ(mpi_comm, PETSC_ERR_ARG_CORRUPT, "Block not yet initialized.");
         if (init_Sm) { PetscErrorCode ierr = DestroySm(); CHKERRQ(ierr); }
@@ -406,7 +445,12 @@ public:
         for (int32_t a = 0; a < nn; ++a) new_of_old[R.old_sector[a]] = a;
 
         std::vector<Mat> src; std::vector<Mat> dst;
-        for (PetscInt i = 0; i < num_sites; ++i) { src.push_back(Source.SpData[i]); src.push_back(Source.SzData[i]); }
+        std::vector<PetscInt> src_site;                 /* site of src[2j], src[2j+1] */
+        for (PetscInt i = 0; i < num_sites; ++i) {
+            const bool want = !keep_sites || ((size_t)i < keep_sites->size() && (*keep_sites)[(size_t)i]);
+            if (!want || !Source.SpData[i] || !Source.SzData[i]) { ops_pruned = PETSC_TRUE; continue; }
+            src.push_back(Source.SpData[i]); src.push_back(Source.SzData[i]); src_site.push_back(i);
+        }
         src.push_back(Source.H);
         const size_t nops = src.size();
         std::vector<dmrgx_secop> ops(nops);
@@ -453,8 +497,9 @@ public:
         for (int32_t a = 0; a < nn; ++a) rts[a] = R.rt[a]->dev_ro();
         dmrgx_rotation rot{nn, R.old_sector.data(), R.kept.data(), rts.data()};
         if (dmrgx_rotate_ops(&olds, &rot, (int32_t)nops, ops.data(), dpp.data(), nullptr)) SETERRQ1(mpi_comm, 1, "dmrgx_rotate_ops: %s", dmrgx_last_error());
-        for (PetscInt i = 0; i < num_sites; ++i) { SpData[i] = dst[2 * i]; SzData[i] = dst[2 * i + 1]; }
+        for (size_t j = 0; j < src_site.size(); ++j) { SpData[(size_t)src_site[j]] = dst[2 * j]; SzData[(size_t)src_site[j]] = dst[2 * j + 1]; }
         H = dst[nops - 1];
+        num_rotated_ops = (PetscInt)nops;
         PetscErrorCode ierr = CheckOperatorBlocks(); CHKERRQ(ierr);
         return SaveAndDestroy();
     }
@@ -481,6 +526,8 @@ protected:
     PetscMPIInt mpi_rank = 0, mpi_size = 1;
     PetscBool mpi_init = PETSC_FALSE, init = PETSC_FALSE, init_once = PETSC_FALSE, init_Sm = PETSC_FALSE;
     PetscBool verbose = PETSC_FALSE, saved = PETSC_FALSE, init_save = PETSC_FALSE, disk_set = PETSC_FALSE;
+    PetscBool ops_pruned = PETSC_FALSE, dead = PETSC_FALSE;
+    PetscInt num_rotated_ops = 0;
     PetscInt num_sites = 0, num_states = 0;
     Spin_t spin_type = SpinOneHalf;
     PetscInt _loc_dim = 2;

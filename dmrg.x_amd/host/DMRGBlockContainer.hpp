@@ -116,6 +116,8 @@ public:
         ierr = PetscOptionsGetBool(NULL, NULL, "-wavefunction_guess", &use_guess, NULL); CHKERRQ(ierr);
         ierr = PetscOptionsGetBool(NULL, NULL, "-rdm_warm_start", &use_rdm_warm, NULL); CHKERRQ(ierr);
         ierr = PetscOptionsGetBool(NULL, NULL, "-corr_batch", &use_corr_batch, NULL); CHKERRQ(ierr);
+        ierr = PetscOptionsGetBool(NULL, NULL, "-prune_ops", &prune_ops, NULL); CHKERRQ(ierr);
+        ierr = PetscOptionsGetBool(NULL, NULL, "-step_profile", &step_profile, NULL); CHKERRQ(ierr);
 
         PetscBool opt = PETSC_FALSE;
         ierr = PetscOptionsGetString(NULL, NULL, "-scratch_dir", path, PETSC_MAX_PATH_LEN, &opt); CHKERRQ(ierr);
@@ -138,6 +140,8 @@ public:
         fprintf(fp_entanglement, "[\n");
         ierr = PetscFOpen(mpi_comm, (data_dir + "Correlations.json").c_str(), "w", &fp_corr); CHKERRQ(ierr);
         ierr = PetscFOpen(mpi_comm, (data_dir + "DMRGRun.json").c_str(), "w", &fp_data); CHKERRQ(ierr);
+        ierr = PetscFOpen(mpi_comm, (data_dir + "KronStats.json").c_str(), "w", &fp_kron); CHKERRQ(ierr);
+        fprintf(fp_kron, "[\n");
         fprintf(fp_data, "{\n"); Ham.SaveOut(fp_data); fprintf(fp_data, ",\n  \"QNSector\": %g", qn_sector); fflush(fp_data);
 
         if (!mpi_rank) {
@@ -195,6 +199,7 @@ public:
         if (m.EnvOps.empty()) m.desc3 += "1 ";
         m.desc3 += ") >";
         measurements.push_back(m);
+        need_built = false;             /* the residency tables depend on the registered correlators */
         return 0;
     }
 
@@ -243,8 +248,16 @@ public:
             env_numsites += env_add; full_cluster += env_add;
             if (env_numsites < 1 || env_numsites > sys_ninit) SETERRQ1(mpi_comm, 1, "Incorrect number of sites. Got %lld.", LLD(env_numsites));
             if (!mpi_rank) { printf(" %s  %lld/%lld/%lld\n", "WARMUP", LLD(LoopIdx), LLD(StepIdx), LLD(GlobIdx)); PrintBlocks(sys_ninit, env_numsites); }
+            /* operator residency (engine extension, -prune_ops 0 disables): the new system block carries the sites a later
+               inter-block term or a registered correlator can touch; the re-derived environment block only coupling sites */
+            StepHints hints;
+            if (prune_ops) {
+                hints.keep_sys = NeedMask(sys_ninit + 1, true, false);
+                hints.keep_env = NeedMask(env_numsites + 1, env_numsites == sys_ninit, false);
+            }
             ierr = SingleDMRGStep(sys_blocks[sys_ninit - 1], sys_blocks[env_numsites - 1], mwarmup,
-                                  sys_blocks[sys_ninit], sys_blocks[env_numsites], PetscBool(sys_ninit + 1 == num_sites / 2)); CHKERRQ(ierr);
+                                  sys_blocks[sys_ninit], sys_blocks[env_numsites], PetscBool(sys_ninit + 1 == num_sites / 2), &hints); CHKERRQ(ierr);
+            if (prune_ops) { ierr = PruneConsumed(sys_ninit - 1); CHKERRQ(ierr); }
             ++sys_ninit;
         }
         if (sys_ninit != num_sites / 2) SETERRQ2(mpi_comm, 1, "Expected sys_ninit = num_sites/2 = %lld. Got %lld.", LLD(num_sites / 2), LLD(sys_ninit));
@@ -302,12 +315,24 @@ public:
         for (PetscInt iblock = num_sites / 2; iblock < num_sites - min_block - 2; ++iblock) {
             const PetscInt insys = iblock - 1, inenv = num_sites - iblock - 3, outsys = iblock, outenv = num_sites - iblock - 2;
             if (!mpi_rank) { printf(" %s  %lld/%lld/%lld\n", "SWEEP", LLD(LoopIdx), LLD(StepIdx), LLD(GlobIdx)); PrintBlocks(insys + 1, inenv + 1); }
-            ierr = SingleDMRGStep(sys_blocks[insys], sys_blocks[inenv], MStates, sys_blocks[outsys], sys_blocks[outenv]); CHKERRQ(ierr);
+            /* centre -> edge: the growing block is read again as a LEFT block only; the re-derived shrinking block
+               (index outenv) is overwritten by the way back before any step reads it: its operators are not computed */
+            StepHints hints;
+            if (prune_ops) { hints.keep_sys = NeedMask(outsys + 1, false, true); hints.dead_env = true; }
+            ierr = SingleDMRGStep(sys_blocks[insys], sys_blocks[inenv], MStates, sys_blocks[outsys], sys_blocks[outenv], PETSC_FALSE, &hints); CHKERRQ(ierr);
         }
         for (PetscInt iblock = min_block; iblock < num_sites / 2; ++iblock) {
             const PetscInt insys = num_sites - iblock - 3, inenv = iblock - 1, outsys = num_sites - iblock - 2, outenv = iblock;
             if (!mpi_rank) { printf(" %s  %lld/%lld/%lld\n", "SWEEP", LLD(LoopIdx), LLD(StepIdx), LLD(GlobIdx)); PrintBlocks(insys + 1, inenv + 1); }
-            ierr = SingleDMRGStep(sys_blocks[insys], sys_blocks[inenv], MStates, sys_blocks[outsys], sys_blocks[outenv], PetscBool(outsys == outenv)); CHKERRQ(ierr);
+            /* edge -> centre: the small block grows towards the measurement at the centre (coupling + correlator sites); the
+               re-derived large block (index outsys) is overwritten by the next sweep before any step reads it */
+            StepHints hints;
+            if (prune_ops) {
+                if (outsys == outenv) hints.keep_sys = NeedMask(outsys + 1, false, false);
+                else { hints.keep_env = NeedMask(outenv + 1, true, false); hints.dead_sys = true; }
+            }
+            ierr = SingleDMRGStep(sys_blocks[insys], sys_blocks[inenv], MStates, sys_blocks[outsys], sys_blocks[outenv], PetscBool(outsys == outenv), &hints); CHKERRQ(ierr);
+            if (prune_ops) { ierr = PruneConsumed(inenv); CHKERRQ(ierr); }
         }
         sweeps_mstates.push_back(MStates);
         ierr = PetscTime(&ts1); CHKERRQ(ierr);
@@ -327,6 +352,7 @@ public:
         if (fp_step) { fprintf(fp_step, "\n  ]\n}\n"); fclose(fp_step); fp_step = NULL; }
         if (fp_timings) { fprintf(fp_timings, "\n  ]\n}\n"); fclose(fp_timings); fp_timings = NULL; }
         if (fp_entanglement) { fprintf(fp_entanglement, "\n]\n"); fclose(fp_entanglement); fp_entanglement = NULL; }
+        if (fp_kron) { fprintf(fp_kron, "\n]\n"); fclose(fp_kron); fp_kron = NULL; }
         if (fp_corr) {
             if (!corr_headers_printed) { PetscErrorCode e2 = PrintCorrelationHeaders(); CHKERRQ(e2); }
             fprintf(fp_corr, "\n  ]\n}\n"); fclose(fp_corr); fp_corr = NULL;
@@ -352,8 +378,13 @@ public:
 
     /** One DMRG step: enlarge both blocks by a site, solve the superblock ground state in the target sector, truncate
         to at most MStates states per block and rotate every operator into the new bases. */
+    /** Residency hints of the sweep schedule for the two output blocks of a step (engine extension; the reference keeps
+        every Sz(i)/Sp(i) of every block and spills whole blocks to disk, src/DMRGBlock.cpp:1090-1103): which site operators
+        to rotate (empty = all), or that the block is never read again (only its sector table is recorded). */
+    struct StepHints { std::vector<char> keep_sys, keep_env; bool dead_sys = false, dead_env = false; };
+
     PetscErrorCode SingleDMRGStep(Block& SysBlock, Block& EnvBlock, const PetscInt& MStates, Block& SysBlockOut, Block& EnvBlockOut,
-                                  PetscBool do_measurements = PETSC_FALSE)
+                                  PetscBool do_measurements = PETSC_FALSE, const StepHints* hints = nullptr)
     {
         PetscErrorCode ierr;
         PetscLogDouble t0 = t0abs, tenlr, tkron, tdiag, trdms, trotb;
@@ -385,6 +416,10 @@ public:
         if (!H) SETERRQ(mpi_comm, 1, "H is null.");
         ierr = PetscTime(&tkron); CHKERRQ(ierr);
         timings.tKron = tkron - tenlr;
+        dmrgx_kron_info kinfo;
+        memset(&kinfo, 0, sizeof(kinfo));
+        if (dmrgx_kron_plan_info(H->plan, &kinfo)) SETERRQ1(mpi_comm, 1, "dmrgx_kron_plan_info: %s", dmrgx_last_error());
+        if (step_profile && dmrgx_kron_plan_timing(H->plan, 1)) SETERRQ1(mpi_comm, 1, "dmrgx_kron_plan_timing: %s", dmrgx_last_error());
 
         if (debug_symm) {   /* -debug_check_symmetry: <u,Hv> == <Hu,v> on random vectors (the reference's H is symmetric) */
             Vec u, v, Hu, Hv;
@@ -415,6 +450,9 @@ public:
             if (dmrgx_eigs_lowest(H->plan, &o, &gse_r, gsv_r->buf->dev_uninitialised(), &st, nullptr))
                 SETERRQ1(mpi_comm, 1, "dmrgx_eigs_lowest: %s", dmrgx_last_error());
             timings.nMatMult = st.n_matvec; total_matmults += st.n_matvec; total_eigs_seconds += st.seconds;
+            double ms4[4] = {0, 0, 0, 0}; int64_t napp = 0;
+            if (step_profile && dmrgx_kron_plan_timing_read(H->plan, ms4, &napp)) SETERRQ1(mpi_comm, 1, "dmrgx_kron_plan_timing_read: %s", dmrgx_last_error());
+            ierr = SaveKronStats(kinfo, SysBlock, EnvBlock, (PetscInt)Terms.size(), st.n_matvec, st.seconds, ms4, napp); CHKERRQ(ierr);
         }
         step.GSEnergy = gse_r;
         ierr = MatDestroy_KronSumShell(&H); CHKERRQ(ierr);
@@ -450,11 +488,14 @@ public:
         timings.tRdms = trdms - tdiag;
 
         ierr = SysBlockOut.Initialize(SysBlockEnl.NumSites(), BT_L.QN); CHKERRQ(ierr);
-        ierr = SysBlockOut.RotateOperators(SysBlockEnl, BT_L.RotMatT); CHKERRQ(ierr);
+        if (hints && hints->dead_sys && !same) SysBlockOut.MarkDead();
+        else { ierr = SysBlockOut.RotateOperators(SysBlockEnl, BT_L.RotMatT, hints && !hints->keep_sys.empty() ? &hints->keep_sys : nullptr); CHKERRQ(ierr); }
         if (!same) {
             ierr = EnvBlockOut.Initialize(EnvBlockEnl.NumSites(), BT_R.QN); CHKERRQ(ierr);
-            ierr = EnvBlockOut.RotateOperators(EnvBlockEnl, BT_R.RotMatT); CHKERRQ(ierr);
+            if (hints && hints->dead_env) EnvBlockOut.MarkDead();
+            else { ierr = EnvBlockOut.RotateOperators(EnvBlockEnl, BT_R.RotMatT, hints && !hints->keep_env.empty() ? &hints->keep_env : nullptr); CHKERRQ(ierr); }
         }
+        timings.nRotOps = (SysBlockOut.Dead() ? 0 : SysBlockOut.NumRotatedOps()) + ((same || EnvBlockOut.Dead()) ? 0 : EnvBlockOut.NumRotatedOps());
         step.NumStates_SysRot = SysBlockOut.NumStates(); step.NumStates_EnvRot = EnvBlockOut.NumStates();
         step.TruncErr_Sys = BT_L.TruncErr; step.TruncErr_Env = BT_R.TruncErr;
         ierr = PetscTime(&trotb); CHKERRQ(ierr);
@@ -734,6 +775,7 @@ public:
                 case OpSm: m = blk.Sm(o.idx); break;
                 default: SETERRQ(mpi_comm, PETSC_ERR_ARG_WRONG, "Correlators take Sz, Sp and Sm operators.");
             }
+            if (!m) SETERRQ2(mpi_comm, PETSC_ERR_ARG_WRONGSTATE, "Correlator operator %s(%lld) is not resident in the block (pruned): register correlators before Warmup().", OpToCStr(o.OpType), LLD(o.idx));
             return 0;
         };
         auto dense = [&](const Op& o, Mat& d) -> PetscErrorCode {
@@ -1033,13 +1075,94 @@ public:
         return 0;
     }
 
+    /* ---- operator residency (engine extension) ----------------------------------------------------------------------
+       A site operator of a stored block can only be touched again by (a) an inter-block term of a later superblock --
+       as a LEFT block (sites i with a term (i, j), j >= nb, in the lattice's term list; also covers the enlargement by
+       site nb) or as a reflected RIGHT block (site s = nout-1-j of a term (i, j) cut between i and j in a superblock of
+       nout sites) -- or (b) a registered correlator, measured on the two half-lattice blocks at the centre.  Everything
+       else is neither rotated nor kept in HBM. */
+    PetscErrorCode BuildNeedTables()
+    {
+        if (need_built) return 0;
+        const PetscInt N = num_sites;
+        need_left.assign((size_t)N + 1, std::vector<char>()); need_right.assign((size_t)N + 1, std::vector<char>());
+        for (PetscInt nb = 1; nb <= N; ++nb) { need_left[(size_t)nb].assign((size_t)nb, 0); need_right[(size_t)nb].assign((size_t)nb, 0); }
+        for (const Hamiltonians::Term& t : Ham.H(N)) {
+            const PetscInt I = std::min(t.Isite, t.Jsite), J = std::max(t.Isite, t.Jsite);
+            for (PetscInt nb = I + 1; nb <= J && nb <= N; ++nb) need_left[(size_t)nb][(size_t)I] = 1;
+            /* right block of nb sites (+1 new site) in a superblock of nout = c + nb + 1 sites, cut c in (I, J): local site nb - (J - c) */
+            for (PetscInt nb = 1; nb < N; ++nb)
+                for (PetscInt c = I + 1; c < J; ++c) {
+                    const PetscInt s = nb - (J - c);
+                    if (s < 0 || s >= nb || c + nb + 1 > N) continue;
+                    need_right[(size_t)nb][(size_t)s] = 1;
+                }
+        }
+        corr_sites.assign((size_t)N, 0);
+        for (const Correlator& c : measurements) {
+            for (const Op& o : c.SysOps) if (o.idx >= 0 && o.idx < N) corr_sites[(size_t)o.idx] = 1;
+            for (const Op& o : c.EnvOps) if (o.idx >= 0 && o.idx < N) corr_sites[(size_t)o.idx] = 1;
+        }
+        need_built = true;
+        return 0;
+    }
+    /** sites of a block with nb sites whose operators must stay resident */
+    std::vector<char> NeedMask(PetscInt nb, bool with_corr, bool left_only)
+    {
+        BuildNeedTables();
+        std::vector<char> m((size_t)nb, 0);
+        if (nb < 1 || nb > num_sites) return std::vector<char>((size_t)std::max<PetscInt>(nb, 0), 1);
+        for (PetscInt i = 0; i < nb; ++i) {
+            m[(size_t)i] = need_left[(size_t)nb][(size_t)i] || (!left_only && need_right[(size_t)nb][(size_t)i]) || (with_corr && nb < num_sites / 2 && corr_sites[(size_t)i]);
+        }
+        /* never empty: an all-zero mask would read as "keep everything" */
+        if (std::find(m.begin(), m.end(), 1) == m.end()) m[(size_t)nb - 1] = 1;
+        return m;
+    }
+    /** an input block of a finished step is only read again through inter-block terms */
+    PetscErrorCode PruneConsumed(PetscInt idx)
+    {
+        if (idx < 0 || idx >= (PetscInt)sys_blocks.size() || !sys_blocks[(size_t)idx].Initialized()) return 0;
+        Block& b = sys_blocks[(size_t)idx];
+        if (b.NumSites() < Ham.NumEnvSites() * 2) return 0;         /* the exact initial blocks stay whole */
+        return b.PruneOperators(NeedMask(b.NumSites(), false, false));
+    }
+
+    /** One record per step in KronStats.json: the superblock as the plan sees it (SURVEY 8d quantities computed from the
+        actual sector tables), the kept-sector tables of both input blocks, and -- with -step_profile -- the HIP-event time of
+        the two GEMM stages summed over the step's MatMults. */
+    PetscErrorCode SaveKronStats(const dmrgx_kron_info& ki, const Block& Sys, const Block& Env, PetscInt nterms, PetscInt nmatvec, double eigs_seconds,
+                                 const double* ms4, int64_t napp)
+    {
+        if (mpi_rank || !fp_kron) return 0;
+        fprintf(fp_kron, "%s  {\"GlobIdx\": %lld, \"LoopType\": \"%s\", \"NSites_Sys\": %lld, \"NSites_Env\": %lld, \"n_states\": %lld, \"flops_alg\": %.17g, \"bytes_alg\": %.17g, "
+                         "\"flops_exec\": %.17g, \"bytes_workspace\": %.17g, \"n_groups\": %d, \"n_tiles_stage1\": %d, \"n_tiles_stage2\": %d, \"n_terms_all\": %lld, "
+                         "\"matmults\": %lld, \"eigs_seconds\": %.9g, \"timed_applies\": %lld, \"ms_stage1\": %.9g, \"ms_stage2\": %.9g,\n",
+                kron_rows ? ",\n" : "", LLD(GlobIdx), LoopType ? "Sweep" : "Warmup", LLD(Sys.NumSites()), LLD(Env.NumSites()), LLD(ki.n_states), ki.flops_alg, ki.bytes_alg, ki.flops_exec,
+                ki.bytes_workspace, ki.n_groups, ki.n_tiles_stage1, ki.n_tiles_stage2, LLD(nterms), LLD(nmatvec), eigs_seconds, LLD(napp), ms4[0] + ms4[1], ms4[2] + ms4[3]);
+        const Block* B[2] = {&Sys, &Env};
+        const char* tag[2] = {"sys", "env"};
+        for (int s = 0; s < 2; ++s) {
+            const std::vector<PetscReal> q = B[s]->Magnetization.List();
+            const std::vector<PetscInt> n = B[s]->Magnetization.Sizes();
+            fprintf(fp_kron, "   \"%s_qn\": [", tag[s]);
+            for (size_t i = 0; i < q.size(); ++i) fprintf(fp_kron, "%s%g", i ? ", " : "", q[i]);
+            fprintf(fp_kron, "], \"%s_sizes\": [", tag[s]);
+            for (size_t i = 0; i < n.size(); ++i) fprintf(fp_kron, "%s%lld", i ? ", " : "", LLD(n[i]));
+            fprintf(fp_kron, "]%s", s == 0 ? ",\n" : "}");
+        }
+        fflush(fp_kron);
+        ++kron_rows;
+        return 0;
+    }
+
 private:
     struct StepData {
         PetscInt NumSites_Sys = 0, NumSites_Env = 0, NumSites_SysEnl = 0, NumSites_EnvEnl = 0;
         PetscInt NumStates_Sys = 0, NumStates_Env = 0, NumStates_SysEnl = 0, NumStates_EnvEnl = 0, NumStates_SysRot = 0, NumStates_EnvRot = 0, NumStates_H = 0;
         PetscScalar GSEnergy = 0; PetscReal TruncErr_Sys = 0, TruncErr_Env = 0;
     };
-    struct TimingsData { PetscLogDouble tEnlr = 0, tKron = 0, tDiag = 0, tRdms = 0, tRotb = 0, Total = 0; PetscInt nMatMult = 0; };
+    struct TimingsData { PetscLogDouble tEnlr = 0, tKron = 0, tDiag = 0, tRdms = 0, tRotb = 0, Total = 0; PetscInt nMatMult = 0, nRotOps = 0; };
     typedef enum { WarmupStep = 0, SweepStep = 1, NullStep = -1 } Step_t;
     typedef enum { SWEEP_MODE_NULL, SWEEP_MODE_NSWEEPS, SWEEP_MODE_MSWEEPS, SWEEP_MODE_TOLERANCE_TEST } SweepMode_t;
 
@@ -1101,7 +1224,13 @@ private:
     PetscReal eps_tol = 1.0e-8;     /* SLEPc's default relative residual tolerance */
     PetscInt eps_ncv = 16, eps_max_it = 1000;
     std::string scratch_dir, data_dir;
-    FILE *fp_step = NULL, *fp_timings = NULL, *fp_entanglement = NULL, *fp_data = NULL, *fp_corr = NULL;
+    FILE *fp_step = NULL, *fp_timings = NULL, *fp_entanglement = NULL, *fp_data = NULL, *fp_corr = NULL, *fp_kron = NULL;
+    PetscInt kron_rows = 0;
+    PetscBool prune_ops = PETSC_TRUE;          /* -prune_ops 0: rotate and keep every site operator of every block, as the reference does */
+    PetscBool step_profile = PETSC_FALSE;      /* -step_profile 1: HIP-event timing of the GEMM stages of every MatMult (KronStats.json) */
+    bool need_built = false;
+    std::vector<std::vector<char>> need_left, need_right;
+    std::vector<char> corr_sites;
     PetscInt mwarmup = 0, nsweeps = 0, msweep_idx = 0;
     std::vector<PetscInt> msweeps, maxnsweeps, sweeps_mstates;
     SweepMode_t sweep_mode = SWEEP_MODE_NULL;

@@ -341,6 +341,7 @@ inline PetscErrorCode KronEye_Explicit(Block::SpinBase& LeftBlock, Block::SpinBa
         for (PetscInt isite = 0; isite < blk.NumSites(); ++isite)
             for (Op_t op : BasicOpTypes) {
                 const Mat src = (op == OpSz) ? blk.Sz(isite) : blk.Sp(isite);
+                if (!src) { BlockOut.SetOpsPruned(); continue; }      /* pruned site (Block::PruneOperators): stays absent in the enlarged block */
                 Mat out = std::make_shared<SectorMat>();
                 out->shift = op; out->sizes = out_sizes;
                 for (PetscInt k = 0; k < nb; ++k) {
@@ -422,6 +423,8 @@ inline PetscErrorCode KronEye_Explicit(Block::SpinBase& LeftBlock, Block::SpinBa
             if (!one_r || MR.Sizes(IR + sB) != 1) SETERRQ(mpi_comm, PETSC_ERR_SUP, "KronEye_Explicit: inter-block terms need one-state right sectors (added site).");
             /* right factor: the 1x1 block (IR -> IR+sB) of the site operator */
             const Mat B = (t.Jop == OpSz) ? RightBlock.Sz(t.Jsite) : RightBlock.Sp(t.Jsite);
+            const Mat A = (t.Iop == OpSz) ? LeftBlock.Sz(t.Isite) : LeftBlock.Sp(t.Isite);
+            if (!A || !B) SETERRQ2(mpi_comm, PETSC_ERR_ARG_CORRUPT, "KronEye_Explicit: the term between sites %lld and %lld needs an operator that is not resident (pruned).", LLD(t.Isite), LLD(t.Jsite));
             const bool trB = (t.Jop == OpSm);
             double b = 0.0;
             for (const MatCell& c : B->cells) {
@@ -430,7 +433,6 @@ inline PetscErrorCode KronEye_Explicit(Block::SpinBase& LeftBlock, Block::SpinBa
                 if (c.kind == DMRGX_CELL_DENSE) b += c.buf->host_ro()[c.off]; else b += c.scale;
             }
             if (b == 0.0) continue;
-            const Mat A = (t.Iop == OpSz) ? LeftBlock.Sz(t.Isite) : LeftBlock.Sp(t.Isite);
             const bool trA = (t.Iop == OpSm);
             for (const MatCell& c : A->cells) {
                 const int32_t rowsec = trA ? c.q + A->shift : c.q;
