@@ -5,7 +5,7 @@ ARCH       ?= gfx950
 PKG        := dmrg.x_amd
 CSRC       := $(PKG)/csrc
 HIPFLAGS   := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude -I$(CSRC) -Wall -Wno-unused-function
-HIP_SRCS   := $(CSRC)/lib.hip $(CSRC)/pool.hip $(CSRC)/ggemm.hip $(CSRC)/kron_plan.hip $(CSRC)/eigs.hip $(CSRC)/rdm.hip $(CSRC)/hqr.hip $(CSRC)/rotate.hip
+HIP_SRCS   := $(CSRC)/lib.hip $(CSRC)/pool.hip $(CSRC)/ggemm.hip $(CSRC)/kron_plan.hip $(CSRC)/eigs.hip $(CSRC)/rdm.hip $(CSRC)/hqr.hip $(CSRC)/rotate.hip $(CSRC)/comm.hip
 HIP_OBJS   := $(HIP_SRCS:.hip=.o)
 
 HOST       := $(PKG)/host
@@ -17,7 +17,7 @@ $(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/ggemm.h $(CSRC)/hqr.h includ
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(PKG)/libdmrgx_hip.so: $(HIP_OBJS)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(HIP_OBJS) -o $@
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC $(HIP_OBJS) -ldl -lpthread -lrt -o $@
 
 # host sweep engine (plain C++17 over the C ABI: no HIP headers needed)
 $(PKG)/dmrgx-square-lattice: $(HOST)/DMRG-SquareLattice.cpp $(HOST_HDRS) $(PKG)/libdmrgx_hip.so

@@ -64,6 +64,32 @@ def cpu_baseline(sb, budget_s=15.0):
                       f"({total_flops / 1e9:.0f} GF per MatMult)"}
 
 
+def cpu_baseline_factored(sb, reps=3):
+    """the same MatMult in factored, operator-merged form (oracle/kron_factored.py: per-sector numpy / OpenBLAS GEMMs,
+    exactly F_alg flops) on this host's cores, timed IN FULL (every row of the superblock; median of `reps` after one warm-up)."""
+    from oracle.kron_factored import FactoredApplyCPU
+    nthreads = int(os.environ.get("DMRGX_CPU_THREADS", min(len(os.sched_getaffinity(0)), 16)))
+    try:
+        from threadpoolctl import threadpool_limits
+        limit = threadpool_limits(limits=nthreads)
+    except Exception:
+        limit = None
+    f = FactoredApplyCPU(sb)
+    x = np.random.default_rng(0).standard_normal(sb.n_states)
+    f.apply(x)
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        f.apply(x)
+        ts.append(time.perf_counter() - t0)
+    if limit is not None:
+        limit.restore_original_limits()
+    t = sorted(ts)[len(ts) // 2]
+    return {"value": 1.0 / t, "unit": "MatMults/s", "cores": nthreads, "kind": "port-factored",
+            "sample": f"all {sb.n_states} rows, {reps} full applies after one warm-up (median {t:.3f} s, {f.flops / t / 1e9:.0f} GF/s on the "
+                      f"{f.flops / 1e9:.1f} GF of SURVEY 8d's F_alg: terms merged per right operator, structural zeros of O(x)1 skipped)"}
+
+
 def engine_run(opts, timeout=300):
     """Run the drop-in sweep engine (dmrg.x_amd/dmrgx-square-lattice, the host C++ driver over the same C ABI) in a child
     process and return its DMRGRun.json.  Child process: it owns its own HIP context, nothing is exec'd from this one."""
@@ -85,6 +111,19 @@ def engine_run(opts, timeout=300):
             e = per.setdefault(int(st[2]), {"steps": 0, "seconds": 0.0, "matmults": 0})
             e["steps"] += 1; e["seconds"] += float(tm[1]); e["matmults"] += int(tm[7])
         run["PerSweep"] = [per[k] for k in sorted(per)]
+        # -step_profile: algorithmic flops and HIP-event GEMM time of every MatMult of every sweep step (KronStats.json)
+        ks = [k for k in json.load(open(os.path.join(d, "KronStats.json"))) if k["LoopType"] == "Sweep" and k["timed_applies"] > 0]
+        if ks:
+            fl = sum(k["flops_alg"] * k["timed_applies"] for k in ks)
+            tg = sum(k["ms_stage1"] + k["ms_stage2"] for k in ks) * 1e-3
+            run["InSweep"] = {"gemm_tflops": fl / tg / 1e12, "roofline_frac": fl / tg / 1e12 / F64_PEAK_TFLOPS,
+                              "mean_flops_alg_per_matmult": fl / sum(k["timed_applies"] for k in ks),
+                              "mean_n_states": sum(k["n_states"] for k in ks) / len(ks), "gemm_seconds": tg}
+        run["SweepEnergies"] = {}
+        for st in steps:
+            if st[1] == "Sweep":
+                run["SweepEnergies"][int(st[2])] = float(st[-1])          # energy of the last step of every sweep
+        run["MaxTruncErr"] = max(float(st[-3]) for st in steps)
         return run
 
 
@@ -94,11 +133,24 @@ def sweep_legs():
     fits one MI355X, about a minute) -- and on configs[1] (J1-J2 8x4, m = 512), and the E0 relative error on configs[0]
     (Heisenberg 16x1 chain, m = 64, 2 sweeps) against exact diagonalisation."""
     def leg(run, config):
-        return {"sites_per_s": run["LastSweepSteps"] / run["LastSweepSeconds"], "config": config, "sweep_steps": run["LastSweepSteps"],
-                "sweep_seconds": run["LastSweepSeconds"], "sweep_matmults": run["LastSweepMatMults"],
-                "matmults_per_s_in_sweep": run["LastSweepMatMults"] / run["LastSweepSeconds"], "gs_energy": run["GSEnergy"]}
+        out = {"sites_per_s": run["LastSweepSteps"] / run["LastSweepSeconds"], "config": config, "sweep_steps": run["LastSweepSteps"],
+               "sweep_seconds": run["LastSweepSeconds"], "sweep_matmults": run["LastSweepMatMults"],
+               "matmults_per_s_in_sweep": run["LastSweepMatMults"] / run["LastSweepSeconds"], "gs_energy": run["GSEnergy"],
+               "max_trunc_err": run["MaxTruncErr"]}
+        if "InSweep" in run:       # the roofline of the dominant kernel on the REAL superblocks of the sweep
+            out["roofline_frac"] = run["InSweep"]["roofline_frac"]
+            out["in_sweep"] = run["InSweep"]
+        # self-consistency of the printed energies (the parity tier compares them with the oracle, tests/test_gpu_engine.py):
+        # DMRG is variational, so the energy at the end of a sweep may not rise above the previous sweep's by more than the
+        # truncation error allows
+        e = [run["SweepEnergies"][k] for k in sorted(run["SweepEnergies"])]
+        tol = 10.0 * max(run["MaxTruncErr"], 1e-12) * abs(e[-1])
+        assert all(b <= a + tol for a, b in zip(e, e[1:])), ("sweep energies rise", e)
+        assert abs(run["GSEnergy"] - e[-1]) <= 1e-12 * abs(e[-1])
+        out["sweep_energies"] = e
+        return out
     j1j2 = ["-J1", 1, "-Jz1", 1, "-J2", 0.5, "-Jz2", 0.5]
-    run3 = engine_run(["-Lx", 20, "-Ly", 8, "-mwarmup", 2048, *j1j2, "-nsweeps", 2], timeout=1200)
+    run3 = engine_run(["-Lx", 20, "-Ly", 8, "-mwarmup", 2048, *j1j2, "-nsweeps", 2, "-step_profile", 1], timeout=1200)
     out = leg(run3, "configs[3] on one GPU: J1-J2 20x8 cylinder (160 sites), J2=0.5, m=2048, warm-up + two finite-system sweeps (real engine "
                     "run); sites_per_s is the second sweep, the first one (environment blocks still from the warm-up) is listed beside it")
     out["per_sweep"] = [{"sites_per_s": p["steps"] / p["seconds"], "matmults_per_s": p["matmults"] / p["seconds"], **p} for p in run3["PerSweep"]]
@@ -107,6 +159,9 @@ def sweep_legs():
     e_ed = -6.9117371455751
     run1 = engine_run(["-Lx", 16, "-Ly", 1, "-heisenberg", 1, "-mwarmup", 64, "-nsweeps", 2, "-H_eps_tol", 1e-12])
     out["e0_rel_err"] = abs(run1["GSEnergy"] - e_ed) / abs(e_ed)
+    assert out["e0_rel_err"] <= 1e-10, out["e0_rel_err"]                     # north-star tolerance
+    # configs[1]: the energy the parity tier ties to the oracle (tests/test_gpu_engine.py::test_baseline_config1_energy_...)
+    assert abs(out["configs_1"]["gs_energy"] - (-27.927342512)) <= 1e-6, out["configs_1"]["gs_energy"]
     out["e0_config"] = "configs[0]: Heisenberg 16x1 chain, m=64, 2 sweeps; exact-diagonalisation E0 = -6.9117371455751"
     return out
 
@@ -116,7 +171,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=16)
-    ap.add_argument("--workload", default="cfg4", help="BASELINE.json config: cfg1..cfg5 (default cfg4 = J1-J2 20x8, m=2048)")
+    ap.add_argument("--workload", default="cfg4real", help="cfg4real (default: BASELINE configs[3], J1-J2 20x8, m=2048, on the sector tables of a real "
+                    "mid-sweep step of the engine) | cfg1..cfg5 (SURVEY 8d's synthetic sigma=1.8 sector profile)")
     ap.add_argument("--ncv", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true", help="skip the engine legs (sites/sec per sweep, E0 rel-err)")
@@ -137,21 +193,28 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        if rehearsal:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("gloo")          # control plane only (id exchange, barrier, max of the wall times): every
+                                                 # data-path collective is RCCL, issued by libdmrgx_hip.so itself
 
     from __graft_entry__ import load_package
     load_package()
-    from dmrgx_amd.superblock import KronPlan
+    from dmrgx_amd.superblock import KronPlan, Communicator
     from dmrgx_amd.workloads import synthetic_superblock, CONFIGS
-    from dmrgx_amd import collectives
 
     sb = synthetic_superblock(args.workload)
     plan = KronPlan(sb, device=f"cuda:{local_rank}", world_size=world, rank=rank)
     info = plan.info
-    hooks = (collectives.host_staged_hooks(dist, rank, world) if rehearsal else collectives.torch_hooks(dist, rank, world)) if world > 1 else {}
+    comm = None
+    if world > 1:
+        # native communicator (csrc/comm.hip): RCCL all-gather / all-reduce enqueued by the eigensolver itself -- no Python in
+        # the step loop.  Rank 0's 128-byte RCCL id reaches the other ranks through the launcher's store.
+        if rehearsal:
+            comm = Communicator(rank, world, host_staged_name="dmrgx_bench_%s" % os.environ.get("MASTER_PORT", "0"))
+        else:
+            ids = [Communicator.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            comm = Communicator(rank, world, unique_id=ids[0])
+    hooks = {"comm": comm} if comm is not None else {}
 
     def barrier():
         torch.cuda.synchronize()
@@ -169,7 +232,7 @@ def main():
     plan.timing(False)
     assert stats.n_matvec == args.steps, (stats.n_matvec, args.steps)
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms4, napp = plan.timing_read()
@@ -202,7 +265,7 @@ def main():
         "value": args.steps / elapsed, "unit": "MatMults/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"{args.workload}: {CONFIGS[args.workload]['desc']}; mid-sweep column cut, sector profile sigma=1.8 (SURVEY 8d)",
+        "config": {"workload": f"{args.workload}: {CONFIGS[args.workload]['desc']}" + ("" if args.workload == "cfg4real" else "; mid-sweep column cut, sector profile sigma=1.8 (SURVEY 8d)"),
                    "m": CONFIGS[args.workload]["m"], "n_states": int(info.n_states), "n_terms": len(sb.terms) + 2,
                    "ncv": args.ncv, "parallelism": f"right-index stripes over {world} GPU(s)"},
         "matmult_isolated_per_s": iso,
@@ -226,7 +289,11 @@ def main():
             out["roofline"]["traffic"] = t["bytes_per_launch"]
             out["roofline"]["traffic_source"] = t["source"]
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(sb)
+        # two CPU statements of the same MatMult on this host: the factored, operator-merged form -- the same
+        # algorithm as the HIP plan, so value / cpu_baseline.value is hardware against hardware -- and beside it the literal
+        # unfactored row loop the reference executes (sampled rows, extrapolated by its exact flop count)
+        out["cpu_baseline"] = cpu_baseline_factored(sb)
+        out["cpu_baseline"]["reference_row_loop"] = cpu_baseline(sb)
     elif rank == 0:
         out["cpu_baseline"] = None
     plan.destroy()
@@ -237,6 +304,8 @@ def main():
         print(json.dumps(out))
     if plan is not None:
         plan.destroy()
+    if comm is not None:
+        comm.destroy()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -81,7 +81,8 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_voi
 
 class EigsOpts(C.Structure):
     _fields_ = [("ncv", C.c_int32), ("max_it", C.c_int32), ("tol", C.c_double), ("seed", C.c_uint64),
-                ("use_initial", C.c_int32), ("max_matvec", C.c_int32), ("allgather", ALLGATHER_FN), ("allreduce_sum", ALLREDUCE_FN), ("user", C.c_void_p)]
+                ("use_initial", C.c_int32), ("max_matvec", C.c_int32), ("allgather", ALLGATHER_FN), ("allreduce_sum", ALLREDUCE_FN), ("user", C.c_void_p),
+                ("comm", C.c_void_p)]
 
 
 class EigsStats(C.Structure):
@@ -128,6 +129,19 @@ SIGNATURES = {
     "dmrgx_dot2d_batch": (C.c_int32, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dmrgx_eigs_lowest": (C.c_int32, [C.c_void_p, C.POINTER(EigsOpts), C.POINTER(C.c_double), C.c_void_p,
                                       C.POINTER(EigsStats), C.c_void_p]),
+    "dmrgx_rdm_create_subset": (C.c_int32, [C.POINTER(Sectors), C.POINTER(Sectors), C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "dmrgx_set_device": (C.c_int32, [C.c_int32]),
+    "dmrgx_comm_unique_id": (C.c_int32, [C.c_void_p]),
+    "dmrgx_comm_init": (C.c_int32, [C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "dmrgx_comm_init_host_staged": (C.c_int32, [C.c_int32, C.c_int32, C.c_char_p, C.POINTER(C.c_void_p)]),
+    "dmrgx_comm_info": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "dmrgx_comm_allgather": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "dmrgx_comm_allreduce_sum": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "dmrgx_comm_bcast": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p]),
+    "dmrgx_comm_allgather_host": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "dmrgx_comm_barrier": (C.c_int32, [C.c_void_p, C.c_void_p]),
+    "dmrgx_comm_destroy": (C.c_int32, [C.c_void_p]),
 }
 
 _lib = None
@@ -147,7 +161,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError if the ABI symbol is missing
             fn.restype, fn.argtypes = res, args
-        if L.dmrgx_abi_version() != 1:
+        if L.dmrgx_abi_version() != 2:
             raise ImportError("dmrgx ABI version mismatch")
         _lib = L
     return _lib

@@ -301,7 +301,11 @@ extern "C" dmrgx_status dmrgx_eigs_lowest(dmrgx_kron_plan* plan, const dmrgx_eig
     dmrgx_kron_info I;
     DMRGX_CHK(dmrgx_kron_plan_info(plan, &I));
     const bool dist = I.vec_len != I.n_states;
-    if (dist && (!opts->allgather || !opts->allreduce_sum)) DMRGX_FAIL(DMRGX_ERR_ARG, "eigs_lowest: striped plan needs allgather/allreduce hooks");
+    const bool hooks = opts->allgather && opts->allreduce_sum;
+    if (dist && !hooks && !opts->comm) DMRGX_FAIL(DMRGX_ERR_ARG, "eigs_lowest: a striped plan needs a communicator (opts->comm) or the allgather/allreduce hooks");
+    auto gather_full = [&](double* full) -> dmrgx_status {      // in-place all-gather of the rank segments of a full vector
+        return hooks ? opts->allgather(opts->user, full, I.seg_stride, st) : dmrgx_comm_allgather(opts->comm, full, I.seg_stride, st);
+    };
     const int64_t n = I.local_len, N = I.n_states;
     int m = opts->ncv > 0 ? opts->ncv : 16;
     m = (int)std::min<int64_t>(std::min(m, MAX_NCV), N);
@@ -335,7 +339,7 @@ extern "C" dmrgx_status dmrgx_eigs_lowest(dmrgx_kron_plan* plan, const dmrgx_eig
     const int nblk = DOT_BLOCKS;      // (scaling the grid down with n was measured slower even at n = 1.6e5: these passes are latency-bound)
     auto allreduce = [&](double* buf, int64_t count) -> dmrgx_status {
         if (!dist) return DMRGX_OK;
-        return opts->allreduce_sum(opts->user, buf, count, st);
+        return hooks ? opts->allreduce_sum(opts->user, buf, count, st) : dmrgx_comm_allreduce_sum(opts->comm, buf, count, st);
     };
     // dots of w against V[0..nv) plus w.w  -> c1[0..nv]
     auto multi_dot = [&](int nv) -> dmrgx_status {
@@ -362,7 +366,7 @@ extern "C" dmrgx_status dmrgx_eigs_lowest(dmrgx_kron_plan* plan, const dmrgx_eig
     auto matvec = [&](const double* v_local, double* y_local) -> dmrgx_status {
         if (!dist) return dmrgx_kron_apply(plan, v_local, y_local, st);
         DMRGX_HIP(hipMemcpyAsync(dX.as<double>() + I.local_offset, v_local, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
-        DMRGX_CHK(opts->allgather(opts->user, dX.as<double>(), I.seg_stride, st));
+        DMRGX_CHK(gather_full(dX.as<double>()));
         return dmrgx_kron_apply(plan, dX.as<double>(), y_local, st);
     };
 
@@ -489,7 +493,7 @@ extern "C" dmrgx_status dmrgx_eigs_lowest(dmrgx_kron_plan* plan, const dmrgx_eig
     if (!dist) DMRGX_CHK(normalise_into(psi_full));
     else {
         DMRGX_CHK(normalise_into(psi_full + I.local_offset));
-        DMRGX_CHK(opts->allgather(opts->user, psi_full, I.seg_stride, st));
+        DMRGX_CHK(gather_full(psi_full));
     }
     DMRGX_HIP(hipStreamSynchronize(st));
     *e0 = lambda;

@@ -21,6 +21,8 @@ struct Pool {
     std::mutex mu;
     std::map<size_t, std::vector<void*>> free_by_size;
     std::unordered_map<void*, size_t> size_of;       // every block handed out or cached
+    std::unordered_map<void*, uint64_t> freed_at;    // cached blocks: value of `clock` when they came back (LRU order of the trim)
+    uint64_t clock = 0;
     size_t cached = 0;
     const bool enabled = !(getenv("DMRGX_POOL") && atoi(getenv("DMRGX_POOL")) == 0);
     const size_t cache_limit = (size_t)(getenv("DMRGX_POOL_LIMIT_GB") ? atof(getenv("DMRGX_POOL_LIMIT_GB")) : 64.0) << 30;
@@ -35,11 +37,25 @@ struct Pool {
         const size_t step = oct / 8;
         return oct + (n - oct + step - 1) / step * step;
     }
-    void trim_locked() {                              // give everything cached back to the driver
-        (void)hipDeviceSynchronize();
-        for (auto& kv : free_by_size) for (void* p : kv.second) { size_of.erase(p); (void)hipFree(p); }
-        free_by_size.clear();
-        cached = 0;
+    // Give cached blocks back to the driver, least recently freed first, until at most `target` bytes stay cached (0 =
+    // everything: the out-of-memory path).  Incremental on purpose: the blocks a sweep step recycles every few milliseconds
+    // are the most recently freed ones and stay; what goes are the sizes the run has moved away from.  hipFree waits for
+    // the device by itself, so there is no explicit device-wide synchronisation here.
+    void trim_locked(size_t target) {
+        std::vector<std::pair<uint64_t, void*>> order;
+        for (auto& kv : free_by_size) for (void* p : kv.second) order.push_back({freed_at[p], p});
+        std::sort(order.begin(), order.end());
+        for (auto& o : order) {
+            if (cached <= target) break;
+            void* p = o.second;
+            const size_t sz = size_of[p];
+            auto& v = free_by_size[sz];
+            v.erase(std::find(v.begin(), v.end(), p));
+            if (v.empty()) free_by_size.erase(sz);
+            size_of.erase(p); freed_at.erase(p);
+            cached -= sz;
+            (void)hipFree(p);
+        }
     }
 };
 Pool& pool() { static Pool* p = new Pool(); return *p; }    // leaked on purpose: no teardown order issues with the HIP runtime
@@ -67,6 +83,7 @@ hipError_t pool_malloc(void** out, size_t bytes)
         *out = it->second.back();
         it->second.pop_back();
         P.cached -= it->first;
+        P.freed_at.erase(*out);
         return hipSuccess;
     }
     static const bool trace = getenv("DMRGX_POOL_TRACE") != nullptr;     // developer aid: driver allocations that miss the cache
@@ -76,7 +93,7 @@ hipError_t pool_malloc(void** out, size_t bytes)
                                                  std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), P.cached / 1073741824.0);
     if (e != hipSuccess) {                            // out of memory with blocks cached: release them and try once more
         (void)hipGetLastError();
-        P.trim_locked();
+        P.trim_locked(0);
         e = hipMalloc(out, c);
     }
     if (e == hipSuccess) P.size_of[*out] = c;
@@ -93,17 +110,25 @@ hipError_t pool_free(void* p)
     auto it = P.size_of.find(p);
     if (it == P.size_of.end()) return hipFree(p);     // not ours
     P.free_by_size[it->second].push_back(p);
+    P.freed_at[p] = ++P.clock;
     P.cached += it->second;
-    if (P.cached > P.cache_limit) P.trim_locked();
+    if (P.cached > P.cache_limit) P.trim_locked(P.cache_limit / 4 * 3);
     return hipSuccess;
 }
 
 // Host -> device copies of task tables and small operands: staged through a pinned ring so that the copy is a true
-// asynchronous DMA (a hipMemcpyAsync from pageable memory blocks the host for ~20 us per call).  The ring is reused after a
-// device-wide synchronisation at wrap-around, i.e. once every H2D_RING_BYTES of uploads.
+// asynchronous DMA (a hipMemcpyAsync from pageable memory blocks the host for ~20 us per call).  The ring is cut into
+// H2D_SLOTS slots; every copy leaves an event on its stream in the slot it was staged in, and a slot is written again only
+// after its events have completed (half a ring of uploads later they long have) -- no device-wide synchronisation.
 namespace {
-constexpr size_t H2D_RING_BYTES = (size_t)64 << 20, H2D_MAX_STAGED = (size_t)4 << 20;
-struct Ring { std::mutex mu; char* base = nullptr; size_t head = 0; bool failed = false; };
+constexpr size_t H2D_RING_BYTES = (size_t)64 << 20, H2D_MAX_STAGED = (size_t)4 << 20, H2D_SLOTS = 16, H2D_SLOT_BYTES = H2D_RING_BYTES / H2D_SLOTS;
+static_assert(H2D_MAX_STAGED <= H2D_SLOT_BYTES, "a staged copy fits one slot");
+struct Ring {
+    std::mutex mu; char* base = nullptr; size_t slot = 0, head = 0; bool failed = false;
+    struct Pending { hipStream_t st; hipEvent_t ev; };
+    std::vector<Pending> pending[H2D_SLOTS];          // one event per stream that copied out of the slot since it was opened
+    std::vector<hipEvent_t> spare;
+};
 Ring& ring() { static Ring* r = new Ring(); return *r; }
 }  // namespace
 
@@ -116,11 +141,26 @@ hipError_t h2d_async(void* dst, const void* src, size_t bytes, hipStream_t st)
         if (!R.base) { if (hipHostMalloc((void**)&R.base, H2D_RING_BYTES, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); R.base = nullptr; R.failed = true; } }
         if (R.base) {
             const size_t need = (bytes + 255) & ~(size_t)255;
-            if (R.head + need > H2D_RING_BYTES) { hipError_t e = hipDeviceSynchronize(); if (e != hipSuccess) return e; R.head = 0; }
-            char* slot = R.base + R.head;
+            if (R.head + need > H2D_SLOT_BYTES) {         // open the next slot: wait for the copies staged in it one lap ago
+                R.slot = (R.slot + 1) % H2D_SLOTS; R.head = 0;
+                for (Ring::Pending& p : R.pending[R.slot]) { hipError_t e = hipEventSynchronize(p.ev); if (e != hipSuccess) return e; R.spare.push_back(p.ev); }
+                R.pending[R.slot].clear();
+            }
+            char* at = R.base + R.slot * H2D_SLOT_BYTES + R.head;
             R.head += need;
-            memcpy(slot, src, bytes);
-            return hipMemcpyAsync(dst, slot, bytes, hipMemcpyHostToDevice, st);
+            memcpy(at, src, bytes);
+            hipError_t e = hipMemcpyAsync(dst, at, bytes, hipMemcpyHostToDevice, st);
+            if (e != hipSuccess) return e;
+            Ring::Pending* mine = nullptr;
+            for (Ring::Pending& p : R.pending[R.slot]) if (p.st == st) mine = &p;
+            if (!mine) {
+                hipEvent_t ev;
+                if (!R.spare.empty()) { ev = R.spare.back(); R.spare.pop_back(); }
+                else { e = hipEventCreateWithFlags(&ev, hipEventDisableTiming); if (e != hipSuccess) return e; }
+                R.pending[R.slot].push_back(Ring::Pending{st, ev});
+                mine = &R.pending[R.slot].back();
+            }
+            return hipEventRecord(mine->ev, st);          // re-recorded after every copy: covers the slot's last copy on this stream
         }
     }
     // large or unstaged: the source must outlive the copy and the callers drop it on return

@@ -384,8 +384,13 @@ struct dmrgx_rdm {
     std::vector<std::vector<double>> eig;      // per matrix: eigenvalues, descending
     std::vector<std::vector<int32_t>> perm;    // per matrix: column of V for the r-th largest eigenvalue
     std::vector<int64_t> perm_off;
+    std::vector<uint8_t> selected;             // per matrix: built and diagonalised by this rank (dmrgx_rdm_create_subset)
     int32_t sweeps = 0;
 };
+
+static dmrgx_status rdm_create_impl(const dmrgx_sectors* left, const dmrgx_sectors* right, int32_t nblocks,
+                                    const int32_t* block_il, const int32_t* block_ir, const double* psi_dev,
+                                    const double* const* v0_rows, const uint8_t* side_mask, void* stream, dmrgx_rdm** out);
 
 extern "C" dmrgx_status dmrgx_rdm_create(const dmrgx_sectors* left, const dmrgx_sectors* right, int32_t nblocks,
                                          const int32_t* block_il, const int32_t* block_ir, const double* psi_dev,
@@ -397,6 +402,21 @@ extern "C" dmrgx_status dmrgx_rdm_create(const dmrgx_sectors* left, const dmrgx_
 extern "C" dmrgx_status dmrgx_rdm_create_warm(const dmrgx_sectors* left, const dmrgx_sectors* right, int32_t nblocks,
                                               const int32_t* block_il, const int32_t* block_ir, const double* psi_dev,
                                               const double* const* v0_rows, void* stream, dmrgx_rdm** out)
+{
+    return rdm_create_impl(left, right, nblocks, block_il, block_ir, psi_dev, v0_rows, nullptr, stream, out);
+}
+
+extern "C" dmrgx_status dmrgx_rdm_create_subset(const dmrgx_sectors* left, const dmrgx_sectors* right, int32_t nblocks,
+                                                const int32_t* block_il, const int32_t* block_ir, const double* psi_dev,
+                                                const uint8_t* side_mask, void* stream, dmrgx_rdm** out)
+{
+    if (!side_mask) DMRGX_FAIL(DMRGX_ERR_ARG, "rdm_create_subset: null side_mask");
+    return rdm_create_impl(left, right, nblocks, block_il, block_ir, psi_dev, nullptr, side_mask, stream, out);
+}
+
+static dmrgx_status rdm_create_impl(const dmrgx_sectors* left, const dmrgx_sectors* right, int32_t nblocks,
+                                    const int32_t* block_il, const int32_t* block_ir, const double* psi_dev,
+                                    const double* const* v0_rows, const uint8_t* side_mask, void* stream, dmrgx_rdm** out)
 {
     hipStream_t st = (hipStream_t)stream;
     if (!left || !right || !block_il || !block_ir || !psi_dev || !out || nblocks <= 0) DMRGX_FAIL(DMRGX_ERR_ARG, "rdm_create: bad argument");
@@ -423,7 +443,9 @@ extern "C" dmrgx_status dmrgx_rdm_create_warm(const dmrgx_sectors* left, const d
         off[k + 1] = off[k] + (int64_t)nl * nr;
         for (int side = 0; side < 2; ++side) {
             MatDesc m;
-            m.n = side == 0 ? nl : nr;
+            const bool sel = !side_mask || ((side_mask[k] >> side) & 1);
+            P->selected.push_back(sel ? 1 : 0);
+            m.n = !sel ? 0 : side == 0 ? nl : nr;             // a matrix left to another rank is an empty matrix here
             m.npad = ((m.n + JS - 1) / JS) * JS;
             m.nb = m.npad / JB;
             m.a_off = total; total += (int64_t)m.npad * m.npad;
@@ -499,13 +521,14 @@ extern "C" dmrgx_status dmrgx_rdm_create_warm(const dmrgx_sectors* left, const d
         std::vector<TrTile> tt;
         for (int32_t k = 0; k < nblocks; ++k) {
             const int32_t nl = left->size[block_il[k]], nr = right->size[block_ir[k]];
+            if (!P->selected[2 * k] && !P->selected[2 * k + 1]) continue;
             for (int ti = 0; ti < (nl + 31) / 32; ++ti) for (int tj = 0; tj < (nr + 31) / 32; ++tj)
                 tt.push_back(TrTile{off[k], psiT_off + off[k], nl, nr, ti, tj});
         }
         DevBuf d_tt;
         DMRGX_CHK(upload(d_tt, tt, st));
         // transpose reads psi (caller memory) and writes the arena: pass distinct base pointers
-        hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)tt.size()), dim3(256), 0, st, d_tt.as<TrTile>(), psi_dev, buf);
+        if (!tt.empty()) hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)tt.size()), dim3(256), 0, st, d_tt.as<TrTile>(), psi_dev, buf);
         DMRGX_HIP(hipGetLastError());
         std::vector<GProd> prods;
         std::vector<GGroup> groups;
@@ -516,13 +539,19 @@ extern "C" dmrgx_status dmrgx_rdm_create_warm(const dmrgx_sectors* left, const d
             const double* PsiT = buf + psiT_off + off[k];
             const MatDesc& mL = P->mats[2 * k];
             const MatDesc& mR = P->mats[2 * k + 1];
-            prods.push_back(GProd{Psi, PsiT, nr, nl, nr, GPROD_GEMM, 1.0});       // rho_L = Psi Psi^T  (:1733)
-            groups.push_back(GGroup{buf + mL.a_off, mL.npad, nl, nl, (int32_t)prods.size() - 1, (int32_t)prods.size(), 0, 0});
-            ggemm_append_tiles_mixed(gb, gt, (int32_t)groups.size() - 1, nl, nl, (nr + GG_BK - 1) / GG_BK);
-            prods.push_back(GProd{PsiT, Psi, nl, nr, nl, GPROD_GEMM, 1.0});       // rho_R = Psi^T Psi  (:1734)
-            groups.push_back(GGroup{buf + mR.a_off, mR.npad, nr, nr, (int32_t)prods.size() - 1, (int32_t)prods.size(), 0, 0});
-            ggemm_append_tiles_mixed(gb, gt, (int32_t)groups.size() - 1, nr, nr, (nl + GG_BK - 1) / GG_BK);
+            if (P->selected[2 * k]) {
+                prods.push_back(GProd{Psi, PsiT, nr, nl, nr, GPROD_GEMM, 1.0});       // rho_L = Psi Psi^T  (:1733)
+                groups.push_back(GGroup{buf + mL.a_off, mL.npad, nl, nl, (int32_t)prods.size() - 1, (int32_t)prods.size(), 0, 0});
+                ggemm_append_tiles_mixed(gb, gt, (int32_t)groups.size() - 1, nl, nl, (nr + GG_BK - 1) / GG_BK);
+            }
+            if (P->selected[2 * k + 1]) {
+                prods.push_back(GProd{PsiT, Psi, nl, nr, nl, GPROD_GEMM, 1.0});       // rho_R = Psi^T Psi  (:1734)
+                groups.push_back(GGroup{buf + mR.a_off, mR.npad, nr, nr, (int32_t)prods.size() - 1, (int32_t)prods.size(), 0, 0});
+                ggemm_append_tiles_mixed(gb, gt, (int32_t)groups.size() - 1, nr, nr, (nl + GG_BK - 1) / GG_BK);
+            }
         }
+        if (prods.empty()) prods.push_back(GProd{nullptr, nullptr, 0, 0, 0, GPROD_GEMM, 0.0});
+        if (groups.empty()) groups.push_back(GGroup{nullptr, 0, 0, 0, 0, 0, 0, 0});
         ggemm_schedule(gt); ggemm_schedule(gb, 2);
         DevBuf dp, dg, dt, db;
         DMRGX_CHK(upload(dp, prods, st)); DMRGX_CHK(upload(dg, groups, st)); DMRGX_CHK(upload(dt, gt, st)); DMRGX_CHK(upload(db, gb, st));
@@ -698,15 +727,21 @@ extern "C" dmrgx_status dmrgx_rdm_create_warm(const dmrgx_sectors* left, const d
             const MatDesc& mR = P->mats[2 * k + 1];
             double* WL = buf + w_base + 2 * off[k];                     // n_R x n_L
             double* WR = WL + (int64_t)nl * nr;                          // n_L x n_R
-            prods.push_back(GProd{PsiT, buf + mL.v_off, nl, mL.npad, nl, GPROD_GEMM, 1.0});
-            groups.push_back(GGroup{WL, nl, nr, nl, (int32_t)prods.size() - 1, (int32_t)prods.size(), 0, 0});
-            ggemm_append_tiles_mixed(gb, gt, (int32_t)groups.size() - 1, nr, nl, (nl + GG_BK - 1) / GG_BK);
-            cn.push_back(ColNormTask{w_base + 2 * off[k], rq_base + (diag_off[2 * k] - diag_base), nr, nl, nl, 0});
-            prods.push_back(GProd{Psi, buf + mR.v_off, nr, mR.npad, nr, GPROD_GEMM, 1.0});
-            groups.push_back(GGroup{WR, nr, nl, nr, (int32_t)prods.size() - 1, (int32_t)prods.size(), 0, 0});
-            ggemm_append_tiles_mixed(gb, gt, (int32_t)groups.size() - 1, nl, nr, (nr + GG_BK - 1) / GG_BK);
-            cn.push_back(ColNormTask{w_base + 2 * off[k] + (int64_t)nl * nr, rq_base + (diag_off[2 * k + 1] - diag_base), nl, nr, nr, 0});
+            if (P->selected[2 * k]) {
+                prods.push_back(GProd{PsiT, buf + mL.v_off, nl, mL.npad, nl, GPROD_GEMM, 1.0});
+                groups.push_back(GGroup{WL, nl, nr, nl, (int32_t)prods.size() - 1, (int32_t)prods.size(), 0, 0});
+                ggemm_append_tiles_mixed(gb, gt, (int32_t)groups.size() - 1, nr, nl, (nl + GG_BK - 1) / GG_BK);
+                cn.push_back(ColNormTask{w_base + 2 * off[k], rq_base + (diag_off[2 * k] - diag_base), nr, nl, nl, 0});
+            }
+            if (P->selected[2 * k + 1]) {
+                prods.push_back(GProd{Psi, buf + mR.v_off, nr, mR.npad, nr, GPROD_GEMM, 1.0});
+                groups.push_back(GGroup{WR, nr, nl, nr, (int32_t)prods.size() - 1, (int32_t)prods.size(), 0, 0});
+                ggemm_append_tiles_mixed(gb, gt, (int32_t)groups.size() - 1, nl, nr, (nr + GG_BK - 1) / GG_BK);
+                cn.push_back(ColNormTask{w_base + 2 * off[k] + (int64_t)nl * nr, rq_base + (diag_off[2 * k + 1] - diag_base), nl, nr, nr, 0});
+            }
         }
+        if (prods.empty()) prods.push_back(GProd{nullptr, nullptr, 0, 0, 0, GPROD_GEMM, 0.0});
+        if (groups.empty()) groups.push_back(GGroup{nullptr, 0, 0, 0, 0, 0, 0, 0});
         ggemm_schedule(gt); ggemm_schedule(gb, 2);
         DevBuf dp, dg, dt, db, dc;
         DMRGX_CHK(upload(dp, prods, st)); DMRGX_CHK(upload(dg, groups, st)); DMRGX_CHK(upload(dt, gt, st)); DMRGX_CHK(upload(db, gb, st));
@@ -716,9 +751,9 @@ extern "C" dmrgx_status dmrgx_rdm_create_warm(const dmrgx_sectors* left, const d
         DMRGX_CHK(ggemm_launch(dt.as<GTile>(), dg.as<GGroup>(), dp.as<GProd>(), (int32_t)gt.size(), st, 0));
         int maxc = 1;
         for (auto& c : cn) maxc = std::max(maxc, c.ncols);
-        hipLaunchKernelGGL(colnorm_kernel, dim3((maxc + 63) / 64, (unsigned)cn.size()), dim3(256), 0, st, dc.as<ColNormTask>(), buf, buf);
+        if (!cn.empty()) hipLaunchKernelGGL(colnorm_kernel, dim3((maxc + 63) / 64, (unsigned)cn.size()), dim3(256), 0, st, dc.as<ColNormTask>(), buf, buf);
         DMRGX_HIP(hipGetLastError());
-        DMRGX_HIP(hipMemcpyAsync(rq.data(), buf + rq_base, rq.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+        if (!rq.empty()) DMRGX_HIP(hipMemcpyAsync(rq.data(), buf + rq_base, rq.size() * sizeof(double), hipMemcpyDeviceToHost, st));
         DMRGX_HIP(hipStreamSynchronize(st));
     }
     stage("rayleigh");
@@ -748,6 +783,7 @@ extern "C" dmrgx_status dmrgx_rdm_create_warm(const dmrgx_sectors* left, const d
 extern "C" dmrgx_status dmrgx_rdm_eigenvalues(const dmrgx_rdm* R, int32_t side, int32_t k, double* host_out)
 {
     if (!R || !host_out || side < 0 || side > 1 || k < 0 || k >= R->nblocks) DMRGX_FAIL(DMRGX_ERR_ARG, "rdm_eigenvalues: bad argument");
+    if (!R->selected[2 * k + side]) DMRGX_FAIL(DMRGX_ERR_ARG, "rdm_eigenvalues: the density matrix (block %d, side %d) was left to another rank", k, side);
     const auto& e = R->eig[2 * k + side];
     std::copy(e.begin(), e.end(), host_out);
     return DMRGX_OK;
@@ -757,6 +793,7 @@ extern "C" dmrgx_status dmrgx_rdm_eigenvectors(const dmrgx_rdm* R, int32_t side,
 {
     if (!R || side < 0 || side > 1 || k < 0 || k >= R->nblocks || count < 0) DMRGX_FAIL(DMRGX_ERR_ARG, "rdm_eigenvectors: bad argument");
     const int mi = 2 * k + side;
+    if (!R->selected[mi]) DMRGX_FAIL(DMRGX_ERR_ARG, "rdm_eigenvectors: the density matrix (block %d, side %d) was left to another rank", k, side);
     const MatDesc& m = R->mats[mi];
     if (count > m.n || (count > 0 && (!dst_dev || ld < m.n))) DMRGX_FAIL(DMRGX_ERR_ARG, "rdm_eigenvectors: count %d > n %d or bad destination", count, m.n);
     if (count == 0) return DMRGX_OK;

@@ -80,7 +80,7 @@ int main(int argc, char** argv)
         ierr = RegisterCorrelators(DMRG); CHKERRQ(ierr);
         ierr = DMRG.Warmup(); CHKERRQ(ierr);
         ierr = DMRG.Sweeps(); CHKERRQ(ierr);
-        printf("FINAL GSEnergy %.14g  MatMults %lld\n", DMRG.GSEnergy(), LLD(DMRG.TotalMatMults()));
+        if (!rank) printf("FINAL GSEnergy %.14g  MatMults %lld  ranks %d\n", DMRG.GSEnergy(), LLD(DMRG.TotalMatMults()), nprocs);
         ierr = DMRG.Destroy(); CHKERRQ(ierr);
     }
     ierr = SlepcFinalize(); CHKERRQ(ierr);

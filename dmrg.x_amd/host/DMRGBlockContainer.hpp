@@ -447,7 +447,18 @@ public:
             if (guessed) { o.use_initial = 1; ++guesses_used; }
             dmrgx_eigs_stats st;
             memset(&st, 0, sizeof(st));
-            if (dmrgx_eigs_lowest(H->plan, &o, &gse_r, gsv_r->buf->dev_uninitialised(), &st, nullptr))
+            if (H->plan_world > 1) {
+                /* striped solve: every rank owns a stripe of the right index of every KronBlock; the solver issues one
+                   RCCL all-gather per MatMult and two fused all-reduces per Lanczos step itself.  The start vector goes in, and
+                   the ground state comes back, in the reference's vector layout, replicated on every rank. */
+                dmrgx_host::DevBuffer psi_full((size_t)kinfo.vec_len, dmrgx_host::DevBuffer::device_only_t{});
+                if (dmrgx_memset_zero(psi_full.dev_uninitialised(), (size_t)kinfo.vec_len * sizeof(double), nullptr)) SETERRQ1(mpi_comm, 1, "%s", dmrgx_last_error());
+                if (guessed && dmrgx_kron_vec_to_striped(H->plan, gsv_r->buf->dev_ro(), psi_full.dev_uninitialised(), nullptr)) SETERRQ1(mpi_comm, 1, "%s", dmrgx_last_error());
+                o.comm = dmrgx_host::WorldComm();
+                if (dmrgx_eigs_lowest(H->plan, &o, &gse_r, psi_full.dev_uninitialised(), &st, nullptr)) SETERRQ1(mpi_comm, 1, "dmrgx_eigs_lowest: %s", dmrgx_last_error());
+                if (dmrgx_kron_vec_from_striped(H->plan, psi_full.dev_ro(), gsv_r->buf->dev_uninitialised(), nullptr)) SETERRQ1(mpi_comm, 1, "%s", dmrgx_last_error());
+            }
+            else if (dmrgx_eigs_lowest(H->plan, &o, &gse_r, gsv_r->buf->dev_uninitialised(), &st, nullptr))
                 SETERRQ1(mpi_comm, 1, "dmrgx_eigs_lowest: %s", dmrgx_last_error());
             timings.nMatMult = st.n_matvec; total_matmults += st.n_matvec; total_eigs_seconds += st.seconds;
             double ms4[4] = {0, 0, 0, 0}; int64_t napp = 0;
@@ -1010,7 +1021,7 @@ public:
         const PetscInt keys[2] = {keyL, keyR};
         std::vector<const double*> v0((size_t)(2 * nb), nullptr);
         PetscInt nwarm = 0;
-        if (use_rdm_warm) for (int side = 0; side < 2; ++side) {
+        if (use_rdm_warm && !dmrgx_host::WorldComm()) for (int side = 0; side < 2; ++side) {
             auto it = rdm_basis.find({keys[side], (keyR == keyL) ? 0 : side});      /* centre step: both sides are the same block */
             if (keys[side] < 0 || it == rdm_basis.end() || it->second.sizes != (side == 0 ? ls : rs)) continue;
             for (PetscInt k = 0; k < nb; ++k) {
@@ -1018,9 +1029,45 @@ public:
                 if (e != it->second.E.end() && e->second) { v0[(size_t)(2 * k + side)] = e->second->dev_ro(); ++nwarm; }
             }
         }
-        if (dmrgx_rdm_create_warm(&sl, &sr, (int32_t)nb, bil.data(), bir.data(), gsv_r->buf->dev_ro(), nwarm ? v0.data() : nullptr, nullptr, &rdm))
+        /* Multi-GPU (the reference solves every density matrix on rank 0 and broadcasts the rotation,
+           include/DMRGBlockContainer.hpp:1673-1677, 1812-1925): the 2 nb density matrices are dealt over the ranks by their n^3
+           cost, heaviest first to the least loaded rank (the same deterministic deal on every rank); each rank builds and
+           diagonalises its share, the spectra are exchanged, every rank performs the same global sort / m-cut, and the owner
+           of a matrix broadcasts its kept eigenvectors. */
+        dmrgx_comm* comm = dmrgx_host::WorldComm();
+        const int W = comm ? dmrgx_host::WorldSize() : 1, me = comm ? dmrgx_host::WorldRank() : 0;
+        std::vector<int> owner((size_t)(2 * nb), 0);
+        if (W > 1) {
+            std::vector<std::pair<double, int>> units;
+            for (PetscInt k = 0; k < nb; ++k) for (int side = 0; side < 2; ++side) { const double n = side == 0 ? ls[bil[k]] : rs[bir[k]]; units.push_back({n * n * n, (int)(2 * k + side)}); }
+            std::stable_sort(units.begin(), units.end(), [](const std::pair<double, int>& a, const std::pair<double, int>& b) { return a.first > b.first; });
+            std::vector<double> load((size_t)W, 0.0);
+            for (const auto& u : units) { int best = 0; for (int w = 1; w < W; ++w) if (load[(size_t)w] < load[(size_t)best]) best = w; load[(size_t)best] += u.first; owner[(size_t)u.second] = best; }
+        }
+        if (W > 1) {
+            std::vector<uint8_t> mask((size_t)nb, 0);
+            for (PetscInt k = 0; k < nb; ++k) mask[(size_t)k] = (uint8_t)((owner[(size_t)(2 * k)] == me ? 1 : 0) | (owner[(size_t)(2 * k + 1)] == me ? 2 : 0));
+            if (dmrgx_rdm_create_subset(&sl, &sr, (int32_t)nb, bil.data(), bir.data(), gsv_r->buf->dev_ro(), mask.data(), nullptr, &rdm))
+                SETERRQ1(mpi_comm, 1, "dmrgx_rdm_create_subset: %s", dmrgx_last_error());
+        }
+        else if (dmrgx_rdm_create_warm(&sl, &sr, (int32_t)nb, bil.data(), bir.data(), gsv_r->buf->dev_ro(), nwarm ? v0.data() : nullptr, nullptr, &rdm))
             SETERRQ1(mpi_comm, 1, "dmrgx_rdm_create: %s", dmrgx_last_error());
-        if (use_rdm_warm) for (int side = 0; side < 2; ++side) {      /* remember this visit's eigenbases (all eigenvectors, as rows) */
+        /* spectra of every matrix on every rank */
+        std::vector<int64_t> spec_off((size_t)(2 * nb + 1), 0);
+        for (PetscInt k = 0; k < nb; ++k) { spec_off[(size_t)(2 * k + 1)] = spec_off[(size_t)(2 * k)] + ls[bil[k]]; spec_off[(size_t)(2 * k + 2)] = spec_off[(size_t)(2 * k + 1)] + rs[bir[k]]; }
+        std::vector<double> spectra((size_t)spec_off[(size_t)(2 * nb)], 0.0);
+        for (PetscInt k = 0; k < nb; ++k) for (int side = 0; side < 2; ++side) {
+            if (owner[(size_t)(2 * k + side)] != me) continue;
+            if (dmrgx_rdm_eigenvalues(rdm, side, (int32_t)k, spectra.data() + spec_off[(size_t)(2 * k + side)])) { dmrgx_rdm_destroy(rdm); SETERRQ1(mpi_comm, 1, "dmrgx_rdm_eigenvalues: %s", dmrgx_last_error()); }
+        }
+        if (W > 1) {
+            std::vector<double> all(spectra.size() * (size_t)W);
+            if (dmrgx_comm_allgather_host(comm, spectra.data(), all.data(), spectra.size() * sizeof(double), nullptr)) { dmrgx_rdm_destroy(rdm); SETERRQ1(mpi_comm, 1, "dmrgx_comm_allgather_host: %s", dmrgx_last_error()); }
+            for (PetscInt u = 0; u < 2 * nb; ++u)
+                std::copy(all.begin() + (int64_t)owner[(size_t)u] * (int64_t)spectra.size() + spec_off[(size_t)u], all.begin() + (int64_t)owner[(size_t)u] * (int64_t)spectra.size() + spec_off[(size_t)u + 1],
+                          spectra.begin() + spec_off[(size_t)u]);
+        }
+        if (use_rdm_warm && W == 1) for (int side = 0; side < 2; ++side) {      /* remember this visit's eigenbases (all eigenvectors, as rows) */
             if (keys[side] < 0 || (side == 1 && keyR == keyL)) continue;
             WarmBasis& wb = rdm_basis[{keys[side], side}];
             wb.sizes = side == 0 ? ls : rs;
@@ -1040,8 +1087,7 @@ public:
             std::vector<Eigen_t> eigen;
             for (PetscInt k = 0; k < nb; ++k) {
                 const PetscInt blk = side == 0 ? bil[k] : bir[k], n = M[side]->Sizes(blk);
-                std::vector<double> w((size_t)n);
-                if (dmrgx_rdm_eigenvalues(rdm, side, (int32_t)k, w.data())) { dmrgx_rdm_destroy(rdm); SETERRQ1(mpi_comm, 1, "dmrgx_rdm_eigenvalues: %s", dmrgx_last_error()); }
+                const double* w = spectra.data() + spec_off[(size_t)(2 * k + side)];
                 for (PetscInt e = 0; e < n; ++e) eigen.push_back({w[(size_t)e], k, e, blk});
             }
             ierr = SaveEntanglementSpectrum(side, eigen, *M[side]); CHKERRQ(ierr);
@@ -1062,7 +1108,9 @@ public:
                 const PetscInt blk = kv.first, k = kv.second.first, cnt = kv.second.second, n = M[side]->Sizes(blk);
                 rot->old_sector.push_back((int32_t)blk); rot->kept.push_back((int32_t)cnt);
                 auto buf = std::make_shared<dmrgx_host::DevBuffer>((size_t)cnt * n, dmrgx_host::DevBuffer::device_only_t{});
-                if (dmrgx_rdm_eigenvectors(rdm, side, (int32_t)k, (int32_t)cnt, buf->dev_uninitialised(), n, nullptr)) { dmrgx_rdm_destroy(rdm); SETERRQ1(mpi_comm, 1, "dmrgx_rdm_eigenvectors: %s", dmrgx_last_error()); }
+                const int own = owner[(size_t)(2 * k + side)];
+                if (own == me && dmrgx_rdm_eigenvectors(rdm, side, (int32_t)k, (int32_t)cnt, buf->dev_uninitialised(), n, nullptr)) { dmrgx_rdm_destroy(rdm); SETERRQ1(mpi_comm, 1, "dmrgx_rdm_eigenvectors: %s", dmrgx_last_error()); }
+                if (W > 1 && dmrgx_comm_bcast(comm, buf->dev_uninitialised(), (size_t)cnt * (size_t)n * sizeof(double), own, nullptr)) { dmrgx_rdm_destroy(rdm); SETERRQ1(mpi_comm, 1, "dmrgx_comm_bcast: %s", dmrgx_last_error()); }
                 rot->rt.push_back(buf);
                 qn_list.push_back(M[side]->List(blk)); qn_size.push_back(cnt);
             }

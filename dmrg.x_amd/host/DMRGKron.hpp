@@ -114,7 +114,9 @@ public:
         ierr = RightBlock.CheckOperators(); CHKERRQ(ierr); ierr = RightBlock.CheckSectors(); CHKERRQ(ierr);
         std::vector<Hamiltonians::Term> TermsLR;
         ierr = ClassifyTerms(Terms, TermsLR); CHKERRQ(ierr);
-        return BuildPlan(LeftBlock.H, RightBlock.H, TermsLR, MatOut);
+        /* the Hamiltonian plan is striped over the ranks of the communicator; the one-term correlator plans
+           below stay whole on every rank (they act on the replicated ground state) */
+        return BuildPlan(LeftBlock.H, RightBlock.H, TermsLR, MatOut, true);
     }
 
     /** Single product Mat_L (x) Mat_R on the KronBlocks (correlators), matrix-free like the Hamiltonian
@@ -148,7 +150,7 @@ private:
         return op == OpSz ? blk.Sz(site) : blk.Sp(site);      /* Sm(i) is read as Sp(i) transposed */
     }
 
-    PetscErrorCode BuildPlan(const Mat& HL, const Mat& HR, const std::vector<Hamiltonians::Term>& TermsLR, Mat& MatOut)
+    PetscErrorCode BuildPlan(const Mat& HL, const Mat& HR, const std::vector<Hamiltonians::Term>& TermsLR, Mat& MatOut, const bool distributed = false)
     {
         std::map<std::pair<int, PetscInt>, int32_t> li, ri;
         std::vector<dmrgx_secop> lops, rops;
@@ -191,11 +193,13 @@ private:
         d.h_left = HL ? &hl : nullptr; d.h_right = HR ? &hr : nullptr;
         d.nterms = (int32_t)terms.size(); d.terms = terms.data();
         d.world_size = 1; d.rank = 0;
+        if (distributed && dmrgx_host::WorldComm()) { d.world_size = dmrgx_host::WorldSize(); d.rank = dmrgx_host::WorldRank(); }
         dmrgx_kron_plan* plan = nullptr;
         if (dmrgx_kron_plan_create(&d, nullptr, &plan)) SETERRQ1(mpi_comm, 1, "dmrgx_kron_plan_create: %s", dmrgx_last_error());
         MatOut = std::make_shared<dmrgx_host::SectorMat>();
         MatOut->plan = plan;
         MatOut->shell_n = num_states;
+        MatOut->plan_world = d.world_size;
         return 0;
     }
 
@@ -218,6 +222,20 @@ private:
 inline PetscErrorCode MatMult_KronSumShell(Mat A, Vec x, Vec y)
 {
     if (!A || !A->plan || !x || !y) SETERRQ(PETSC_COMM_SELF, PETSC_ERR_ARG_CORRUPT, "MatMult_KronSumShell: not a shell matrix / null vector.");
+    if (A->plan_world > 1) {
+        /* striped plan: x (reference layout, replicated) -> rank-major stripes; every rank applies its stripe; one
+           all-gather; back to the reference layout -- the VecScatter-to-all + local rows of the reference (src/DMRGKron.cpp:1833-1869) */
+        dmrgx_kron_info I;
+        if (dmrgx_kron_plan_info(A->plan, &I)) SETERRQ1(PETSC_COMM_SELF, 1, "dmrgx_kron_plan_info: %s", dmrgx_last_error());
+        dmrgx_host::DevBuffer xs((size_t)I.vec_len, dmrgx_host::DevBuffer::device_only_t{}), ys((size_t)I.vec_len, dmrgx_host::DevBuffer::device_only_t{});
+        if (dmrgx_memset_zero(xs.dev_uninitialised(), (size_t)I.vec_len * sizeof(double), nullptr) || dmrgx_memset_zero(ys.dev_uninitialised(), (size_t)I.vec_len * sizeof(double), nullptr) ||
+            dmrgx_kron_vec_to_striped(A->plan, x->buf->dev_ro(), xs.dev_uninitialised(), nullptr) ||
+            dmrgx_kron_apply(A->plan, xs.dev_ro(), ys.dev_uninitialised() + I.local_offset, nullptr) ||
+            dmrgx_comm_allgather(dmrgx_host::WorldComm(), ys.dev_uninitialised(), I.seg_stride, nullptr) ||
+            dmrgx_kron_vec_from_striped(A->plan, ys.dev_ro(), y->buf->dev(), nullptr))
+            SETERRQ1(PETSC_COMM_SELF, 1, "striped MatMult: %s", dmrgx_last_error());
+        return 0;
+    }
     if (dmrgx_kron_apply(A->plan, x->buf->dev_ro(), y->buf->dev(), nullptr)) SETERRQ1(PETSC_COMM_SELF, 1, "dmrgx_kron_apply: %s", dmrgx_last_error());
     return 0;
 }

@@ -95,6 +95,7 @@ public:
     std::vector<MatCell> cells;
     dmrgx_kron_plan* plan = nullptr;  /**< shell matrix: the HIP plan that applies it */
     PetscInt shell_n = 0;
+    int32_t plan_world = 1;           /**< > 1: the plan is striped over the ranks of the communicator */
 
     PetscInt N() const { if (plan) return shell_n; PetscInt n = 0; for (int32_t s : sizes) n += s; return n; }
     std::vector<PetscInt> offsets() const { std::vector<PetscInt> o(sizes.size() + 1, 0); for (size_t i = 0; i < sizes.size(); ++i) o[i + 1] = o[i] + sizes[i]; return o; }

@@ -97,6 +97,19 @@ int main()
             printf("kronblocks %lld %lld", LLD(kb.size()), LLD(kb.NumStates()));
             for (PetscInt k = 0; k < kb.size(); ++k) printf(" %lld,%lld,%lld,%lld", LLD(kb.LeftIdx(k)), LLD(kb.RightIdx(k)), LLD(kb.Sizes(k)), LLD(kb.Offsets(k)));
             printf("\n");
+        } else if (cmd == "iterate") {           /* walk KronBlocksIterator over [istart, iend) of the (sector-filtered) KronBlocks */
+            std::string l, r; PetscInt i0, i1; is >> l >> r >> i0 >> i1;
+            std::vector<PetscReal> qs; PetscReal q;
+            while (is >> q) qs.push_back(q);
+            KronBlocks_t kb(blocks[l], blocks[r], qs, NULL, 0);
+            if (i1 < 0) i1 = kb.NumStates();
+            KronBlocksIterator it(kb, i0, i1);
+            printf("iterate %lld %lld\n", LLD(it.IdxStart()), LLD(it.IdxEnd()));
+            for (; it.Loop(); ++it)
+                printf("it %lld %lld %lld %lld %lld %lld %lld %lld %lld %d %lld %lld %lld\n", LLD(it.Idx()), LLD(it.BlockIdx()), LLD(it.LocIdx()), LLD(it.BlockIdxLeft()),
+                       LLD(it.BlockIdxRight()), LLD(it.LocIdxLeft()), LLD(it.LocIdxRight()), LLD(it.GlobalIdxLeft()), LLD(it.GlobalIdxRight()), (int)it.UpdatedBlock(),
+                       LLD(it.Steps()), LLD(it.BlockStartIdx(0)), LLD(it.BlockSize(+1)));
+            printf("end\n");
         } else if (cmd == "ham") {
             dmrgx_host::Options::Global().Clear();
             std::string k, v;

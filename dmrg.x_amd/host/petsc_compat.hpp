@@ -17,6 +17,9 @@
 #include <stdexcept>
 #include <vector>
 #include <sys/stat.h>
+#include <unistd.h>
+#include <thread>
+#include "dmrgx.h"
 
 typedef int64_t PetscInt;
 typedef double PetscScalar;
@@ -94,6 +97,57 @@ private:
 
 inline int& WorldSize() { static int v = 1; return v; }
 inline int& WorldRank() { static int v = 0; return v; }
+/** the process-wide communicator (NULL on one rank): RCCL over xGMI, or the host-staged rehearsal back-end */
+inline dmrgx_comm*& WorldComm() { static dmrgx_comm* c = nullptr; return c; }
+
+/** One process per GPU, started by any launcher that exports RANK / WORLD_SIZE / LOCAL_RANK (torch.distributed.run's
+    convention; `mpirun`-style launchers of the reference map onto it with a two-line wrapper).  Takes the place of
+    MPI_Init inside SlepcInitialize: selects the device, creates the communicator.
+      DMRGX_COMM=rccl (default)  RCCL; the 128-byte id goes from rank 0 to the others through a rendezvous file
+                                 (DMRGX_RDZV_FILE, default /tmp/dmrgx_rdzv_<launcher pid>_<MASTER_PORT>)
+      DMRGX_COMM=shm             all ranks share one GPU and exchange through POSIX shared memory DMRGX_SHM_NAME
+                                 (rehearsal of the multi-rank control flow on a one-GPU box; tests) */
+inline int CommBootstrap()
+{
+    const char* ws = getenv("WORLD_SIZE");
+    const int world = ws ? atoi(ws) : 1;
+    if (world <= 1) return 0;
+    const int rank = getenv("RANK") ? atoi(getenv("RANK")) : 0;
+    const int local = getenv("LOCAL_RANK") ? atoi(getenv("LOCAL_RANK")) : rank;
+    const std::string mode = getenv("DMRGX_COMM") ? getenv("DMRGX_COMM") : "rccl";
+    const std::string tag = std::to_string((long)getppid()) + "_" + (getenv("MASTER_PORT") ? getenv("MASTER_PORT") : "0");
+    dmrgx_comm* comm = nullptr;
+    if (mode == "shm") {
+        if (dmrgx_set_device(0)) { fprintf(stderr, "[dmrgx] %s\n", dmrgx_last_error()); return 1; }
+        const std::string name = getenv("DMRGX_SHM_NAME") ? getenv("DMRGX_SHM_NAME") : "dmrgx_shm_" + tag;
+        if (dmrgx_comm_init_host_staged(rank, world, name.c_str(), &comm)) { fprintf(stderr, "[dmrgx] %s\n", dmrgx_last_error()); return 1; }
+    } else {
+        if (dmrgx_set_device(local)) { fprintf(stderr, "[dmrgx] %s\n", dmrgx_last_error()); return 1; }
+        const std::string path = getenv("DMRGX_RDZV_FILE") ? getenv("DMRGX_RDZV_FILE") : "/tmp/dmrgx_rdzv_" + tag;
+        uint8_t id[DMRGX_COMM_ID_BYTES];
+        if (rank == 0) {
+            if (dmrgx_comm_unique_id(id)) { fprintf(stderr, "[dmrgx] %s\n", dmrgx_last_error()); return 1; }
+            const std::string tmp = path + ".tmp";
+            FILE* f = fopen(tmp.c_str(), "wb");
+            if (!f || fwrite(id, 1, sizeof(id), f) != sizeof(id)) { fprintf(stderr, "[dmrgx] cannot write %s\n", tmp.c_str()); return 1; }
+            fclose(f);
+            if (rename(tmp.c_str(), path.c_str()) != 0) { fprintf(stderr, "[dmrgx] cannot publish %s\n", path.c_str()); return 1; }
+        } else {
+            const auto t0 = std::chrono::steady_clock::now();
+            while (true) {
+                FILE* f = fopen(path.c_str(), "rb");
+                if (f) { const size_t n = fread(id, 1, sizeof(id), f); fclose(f); if (n == sizeof(id)) break; }
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(300)) { fprintf(stderr, "[dmrgx] rank %d: no rendezvous file %s\n", rank, path.c_str()); return 1; }
+                std::this_thread::sleep_for(std::chrono::milliseconds(10));
+            }
+        }
+        if (dmrgx_comm_init(rank, world, id, &comm)) { fprintf(stderr, "[dmrgx] %s\n", dmrgx_last_error()); return 1; }
+        if (dmrgx_comm_barrier(comm, nullptr)) { fprintf(stderr, "[dmrgx] %s\n", dmrgx_last_error()); return 1; }
+        if (rank == 0) unlink(path.c_str());
+    }
+    WorldSize() = world; WorldRank() = rank; WorldComm() = comm;
+    return 0;
+}
 
 }  // namespace dmrgx_host
 
@@ -145,20 +199,24 @@ inline PetscErrorCode PetscOptionsSetValue(void*, const char* name, const char* 
 
 inline PetscErrorCode MPI_Comm_size(MPI_Comm, PetscMPIInt* n) { *n = dmrgx_host::WorldSize(); return 0; }
 inline PetscErrorCode MPI_Comm_rank(MPI_Comm, PetscMPIInt* r) { *r = dmrgx_host::WorldRank(); return 0; }
-inline PetscErrorCode MPI_Barrier(MPI_Comm) { return 0; }
+inline PetscErrorCode MPI_Barrier(MPI_Comm) { return dmrgx_host::WorldComm() ? (PetscErrorCode)dmrgx_comm_barrier(dmrgx_host::WorldComm(), nullptr) : 0; }
 
 inline PetscErrorCode SlepcInitialize(int* argc, char*** argv, const char*, const char*) {
     if (argc && argv) dmrgx_host::Options::Global().Parse(*argc, *argv);
+    return dmrgx_host::CommBootstrap();
+}
+inline PetscErrorCode SlepcFinalize() {
+    if (dmrgx_host::WorldComm()) { dmrgx_comm_destroy(dmrgx_host::WorldComm()); dmrgx_host::WorldComm() = nullptr; }
     return 0;
 }
-inline PetscErrorCode SlepcFinalize() { return 0; }
 inline PetscErrorCode PetscTime(PetscLogDouble* t) {
     *t = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
     return 0;
 }
 #define PetscPrintf(comm, ...) (printf(__VA_ARGS__), 0)
 inline PetscErrorCode PetscFOpen(MPI_Comm, const char* fn, const char* mode, FILE** fp) {
-    *fp = fopen(fn, mode);
+    /* like PETSc's: only the first rank of the communicator owns the file; the others write into the void */
+    *fp = fopen(dmrgx_host::WorldRank() == 0 ? fn : "/dev/null", mode);
     if (!*fp) { fprintf(stderr, "[dmrgx] cannot open %s\n", fn); return PETSC_ERR_FILE_OPEN; }
     return 0;
 }

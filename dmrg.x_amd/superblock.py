@@ -114,10 +114,12 @@ class KronPlan:
                                                             self._stream_ptr(stream)))
 
     def eigs_lowest(self, ncv=16, max_it=1000, tol=1e-8, seed=1, psi0=None, allgather=None, allreduce=None, stream=None,
-                    max_matvec=0):
+                    max_matvec=0, comm=None):
         """Lowest eigenpair (EPS_HEP / EPS_SMALLEST_REAL / nev=1).  Returns (e0, psi_full tensor, stats).
 
-        max_matvec > 0 (benchmarks): run exactly that many Lanczos steps; non-convergence is then not an error."""
+        max_matvec > 0 (benchmarks): run exactly that many Lanczos steps; non-convergence is then not an error.
+        comm: a Communicator -- the solver then issues its RCCL collectives itself (no Python inside the solve); the
+        allgather/allreduce callbacks are the harness alternative."""
         opts = _capi.EigsOpts()
         opts.ncv, opts.max_it, opts.tol, opts.seed, opts.max_matvec = ncv, max_it, tol, seed, max_matvec
         psi = self.new_vector()
@@ -127,6 +129,7 @@ class KronPlan:
         self._cb = (_capi.ALLGATHER_FN(allgather) if allgather else _capi.ALLGATHER_FN(),
                     _capi.ALLREDUCE_FN(allreduce) if allreduce else _capi.ALLREDUCE_FN())
         opts.allgather, opts.allreduce_sum = self._cb
+        opts.comm = comm.handle if comm is not None else None
         e0 = C.c_double(0.0)
         stats = _capi.EigsStats()
         rc = _capi.lib().dmrgx_eigs_lowest(self._handle, C.byref(opts), C.byref(e0), C.c_void_p(psi.data_ptr()),
@@ -221,3 +224,54 @@ class ReducedDensityMatrices:
             self.destroy()
         except Exception:
             pass
+
+
+class Communicator:
+    """dmrgx_comm handle: RCCL over xGMI (one process per GPU), or the host-staged rehearsal back-end for several ranks on one
+    GPU.  The 128-byte RCCL id is produced by rank 0 (Communicator.unique_id()) and handed to the other ranks by the caller
+    (bench.py: one torch.distributed broadcast at start-up; the C++ engine: a rendezvous file)."""
+
+    def __init__(self, rank, world, unique_id=None, host_staged_name=None):
+        L = _capi.lib()
+        self.handle = C.c_void_p()
+        self.rank, self.world = rank, world
+        if host_staged_name is not None:
+            _capi.check(L.dmrgx_comm_init_host_staged(rank, world, host_staged_name.encode(), C.byref(self.handle)))
+        else:
+            assert unique_id is not None and len(unique_id) == 128
+            buf = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
+            _capi.check(L.dmrgx_comm_init(rank, world, C.cast(buf, C.c_void_p), C.byref(self.handle)))
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_uint8 * 128)()
+        _capi.check(_capi.lib().dmrgx_comm_unique_id(C.cast(buf, C.c_void_p)))
+        return bytes(buf)
+
+    @staticmethod
+    def _st(stream):
+        return C.c_void_p((stream or torch.cuda.current_stream()).cuda_stream)
+
+    def allgather(self, full, seg_stride, stream=None):
+        _capi.check(_capi.lib().dmrgx_comm_allgather(self.handle, C.c_void_p(full.data_ptr()), seg_stride, self._st(stream)))
+
+    def allreduce_sum(self, buf, stream=None):
+        _capi.check(_capi.lib().dmrgx_comm_allreduce_sum(self.handle, C.c_void_p(buf.data_ptr()), buf.numel(), self._st(stream)))
+
+    def bcast(self, buf, root, stream=None):
+        _capi.check(_capi.lib().dmrgx_comm_bcast(self.handle, C.c_void_p(buf.data_ptr()), buf.numel() * buf.element_size(), root, self._st(stream)))
+
+    def allgather_host(self, arr, stream=None):
+        """arr: C-contiguous numpy array (same shape on every rank) -> array of shape (world,) + arr.shape."""
+        arr = np.ascontiguousarray(arr)
+        out = np.empty((self.world,) + arr.shape, dtype=arr.dtype)
+        _capi.check(_capi.lib().dmrgx_comm_allgather_host(self.handle, arr.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), arr.nbytes, self._st(stream)))
+        return out
+
+    def barrier(self, stream=None):
+        _capi.check(_capi.lib().dmrgx_comm_barrier(self.handle, self._st(stream)))
+
+    def destroy(self):
+        if self.handle:
+            _capi.check(_capi.lib().dmrgx_comm_destroy(self.handle))
+            self.handle = C.c_void_p()

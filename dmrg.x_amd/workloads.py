@@ -79,12 +79,14 @@ def kept_profile(m, sigma=1.8):
 
 
 def enlarged_sectors(kept):
-    """-> (qn list desc, sizes, sub = [(size_down_part, size_up_part)]) ; q_e in units of 1/2 stored as 2*Sz."""
-    two_q = sorted({2 * q + 1 for q in kept} | {2 * q - 1 for q in kept}, reverse=True)
+    """kept: {Sz of a kept-block sector: size} (Sz integer or half-integer).
+    -> (qn list desc, sizes, sub = [(size_down_part, size_up_part)]) of kept (x) one spin-1/2 site."""
+    kept2 = {int(round(2 * q)): n for q, n in kept.items()}          # keyed by 2*Sz
+    two_q = sorted({t + 1 for t in kept2} | {t - 1 for t in kept2}, reverse=True)
     qn, sizes, sub = [], [], []
     for tq in two_q:
-        dn = kept.get((tq + 1) // 2, 0)   # old sector q_e + 1/2, new site down
-        up = kept.get((tq - 1) // 2, 0)   # old sector q_e - 1/2, new site up
+        dn = kept2.get(tq + 1, 0)   # old sector q_e + 1/2, new site down
+        up = kept2.get(tq - 1, 0)   # old sector q_e - 1/2, new site up
         if dn + up == 0:
             continue
         qn.append(tq / 2.0)
@@ -140,12 +142,23 @@ def _sym_block_op(rng, sizes):
     return op
 
 
+# Kept-block sector tables of a REAL mid-sweep step of BASELINE configs[3] (J1-J2 20x8 cylinder, J2 = 0.5, m = 2048), dumped by
+# the engine into KronStats.json (second sweep, GlobIdx 228: system block of 80 sites, environment block of 78 sites;
+# profiles/r02_cfg4_sweep_kronstats.json).  The real distribution is narrower than SURVEY 8d's sigma = 1.8 estimate
+# (central sectors of 578 / 459 states instead of 462 / 388), which makes the real superblock 1.7x heavier per MatMult.
+REAL_PROFILES = {
+    "cfg4real": dict(left={4: 4, 3: 52, 2: 220, 1: 459, 0: 578, -1: 459, -2: 220, -3: 52, -4: 4},
+                     right={4: 6, 3: 58, 2: 220, 1: 453, 0: 575, -1: 453, -2: 220, -3: 57, -4: 6}),
+}
+
 CONFIGS = {
     # name: (m, Ly, J1, Jz1, J2, Jz2, seed)   -- BASELINE.json configs[0..4]; seeds per SURVEY 8d
     "cfg1": dict(m=64, Ly=1, J1=0.5, Jz1=1.0, J2=0.0, Jz2=0.0, seed=20261, desc="1D Heisenberg chain 16x1, m=64"),
     "cfg2": dict(m=512, Ly=4, J1=1.0, Jz1=1.0, J2=0.5, Jz2=0.5, seed=20262, desc="J1-J2 8x4 cylinder, J2=0.5, m=512"),
     "cfg3": dict(m=1024, Ly=6, J1=0.5, Jz1=1.0, J2=0.0, Jz2=0.0, seed=20263, desc="Heisenberg 16x6 cylinder, m=1024"),
     "cfg4": dict(m=2048, Ly=8, J1=1.0, Jz1=1.0, J2=0.5, Jz2=0.5, seed=20264, desc="J1-J2 20x8 cylinder, J2=0.5, m=2048"),
+    "cfg4real": dict(m=2048, Ly=8, J1=1.0, Jz1=1.0, J2=0.5, Jz2=0.5, seed=20264,
+                     desc="J1-J2 20x8 cylinder, J2=0.5, m=2048, sector tables of a real mid-sweep step (80|78 sites) of the engine's second sweep"),
     "cfg5": dict(m=4096, Ly=8, J1=1.0, Jz1=0.0, J2=0.0, Jz2=0.0, seed=20265, desc="XY 32x8 cylinder (no NNN: reference quirk), m=4096"),
 }
 
@@ -189,12 +202,16 @@ def synthetic_superblock(name="cfg2", m=None, Ly=None, seed=None, sigma=1.8, **c
         cfg["seed"] = seed
     cfg.update(couplings)
     rng = np.random.default_rng(cfg["seed"])
-    kept = kept_profile(cfg["m"], sigma)
-    qn, sizes, sub = enlarged_sectors(kept)
+    if name in REAL_PROFILES and m is None:
+        kept_l, kept_r = REAL_PROFILES[name]["left"], REAL_PROFILES[name]["right"]
+    else:
+        kept_l = kept_r = kept_profile(cfg["m"], sigma)
+    qn, sizes, sub = enlarged_sectors(kept_l)
+    rqn, rsizes, rsub = (qn, sizes, sub) if kept_r is kept_l else enlarged_sectors(kept_r)
     Ly = cfg["Ly"]
     terms = column_cut_terms(Ly, cfg["J1"], cfg["Jz1"], cfg["J2"], cfg["Jz2"])
 
-    def side_ops(used):
+    def side_ops(used, sizes, sub):
         ops = {}
         for (op, site) in sorted(used):
             base = OpSp if op in (OpSp, OpSm) else OpSz
@@ -206,12 +223,12 @@ def synthetic_superblock(name="cfg2", m=None, Ly=None, seed=None, sigma=1.8, **c
                 ops[(base, site)] = _old_site_op(rng, base, sizes, sub)
         return ops
 
-    left_ops = side_ops({(t[1], t[2]) for t in terms})
-    right_ops = side_ops({(t[3], t[4]) for t in terms})
-    h_left, h_right = _sym_block_op(rng, sizes), _sym_block_op(rng, sizes)
+    left_ops = side_ops({(t[1], t[2]) for t in terms}, sizes, sub)
+    right_ops = side_ops({(t[3], t[4]) for t in terms}, rsizes, rsub)
+    h_left, h_right = _sym_block_op(rng, sizes), _sym_block_op(rng, rsizes)
     # target sector Sz_total = 0: q_L + q_R == 0, nested IL-then-IR order (include/DMRGKron.hpp:160-171)
-    blocks = [(il, ir) for il in range(len(qn)) for ir in range(len(qn)) if qn[il] + qn[ir] == 0.0]
-    return Superblock(name=name, left_sizes=list(sizes), right_sizes=list(sizes), left_qn=list(qn), right_qn=list(qn),
+    blocks = [(il, ir) for il in range(len(qn)) for ir in range(len(rqn)) if qn[il] + rqn[ir] == 0.0]
+    return Superblock(name=name, left_sizes=list(sizes), right_sizes=list(rsizes), left_qn=list(qn), right_qn=list(rqn),
                       blocks=blocks, left_ops=left_ops, right_ops=right_ops, h_left=h_left, h_right=h_right,
                       terms=terms, n_left_sites=Ly, n_right_sites=Ly)
 

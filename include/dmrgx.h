@@ -14,10 +14,15 @@
  *   dmrgx_kron_plan_destroy  <- MatDestroy_KronSumShell (src/DMRGKron.cpp:1919-1942)
  *   dmrgx_eigs_lowest        <- EPSSolve(EPS_HEP, EPS_SMALLEST_REAL, nev=1) as configured at
  *                               include/DMRGBlockContainer.hpp:1488-1499 [SLEPc Krylov-Schur, external]
- *   dmrgx_rdm_truncate       <- GetTruncation + EigRDM_BlockDiag + FillRotation_BlockDiag
- *                               (include/DMRGBlockContainer.hpp:1656-2057)
+ *   dmrgx_rdm_create         <- the device part of GetTruncation: rho_L, rho_R of every KronBlock and all their eigenpairs
+ *   dmrgx_rdm_eigenvalues       (EigRDM_BlockDiag, include/DMRGBlockContainer.hpp:1715-1775, 1962-2003); the global sort and
+ *   dmrgx_rdm_eigenvectors      the m-cut stay with the caller; _eigenvectors == FillRotation_BlockDiag (:2006-2057)
  *   dmrgx_rotate_ops         <- Block::SpinBase::RotateOperators (src/DMRGBlock.cpp:677-823)
- *   dmrgx_enlarge_ops        <- MatKronEyeConstruct + block-H KronSum (src/DMRGKron.cpp:52-456, 612)
+ *   dmrgx_cells_axpy         <- the explicit KronSum that assembles an enlarged block's H (src/DMRGKron.cpp:612 ->
+ *                               KronSumFillMatrix :1440-1446); the site operators of an enlarged block
+ *                               (MatKronEyeConstruct, src/DMRGKron.cpp:52-456) are views and need no device call
+ *   dmrgx_comm_*             <- the communicator of the reference's MPI path: VecScatter-to-all of x inside every MatMult
+ *                               (src/DMRGKron.cpp:1833-1834) and the MPI_Allreduce behind SLEPc's VecDot / VecNorm
  *
  * Data model.  All floating point is f64 real (include/DMRGKron.hpp:395-399).  A block's basis is split in
  * Sz sectors (descending Sz); an operator with sector shift s (Op_t value: Sm=-1, Sz=0, Sp=+1,
@@ -39,7 +44,7 @@
 extern "C" {
 #endif
 
-#define DMRGX_ABI_VERSION 1
+#define DMRGX_ABI_VERSION 2
 
 typedef int32_t dmrgx_status;
 enum {
@@ -56,6 +61,32 @@ enum {
 int32_t      dmrgx_abi_version(void);
 const char*  dmrgx_last_error(void);                 /* thread-local, valid until the next failing call  */
 dmrgx_status dmrgx_device_count(int32_t* n);         /* fails loudly (DMRGX_ERR_DEVICE) without a GPU     */
+
+/* ---- communicator: one process per GPU, collectives over RCCL / xGMI ------------------------ */
+/* Replaces the reference's MPI traffic on the hot path: the VecScatter-to-all of x inside every MatMult
+ * (src/DMRGKron.cpp:1833-1834), the MPI_Allreduce behind SLEPc's VecDot / VecNorm, and the rank-0 RDM solve followed by
+ * a broadcast of the rotation (include/DMRGBlockContainer.hpp:1673-1677, 1812-1925).  Every collective is enqueued on the
+ * caller's stream and must be called by all ranks in the same order.
+ *   launch: rank 0 calls dmrgx_comm_unique_id and hands the 128 bytes to the other ranks by any means (file, socket, the
+ *   launcher's store); every rank then calls dmrgx_set_device(local rank) and dmrgx_comm_init.
+ * The host-staged back-end (several ranks on ONE GPU exchanging through a POSIX shared-memory segment named by rank 0)
+ * exists to rehearse the N > 1 control flow on a one-GPU box; it is not a measurement path. */
+typedef struct dmrgx_comm dmrgx_comm;
+#define DMRGX_COMM_ID_BYTES 128
+enum { DMRGX_COMM_RCCL = 1, DMRGX_COMM_HOST_STAGED = 2 };
+dmrgx_status dmrgx_set_device(int32_t device);
+dmrgx_status dmrgx_comm_unique_id(uint8_t* id128);
+dmrgx_status dmrgx_comm_init(int32_t rank, int32_t world, const uint8_t* id128, dmrgx_comm** out);
+dmrgx_status dmrgx_comm_init_host_staged(int32_t rank, int32_t world, const char* shm_name, dmrgx_comm** out);
+dmrgx_status dmrgx_comm_info(const dmrgx_comm* comm, int32_t* rank, int32_t* world, int32_t* backend);
+/* in place: segment r of full_vec (seg_stride doubles, this rank's = the send buffer) is replicated on every rank */
+dmrgx_status dmrgx_comm_allgather(dmrgx_comm* comm, double* full_vec_dev, int64_t seg_stride, void* stream);
+dmrgx_status dmrgx_comm_allreduce_sum(dmrgx_comm* comm, double* buf_dev, int64_t count, void* stream);
+dmrgx_status dmrgx_comm_bcast(dmrgx_comm* comm, void* buf_dev, size_t bytes, int32_t root, void* stream);
+/* host payloads (spectra, counters): recv = concatenation over ranks of bytes_per_rank bytes; synchronises the stream */
+dmrgx_status dmrgx_comm_allgather_host(dmrgx_comm* comm, const void* send, void* recv, size_t bytes_per_rank, void* stream);
+dmrgx_status dmrgx_comm_barrier(dmrgx_comm* comm, void* stream);      /* all ranks have finished the work queued on `stream` */
+dmrgx_status dmrgx_comm_destroy(dmrgx_comm* comm);
 
 /* ---- operator cells --------------------------------------------------------------------------------- */
 enum { DMRGX_CELL_DENSE = 1, DMRGX_CELL_IDENT = 2 };
@@ -180,6 +211,9 @@ typedef struct {
     dmrgx_status (*allgather)(void* user, double* full_vec, int64_t seg_stride, void* stream);
     dmrgx_status (*allreduce_sum)(void* user, double* buf, int64_t count, void* stream);
     void* user;
+    /* native collectives: when `comm` is set (and the hooks are NULL) the solver calls dmrgx_comm_allgather /
+     * dmrgx_comm_allreduce_sum itself -- the product path; the hooks remain for harnesses that own their communicator */
+    dmrgx_comm* comm;
 } dmrgx_eigs_opts;
 
 typedef struct {
@@ -207,6 +241,12 @@ dmrgx_status dmrgx_rdm_create(const dmrgx_sectors* left, const dmrgx_sectors* ri
  * previous visit of the same block).  Results do not depend on v0_rows, only the number of Jacobi sweeps can.  It is a
  * hint: the default solver preconditions every matrix with one Householder-QR step on the sorted matrix (csrc/hqr.hip),
  * which supersedes it; with DMRGX_RDM_QR=0 the matrix is transformed into the supplied basis before the iteration. */
+/* Multi-GPU form: only the density matrices selected by side_mask[k] (bit 0: rho_L, bit 1: rho_R of KronBlock k) are built and
+ * diagonalised by this rank -- the matrices of a step are dealt over the ranks by their n^3 cost; psi_dev is the
+ * whole vector on every rank.  Queries for a matrix that was not selected fail with DMRGX_ERR_ARG. */
+dmrgx_status dmrgx_rdm_create_subset(const dmrgx_sectors* left, const dmrgx_sectors* right, int32_t nblocks,
+                                     const int32_t* block_il, const int32_t* block_ir, const double* psi_dev,
+                                     const uint8_t* side_mask, void* stream, dmrgx_rdm** out);
 dmrgx_status dmrgx_rdm_create_warm(const dmrgx_sectors* left, const dmrgx_sectors* right, int32_t nblocks,
                                    const int32_t* block_il, const int32_t* block_ir, const double* psi_dev,
                                    const double* const* v0_rows, void* stream, dmrgx_rdm** out);

@@ -16,10 +16,32 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE = os.path.join(ROOT, "dmrg.x_amd", "dmrgx-square-lattice")
 
 
-def run_engine(tmp_path, *opts):
+def run_engine(tmp_path, *opts, ranks=1):
+    """ranks > 1: that many engine processes share cuda:0 and talk through the host-staged communicator (DMRGX_COMM=shm) --
+    the multi-GPU control flow (striped plan, native collectives inside the eigensolve, density matrices dealt over the
+    ranks, broadcast rotations) rehearsed on the one-GPU test box; rank 0 writes the output files."""
     d = str(tmp_path) + "/"
-    out = subprocess.run([EXE, *[str(o) for o in opts], "-data_dir", d], capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    os.makedirs(d, exist_ok=True)
+    cmd = [EXE, *[str(o) for o in opts], "-data_dir", d]
+    if ranks == 1:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    else:
+        name = "dmrgx_test_%d_%s" % (os.getpid(), os.path.basename(os.path.normpath(d)))
+        procs = []
+        for r in range(ranks):
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(ranks), LOCAL_RANK="0", DMRGX_COMM="shm", DMRGX_SHM_NAME=name, DMRGX_SHM_MB="64")
+            procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+        outs = []
+        try:
+            for pr in procs:
+                outs.append(pr.communicate(timeout=600)[0])
+        finally:
+            for pr in procs:
+                if pr.poll() is None:
+                    pr.kill()
+        for r, (pr, o) in enumerate(zip(procs, outs)):
+            assert pr.returncode == 0, "rank %d: %s" % (r, o[-3000:])
     steps = json.load(open(d + "DMRGSteps.json"))
     rows = [dict(zip(steps["headers"], r)) for r in steps["table"]]
     run = json.load(open(d + "DMRGRun.json"))
@@ -92,6 +114,113 @@ def test_step_by_step_parity_with_oracle_under_truncation(tmp_path):
             assert abs(g - w) <= 1e-10 * max(abs(w), 1e-2), (c["name"], g, w)
             nonzero += abs(w) > 1e-3
     assert nonzero > 20                                                    # Sz = 1 sector: magnetisations do not vanish
+
+
+TRUNCATING_2D = [
+    # (Lx, Ly, J1, Jz1, J2, Jz2, Sz sector): J1-J2 lattices with next-nearest-neighbour terms, every one truncating hard at m = 4
+    # (TruncErr 1e-4 .. 1e-1) with every m-cut inside a spectral gap (scanned with the oracle; asserted below)
+    (6, 2, 0.7, 1.0, 0.4, 0.6, 1),      # Ly = 2: periodic-y doubles the vertical and the diagonal bonds
+    (8, 2, 0.7, 1.0, 0.4, 0.6, 1),
+    (4, 4, 1.0, 1.0, 0.5, 0.5, 1),      # BASELINE's couplings (J2 = Jz2 = 0.5), mid-column cuts of a width-4 cylinder
+    (6, 4, 1.0, 0.8, 0.5, 0.3, 1),      # 24 sites, 48 steps
+]
+
+
+@pytest.mark.parametrize("ranks", [1, 2])
+@pytest.mark.parametrize("Lx,Ly,J1,Jz1,J2,Jz2,sz", TRUNCATING_2D)
+def test_step_by_step_parity_with_oracle_under_truncation_2d(tmp_path, Lx, Ly, J1, Jz1, J2, Jz2, sz, ranks):
+    """The step-by-step comparison of the chain test on two-dimensional J1-J2 lattices where the m-cut bites: NNN terms,
+    the doubled bonds of Ly = 2, cuts in the middle of a column (one side holds fewer distinct operators than the other,
+    which flips the plan's operator-merge direction), the operator pruning of the sweep schedule.  Per step: sizes,
+    ground-state energy and both truncation errors at 1e-10 relative against the CPU restatement of the reference
+    (include/DMRGBlockContainer.hpp:1656-1959, src/Hamiltonians.cpp:93-112); then every correlator row."""
+    H = J1J2XXZModel_SquareLattice(Lx=Lx, Ly=Ly, J1=J1, Jz1=Jz1, J2=J2, Jz2=Jz2)
+    m = 4
+    if ranks > 1 and Lx * Ly > 16:
+        pytest.skip("the two-rank rehearsal runs the two smaller lattices")
+    rows, run, _ = run_engine(tmp_path, "-Lx", Lx, "-Ly", Ly, "-J1", J1, "-Jz1", Jz1, "-J2", J2, "-Jz2", Jz2, "-qn_sector", sz, "-mwarmup", m,
+                              "-nsweeps", 2, "-H_eps_tol", 1e-13, ranks=ranks)
+    corr = json.load(open(str(tmp_path) + "/Correlations.json"))
+    orc = DMRGOracle(H, m, qn_sector=float(sz))
+    for c in corr["info"]:
+        orc.SetUpCorrelation(parse_desc2(c["desc2"]))
+    orc.Warmup()
+    orc.Sweeps(nsweeps=2)
+    for o in orc.steps:
+        for lam_kept, lam_dropped in (o["cut_Sys"], o["cut_Env"]):
+            assert lam_kept > 1e-9 and (lam_dropped == 0.0 or (lam_kept - lam_dropped) / lam_kept > 1e-2), "parity case is not well-defined"
+    assert any(t.Isite != t.Jsite and abs(t.a) in (J2, Jz2) for t in H.H(Lx * Ly))        # the NNN terms are there
+    assert len(rows) == len(orc.steps)
+    for r, o in zip(rows, orc.steps):
+        for key in ("NSites_Sys", "NSites_Env", "NStates_SysEnl", "NStates_EnvEnl", "NumStates_H", "NStates_SysRot", "NStates_EnvRot"):
+            assert r[key] == o[key], (r["GlobIdx"], key)
+        assert abs(r["GSEnergy"] - o["GSEnergy"]) <= 1e-10 * abs(o["GSEnergy"]), (r["GlobIdx"], r["GSEnergy"], o["GSEnergy"])
+        for side in ("TruncErr_Sys", "TruncErr_Env"):      # same absolute slack as the chain test (Lanczos residual 1e-13 vs dense eigh)
+            assert abs(r[side] - o[side]) <= 1e-10 * abs(o[side]) + 1e-13, (r["GlobIdx"], side, r[side], o[side])
+    assert max(o["TruncErr_Sys"] for o in orc.steps) > 5e-5
+    assert len(corr["values"]) == len(orc.corr_values) == 3
+    nonzero = 0
+    for got, want in zip(corr["values"], orc.corr_values):
+        assert len(got) == len(want) == len(corr["info"])
+        for c, g, w in zip(corr["info"], got, want):
+            assert abs(g - w) <= 1e-10 * max(abs(w), 1e-2), (c["name"], g, w)
+            nonzero += abs(w) > 1e-3
+    assert nonzero > 20
+
+
+def test_baseline_config1_energy_against_the_oracle_at_reduced_m(tmp_path):
+    """BASELINE configs[1] (J1-J2 8x4 cylinder, J2 = 0.5) is too large for exact diagonalisation and, at m = 512, for the CPU
+    oracle.  In the Sz = 0 sector the +q/-q spectra are degenerate, so the kept subspaces of two implementations may differ by
+    the states at the cut and energies agree only at the truncation-error level: the engine at m = 48
+    must reproduce the oracle's m = 48 energy within 2 x (largest truncation error) x |E|, and the energy bench.py quotes at
+    m = 512 must lie below both and within the same scale of them (DMRG is variational in m)."""
+    H = J1J2XXZModel_SquareLattice(Lx=8, Ly=4, J1=1.0, Jz1=1.0, J2=0.5, Jz2=0.5)
+    orc = DMRGOracle(H, 48)
+    orc.Warmup()
+    orc.Sweeps(nsweeps=1)
+    trunc = max(o["TruncErr_Sys"] for o in orc.steps)
+    assert 1e-7 < trunc < 1e-4
+    model = ["-Lx", 8, "-Ly", 4, "-J1", 1, "-Jz1", 1, "-J2", 0.5, "-Jz2", 0.5, "-nsweeps", 1, "-H_eps_tol", 1e-12]
+    _, run48, _ = run_engine(tmp_path / "m48", *model, "-mwarmup", 48)
+    _, run512, _ = run_engine(tmp_path / "m512", *model, "-mwarmup", 512)
+    e_o, e48, e512 = orc.gse, run48["GSEnergy"], run512["GSEnergy"]
+    assert abs(e48 - e_o) <= 2.0 * trunc * abs(e_o), (e48, e_o, trunc)
+    assert e512 < min(e48, e_o) and min(e48, e_o) - e512 <= 20.0 * trunc * abs(e_o), (e512, e48, e_o)
+    assert abs(e512 - (-27.92734251200497)) <= 1e-7 * abs(e512)          # the value bench.py's sweep leg printed in round 1
+
+
+def test_multi_rank_engine_sweep_reproduces_the_single_rank_run(tmp_path):
+    """A whole engine run on 3 ranks (striped Hamiltonian plan, RDMs dealt by n^3, rotations from broadcast eigenvectors) against
+    the same run on one rank, J1-J2 6x4 at m = 40 in the Sz = 1 sector: sector tables of the warm-up, every warm-up energy at
+    1e-10 relative, the final energy within the scale of the truncation error (beyond the first steps the edge steps of a
+    sweep keep numerically-zero states, whose choice -- made by rounding noise, here by the summation order of the reductions --
+    shifts later energies at the truncation-error level in any implementation; the m = 4 parity cases above have no such steps
+    and agree with the oracle to 1e-10 on two ranks as well)."""
+    model = ["-Lx", 6, "-Ly", 4, "-J1", 1, "-Jz1", 0.8, "-J2", 0.5, "-Jz2", 0.3, "-qn_sector", 1, "-mwarmup", 40, "-nsweeps", 1, "-H_eps_tol", 1e-12]
+    r1, run1, _ = run_engine(tmp_path / "w1", *model)
+    r3, run3, _ = run_engine(tmp_path / "w3", *model, ranks=3)
+    assert len(r1) == len(r3) == 8 + 20
+    trunc = max(max(r["TruncErr_Sys"] for r in r1), 1e-12)
+    for a, b in zip(r1, r3):
+        if a["LoopType"] == "Warmup" and a["GlobIdx"] < 4:
+            assert a["NumStates_H"] == b["NumStates_H"] and abs(a["GSEnergy"] - b["GSEnergy"]) <= 1e-10 * abs(a["GSEnergy"]), a["GlobIdx"]
+        assert abs(a["GSEnergy"] - b["GSEnergy"]) <= 10.0 * trunc * abs(a["GSEnergy"]), (a["GlobIdx"], a["GSEnergy"], b["GSEnergy"])
+    assert abs(run1["GSEnergy"] - run3["GSEnergy"]) <= 10.0 * trunc * abs(run1["GSEnergy"])
+    c1, c3 = (json.load(open(str(tmp_path / d) + "/Correlations.json")) for d in ("w1", "w3"))
+    assert len(c1["values"]) == len(c3["values"]) == 2
+
+
+def test_pruned_and_unpruned_operator_sets_give_identical_steps(tmp_path):
+    """-prune_ops 0 rotates and keeps every Sz(i)/Sp(i) of every block, as the reference does; the default keeps the sites a
+    later inter-block term or a registered correlator can touch and skips the blocks no later step reads.  Every row of
+    DMRGSteps.json and every correlator value must be identical, bit for bit (J1-J2 6x4, m = 48, truncating)."""
+    model = ["-Lx", 6, "-Ly", 4, "-J1", 1, "-Jz1", 1, "-J2", 0.5, "-Jz2", 0.5, "-mwarmup", 48, "-nsweeps", 2]
+    ra, _, ta = run_engine(tmp_path / "a", *model)
+    rb, _, tb = run_engine(tmp_path / "b", *model, "-prune_ops", 0)
+    assert ra == rb and len(ra) == 8 + 2 * 20
+    ca, cb = (json.load(open(str(tmp_path / d) + "/Correlations.json")) for d in ("a", "b"))
+    assert ca["values"] == cb["values"] and len(ca["values"]) == 3
+    assert max(r["TruncErr_Sys"] for r in ra) > 1e-8
 
 
 def test_correlators_match_exact_diagonalisation(tmp_path):
@@ -243,8 +372,33 @@ def test_two_rank_eigensolve_on_one_gpu():
     assert "two-rank eigensolve ok" in outs[0]
 
 
+def test_native_communicator_rccl_single_rank():
+    """csrc/comm.hip, RCCL back-end on the one GPU of the box (world 1): librccl.so resolves, the communicator initialises and
+    the in-place collective call forms run; the eigensolver accepts opts.comm."""
+    import sys
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "comm_worker.py"), "rccl1"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert p.returncode == 0 and "native rccl communicator ok" in p.stdout.decode(), p.stdout.decode()[-3000:]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_native_communicator_host_staged_ranks_on_one_gpu(world):
+    """The same entry points through the host-staged back-end, `world` processes sharing cuda:0: all-gather / all-reduce /
+    broadcast / host all-gather semantics, then the striped eigensolve issuing its own collectives (no Python callback in the
+    Lanczos loop) against the one-rank solve (energy 1e-10 relative, eigenvector overlap)."""
+    import sys
+    name = "dmrgx_commtest_%d_%d" % (os.getpid(), world)
+    env = dict(os.environ, PYTHONPATH=ROOT, DMRGX_SHM_MB="64")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "comm_worker.py"), "shm", str(r), str(world), name], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)[-3000:]
+    assert "native %d-rank eigensolve ok" % world in outs[0]
+
+
 def test_rccl_hooks_single_rank():
-    """The RCCL hook implementations bench.py installs for N > 1 (collectives.torch_hooks), on a one-rank nccl group."""
+    """The torch.distributed form of the eigensolver's collective hooks (collectives.torch_hooks: the harness alternative to the
+    native communicator), on a one-rank nccl group."""
     import sys
     script = os.path.join(ROOT, "tests", "nccl_hooks_worker.py")
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29643", PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -255,8 +409,8 @@ def test_rccl_hooks_single_rank():
 
 def test_bench_multi_rank_control_flow_rehearsal():
     """bench.py as the driver launches it for N > 1 (torch.distributed.run, one process per rank), rehearsed with two ranks
-    on the one GPU and host-staged collectives: striped plans, hooks, barrier + max-over-ranks timing, one JSON line from
-    rank 0 with whole-job throughput."""
+    on the one GPU and the host-staged back-end of the native communicator: striped plans, the solver's own collectives, barrier +
+    max-over-ranks timing, one JSON line from rank 0 with whole-job throughput."""
     import sys
     env = dict(os.environ, DMRGX_BENCH_REHEARSAL="1", PYTHONPATH=ROOT)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29651",

@@ -61,6 +61,57 @@ def test_engine_kroneye_matches_reference_table():
     assert n == 120
 
 
+def test_kronblocks_iterator_decodes_rows_like_the_reference():
+    """SURVEY 8a row A2 (reference include/DMRGKron.hpp:501-656): KronBlocksIterator walks superblock rows and decodes
+    (KronBlock, local index, left/right sector, left/right local and global index).  Checked three ways on the blocks of
+    the reference's TestKron01: against the oracle's restatement of the decode (:587-620), against the reference-held
+    expected table (a left-site operator O (x) 1 has out[r, r'] = O[gL(r), gL(r')] delta(gR(r), gR(r')), so the table's
+    column lists follow from the decoded (gL, gR) alone), and for a sub-range [istart, iend) that starts inside a block."""
+    from oracle.block import Block as OBlock
+    from oracle.kron import KronBlocks as OKronBlocks
+    g = json.load(open(os.path.join(GOLD, "testkron01.json")))
+    out = tool(block_lines("L", g["left"]) + block_lines("R", g["right"]) + ["iterate L R 0 -1", "iterate L R 5 11", "iterate L R 0 -1 0.5"])
+    runs, cur = [], None
+    for ln in out:
+        t = ln.split()
+        if t[0] == "iterate":
+            cur = {"range": (int(t[1]), int(t[2])), "rows": []}
+            runs.append(cur)
+        elif t[0] == "it":
+            cur["rows"].append([int(v) for v in t[1:]])
+    full, part, sector = runs
+    def oblock(d):
+        return OBlock.with_sectors(d["nsites"], d["qn_list"], d["qn_size"])
+    L, R = oblock(g["left"]), oblock(g["right"])
+    for run, qn in ((full, ()), (sector, (0.5,))):
+        kb = OKronBlocks(L, R, qn)
+        k, IL, IR, lL, lR, gL, gR = kb.rows()
+        assert run["range"] == (0, kb.NumStates()) and len(run["rows"]) == kb.NumStates() > 0
+        offs = [kb.Offsets(i) for i in range(kb.size() + 1)]
+        for idx, row in enumerate(run["rows"]):
+            assert row[:9] == [idx, k[idx], idx - offs[k[idx]], IL[idx], IR[idx], lL[idx], lR[idx], gL[idx], gR[idx]], idx
+            assert row[9] == int(idx == 0 or k[idx] != k[idx - 1])                              # UpdatedBlock
+            assert row[10] == idx and row[11] == offs[k[idx]]                                   # Steps, BlockStartIdx(0)
+            assert row[12] == (kb.kb[k[idx] + 1][3] if k[idx] + 1 < kb.size() else -1)          # BlockSize(+1), -1 past the end
+    assert part["range"] == (5, 11) and [r[0] for r in part["rows"]] == list(range(5, 11))
+    assert [r[1:9] for r in part["rows"]] == [r[1:9] for r in full["rows"][5:11]] and [r[10] for r in part["rows"]] == list(range(6))
+    # the reference's expected table, re-derived from the decoded indices
+    gLs, gRs = [r[7] for r in full["rows"]], [r[8] for r in full["rows"]]
+    nl, checked = g["left"]["nsites"], 0
+    for opname in ("Sz", "Sp"):
+        for site, rows in g["expected"][opname].items():
+            if int(site) >= nl:
+                continue
+            src = g["left"][opname][site]                                                       # row -> columns (value == column index)
+            for row, exp in rows.items():
+                r = int(row)
+                want = {c: v for c, v in zip(exp["cols"], exp["vals"]) if v != 0.0}
+                got = {rp: float(gLs[rp]) for rp in range(len(gLs)) if gRs[rp] == gRs[r] and gLs[rp] in src.get(str(gLs[r]), []) and gLs[rp] != 0}
+                assert got == want, (opname, site, row)
+                checked += 1
+    assert checked >= 40
+
+
 def test_engine_block_checks_and_planted_error():
     """tests/UnitTests_DMRGBlock.cpp:76-131: valid patterns pass; an entry outside its sector block is refused with
     PETSC_ERR_ARG_OUTOFRANGE (63) -- in the engine at insertion time, since cells cannot hold such an entry."""
