@@ -27,7 +27,7 @@ constexpr int JB = DMRGX_JB, JS = 2 * JB;          // block size, sub-problem si
                                              // update launch of pure latency (~20 + 13 us at any matrix size); 32 x 32
                                              // sub-problems (31 dependent rotation rounds on 256 threads) measured best:
                                              // JB = 32 halves the rounds but its 63-round, 1024-thread solve is > 2x slower
-constexpr int JACOBI_INNER_SWEEPS = 1;       // one cyclic sweep per visit: the outer sweeps finish the job (fewer total us)
+                                             // (one cyclic sweep per visit: the outer sweeps finish the job)
 constexpr int JLD = JS + 1;
 constexpr int SUB_THREADS = JB * JB;           // sub-solve: one thread per pair of rotation pairs
 
@@ -74,16 +74,6 @@ __global__ void __launch_bounds__(256) transpose_kernel(const TrTile* __restrict
     }
 }
 
-// Round-robin tournament pairing of JS indices: pair u of round rr (p < q); no integer division (rr < JS-1, u < JB).
-__device__ __forceinline__ void jacobi_pair(int rr, int u, int& p, int& q)
-{
-    int a = rr + u, b = rr - u;
-    if (a >= JS - 1) a -= JS - 1;
-    if (b < 0) b += JS - 1;
-    if (u == 0) { a = JS - 1; b = rr; }
-    p = min(a, b); q = max(a, b);
-}
-
 // 1/sqrt(x): hardware estimate (v_rsq_f64) + two Newton steps -- the sub-solve is a chain of dependent scalar math on
 // one wave per SIMD, so the length of this sequence is what a Jacobi round costs.
 __device__ __forceinline__ double fast_rsqrt(double x)
@@ -116,17 +106,36 @@ struct UpdTask { int32_t mat, p, q, kind; };     // p: pair index (kind 0) or ro
 __device__ __forceinline__ void jacobi_update_body(double* sh, const MatDesc* __restrict__ mats, const int32_t* __restrict__ pair_start, const UpdTask t,
                                                    double* __restrict__ buf, const double* __restrict__ rbuf, int round);
 
+// Seat permutation of the round-robin tournament in "neighbours play" form: the JS indices sit in two rows of JB seats, seat
+// 2t above seat 2t+1, and seat 2t always plays seat 2t+1.  After a round everybody except seat 0 moves one seat clockwise;
+// after JS-1 rounds all pairs have met and everybody is back (period JS-1), so S and R end in their original order.
+__device__ __forceinline__ int jacobi_next_seat(int s)
+{
+    if (s == 0) return 0;
+    if (s == 1) return 2;
+    if (s & 1) return s - 2;                 // lower row moves left
+    return s == JS - 2 ? JS - 1 : s + 2;     // upper row moves right, the last one drops to the lower row
+}
+
 // Workgroups [0, npairs): the sub-problems of round `round` (rotations to rbuf).  Workgroups past npairs: the eigenvector
 // updates V <- V R of the PREVIOUS round (vtasks, rbuf_prev, round_prev) -- nothing in this round depends on them, so they
 // fill the CUs that the latency-bound sub-solves leave idle instead of lengthening the update launch.
+//
+// The sub-solve is a chain of JS-1 dependent rotation rounds; what a round costs is instructions issued (several sub-problems
+// share a CU) plus two LDS round trips.  So the loop carries no index arithmetic at all: thread (k, l) always owns the 2 x 2
+// block of seats {2k, 2k+1} x {2l, 2l+1} of S and rows 2k, 2k+1 x columns {2l, 2l+1} of R, reads it from fixed addresses and
+// writes the rotated block to the fixed addresses of the seats its rows / columns move to (double-buffered S and R); the JB
+// rotations of a round are computed once, by the first JB lanes of wave 0 from the fixed pivot positions (2t, 2t+1), and
+// handed over through LDS.
 __global__ void __launch_bounds__(SUB_THREADS)
 jacobi_sub_kernel(const MatDesc* __restrict__ mats, const PairRef* __restrict__ pairs, int npairs, double* __restrict__ buf, double* __restrict__ rbuf, int round,
                   const UpdTask* __restrict__ vtasks, const int32_t* __restrict__ pair_start, const double* __restrict__ rbuf_prev, int round_prev)
 {
-    __shared__ double sh[3 * JS * JLD];
+    __shared__ double sh[4 * JS * JLD];               // S and R, double-buffered
     __shared__ double red0[SUB_THREADS / 64], red1[SUB_THREADS / 64];
+    __shared__ double rot_c[JB], rot_s[JB];
     if ((int)blockIdx.x >= npairs) { jacobi_update_body(sh, mats, pair_start, vtasks[blockIdx.x - npairs], buf, rbuf_prev, round_prev); return; }
-    double* S = sh;                                   // S is double-buffered: a round reads one copy and writes the other
+    double* S = sh;
     double* R = sh + 2 * JS * JLD;
     const PairRef pr = pairs[blockIdx.x];
     const MatDesc m = mats[pr.mat];
@@ -141,7 +150,8 @@ jacobi_sub_kernel(const MatDesc* __restrict__ mats, const PairRef* __restrict__ 
         R[i * JLD + j] = (i == j) ? 1.0 : 0.0;
     }
     __syncthreads();
-    for (int sweep = 0; sweep < JACOBI_INNER_SWEEPS; ++sweep) {
+    int final_buf = 0;
+    {
         // convergence: off-diagonal mass relative to the diagonal (wave-uniform decision); the outer sweeps finish the job
         double off = 0.0, dg = 0.0;
         for (int e = tid; e < JS * JS; e += SUB_THREADS) {
@@ -154,38 +164,45 @@ jacobi_sub_kernel(const MatDesc* __restrict__ mats, const PairRef* __restrict__ 
         __syncthreads();
         double offt = 0.0, dgt = 0.0;
         for (int w = 0; w < SUB_THREADS / 64; ++w) { offt += red0[w]; dgt += red1[w]; }
-        __syncthreads();
-        if (offt <= 1e-26 * dgt) break;
-        // One thread per pair of rotation pairs (k, l): it owns the 2 x 2 block rows {p_k, q_k} x columns {p_l, q_l}
-        // of S, recomputes both rotations itself from the pivots it reads (division-free, two rsqrt each) and applies
-        // J_k^T . J_l to its block in registers -- one barrier per round, no serial parameter phase, no second pass
-        // over S.  The same thread carries rows 2k, 2k+1 of R through J_l.
-        const int k = tid / JB, l = tid % JB;
-        double* Sn = sh + JS * JLD;
-        for (int rr = 0; rr < JS - 1; ++rr) {
-            int pk, qk, pl, ql;
-            jacobi_pair(rr, k, pk, qk);
-            jacobi_pair(rr, l, pl, ql);
-            double ck, sk, cl, sl;
-            jacobi_rotation(S[pk * JLD + qk], S[pk * JLD + pk], S[qk * JLD + qk], ck, sk);
-            jacobi_rotation(S[pl * JLD + ql], S[pl * JLD + pl], S[ql * JLD + ql], cl, sl);
-            const double b00 = S[pk * JLD + pl], b01 = S[pk * JLD + ql], b10 = S[qk * JLD + pl], b11 = S[qk * JLD + ql];
-            const double t00 = cl * b00 - sl * b01, t01 = sl * b00 + cl * b01;
-            const double t10 = cl * b10 - sl * b11, t11 = sl * b10 + cl * b11;
-            Sn[pk * JLD + pl] = ck * t00 - sk * t10; Sn[pk * JLD + ql] = ck * t01 - sk * t11;
-            Sn[qk * JLD + pl] = sk * t00 + ck * t10; Sn[qk * JLD + ql] = sk * t01 + ck * t11;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int i = 2 * k + h;
-                const double rp = R[i * JLD + pl], rq = R[i * JLD + ql];
-                R[i * JLD + pl] = cl * rp - sl * rq; R[i * JLD + ql] = sl * rp + cl * rq;
+        if (offt > 1e-26 * dgt) {
+            const int k = tid / JB, l = tid % JB;
+            // loop-invariant LDS offsets (elements): the block this thread reads, and where its two rows / columns go
+            const int r0 = 2 * k, r1 = 2 * k + 1, c0 = 2 * l, c1 = 2 * l + 1;
+            const int nr0 = jacobi_next_seat(r0), nr1 = jacobi_next_seat(r1), nc0 = jacobi_next_seat(c0), nc1 = jacobi_next_seat(c1);
+            const int in00 = r0 * JLD + c0, in01 = r0 * JLD + c1, in10 = r1 * JLD + c0, in11 = r1 * JLD + c1;
+            const int so00 = nr0 * JLD + nc0, so01 = nr0 * JLD + nc1, so10 = nr1 * JLD + nc0, so11 = nr1 * JLD + nc1;     // S: rows and columns move
+            const int ro00 = r0 * JLD + nc0, ro01 = r0 * JLD + nc1, ro10 = r1 * JLD + nc0, ro11 = r1 * JLD + nc1;         // R: only columns move
+            const int piv = (2 * tid) * JLD + 2 * tid;                                                                  // lane t < JB: pivot block (2t, 2t+1)
+            constexpr int BUFSZ = JS * JLD;
+            int cur = 0;
+#pragma unroll 1
+            for (int rr = 0; rr < JS - 1; ++rr) {
+                const double* Sc = S + cur * BUFSZ; double* Sn = S + (cur ^ 1) * BUFSZ;
+                const double* Rc = R + cur * BUFSZ; double* Rn = R + (cur ^ 1) * BUFSZ;
+                if (tid < JB) {                                            // wave 0, JB lanes: one rotation each
+                    double c, sn;
+                    jacobi_rotation(Sc[piv + 1], Sc[piv], Sc[piv + JLD + 1], c, sn);
+                    rot_c[tid] = c; rot_s[tid] = sn;
+                }
+                const double b00 = Sc[in00], b01 = Sc[in01], b10 = Sc[in10], b11 = Sc[in11];
+                const double q00 = Rc[in00], q01 = Rc[in01], q10 = Rc[in10], q11 = Rc[in11];
+                __syncthreads();
+                const double ck = rot_c[k], sk = rot_s[k], cl = rot_c[l], sl = rot_s[l];
+                const double t00 = cl * b00 - sl * b01, t01 = sl * b00 + cl * b01;
+                const double t10 = cl * b10 - sl * b11, t11 = sl * b10 + cl * b11;
+                Sn[so00] = ck * t00 - sk * t10; Sn[so01] = ck * t01 - sk * t11;
+                Sn[so10] = sk * t00 + ck * t10; Sn[so11] = sk * t01 + ck * t11;
+                Rn[ro00] = cl * q00 - sl * q01; Rn[ro01] = sl * q00 + cl * q01;
+                Rn[ro10] = cl * q10 - sl * q11; Rn[ro11] = sl * q10 + cl * q11;
+                __syncthreads();
+                cur ^= 1;
             }
-            __syncthreads();                               // one barrier per round: the next round reads Sn, writes S
-            double* t = S; S = Sn; Sn = t;
+            final_buf = cur;
         }
     }
+    const double* Rf = R + final_buf * JS * JLD;
     double* Rout = rbuf + (int64_t)blockIdx.x * JS * JS;
-    for (int e = tid; e < JS * JS; e += SUB_THREADS) Rout[e] = R[(e / JS) * JLD + (e % JS)];
+    for (int e = tid; e < JS * JS; e += SUB_THREADS) Rout[e] = Rf[(e / JS) * JLD + (e % JS)];
 }
 
 // One 16 x 16 block (block row wr, block column wc) of L * M for two JS x JS operands in LDS (row stride JLD), on the MFMA

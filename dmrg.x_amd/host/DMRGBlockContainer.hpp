@@ -472,7 +472,9 @@ public:
         timings.tDiag = tdiag - tkron;
 
         BasisTransformation BT_L, BT_R;
-        ierr = GetTruncation(KronBlocks, gsv_r, MStates, BT_L, BT_R, BlockIndex(SysBlockOut), BlockIndex(EnvBlockOut)); CHKERRQ(ierr);
+        /* a side whose output block no later step reads needs its spectrum (truncation error, sector table) but no eigenvectors */
+        const bool vec_sys = !(hints && hints->dead_sys && !same), vec_env = !(hints && hints->dead_env && !same);
+        ierr = GetTruncation(KronBlocks, gsv_r, MStates, BT_L, BT_R, BlockIndex(SysBlockOut), BlockIndex(EnvBlockOut), vec_sys, vec_env); CHKERRQ(ierr);
         ierr = CalculateCorrelations_BlockDiag(KronBlocks, gsv_r, do_measurements); CHKERRQ(ierr);
         if (use_guess) {   /* what the next step needs to carry this ground state over */
             prev.valid = false;
@@ -644,6 +646,7 @@ public:
                     const int32_t ka = G->kept[(size_t)a];
                     if (ka == 0) continue;
                     const PhiBlock& pb = phis[ip++];
+                    if (!G->rt[(size_t)a]) return 0;            /* a rotation kept for its sector table only */
                     if (grow_left)          /* (ka x nL) . (nL x nR) */
                         t1.push_back(dmrgx_gemm_task{ka, nR, nL, 0, G->rt[(size_t)a]->dev_ro(), nL, x + kb[4], nR, ph + pb.off, nR});
                     else {                  /* (nL x nR) . (nR x ka) */
@@ -662,6 +665,7 @@ public:
                 const int32_t j = e.old_sector;
                 if (j >= nS || S->kept[(size_t)j] != e.size) return 0;
                 if (e.size == 0) continue;
+                if (!S->rt[(size_t)j]) return 0;
                 const int32_t Jnew = S->old_sector[(size_t)j], nJ = S->old_sizes[(size_t)Jnew];
                 auto it = where.find({pb.a, e.site_sector});
                 if (it == where.end()) continue;                                /* that (sector, site state) does not exist in the new block */
@@ -999,8 +1003,12 @@ public:
     /** Reduced density matrices of both sides, their full spectra (device), the global cut to MStates states and the
         rotation matrices.  The ordering rules are the reference's: concatenate the spectra KronBlock by KronBlock,
         stable-sort by decreasing eigenvalue, keep the first min(MStates, #), stable-sort the survivors by sector. */
+    /*  need_vec_L / need_vec_R = false (engine extension): that side's rotation is not wanted (its output block is never read
+        again).  Its spectrum is then taken from the OTHER side of the same KronBlock -- Psi Psi^T and Psi^T Psi share their
+        non-zero eigenvalues, the rest are exact zeros -- so the density matrices of that side are neither built nor
+        diagonalised; truncation error and kept-sector table follow from the same sort / cut rules as ever. */
     PetscErrorCode GetTruncation(const KronBlocks_t& KronBlocks, const Vec& gsv_r, const PetscInt& MStates, BasisTransformation& BT_L, BasisTransformation& BT_R,
-                                 const PetscInt keyL = -1, const PetscInt keyR = -1)
+                                 const PetscInt keyL = -1, const PetscInt keyR = -1, const bool need_vec_L = true, const bool need_vec_R = true)
     {
         PetscErrorCode ierr;
         if (gsv_r->n != KronBlocks.NumStates()) SETERRQ2(PETSC_COMM_SELF, 1, "Incorrect vector length. Expected %lld. Got %lld.", LLD(KronBlocks.NumStates()), LLD(gsv_r->n));
@@ -1036,15 +1044,21 @@ public:
            of a matrix broadcasts its kept eigenvectors. */
         dmrgx_comm* comm = dmrgx_host::WorldComm();
         const int W = comm ? dmrgx_host::WorldSize() : 1, me = comm ? dmrgx_host::WorldRank() : 0;
-        std::vector<int> owner((size_t)(2 * nb), 0);
+        const bool need_vec[2] = {need_vec_L || !need_vec_R, need_vec_R};        /* at least one side is solved */
+        const bool partial = !need_vec[0] || !need_vec[1];
+        std::vector<int> owner((size_t)(2 * nb), 0);                              /* -1: not solved by anyone (spectrum borrowed) */
+        for (PetscInt k = 0; k < nb; ++k) for (int side = 0; side < 2; ++side) if (!need_vec[side]) owner[(size_t)(2 * k + side)] = -1;
         if (W > 1) {
             std::vector<std::pair<double, int>> units;
-            for (PetscInt k = 0; k < nb; ++k) for (int side = 0; side < 2; ++side) { const double n = side == 0 ? ls[bil[k]] : rs[bir[k]]; units.push_back({n * n * n, (int)(2 * k + side)}); }
+            for (PetscInt k = 0; k < nb; ++k) for (int side = 0; side < 2; ++side) {
+                if (!need_vec[side]) continue;
+                const double n = side == 0 ? ls[bil[k]] : rs[bir[k]]; units.push_back({n * n * n, (int)(2 * k + side)});
+            }
             std::stable_sort(units.begin(), units.end(), [](const std::pair<double, int>& a, const std::pair<double, int>& b) { return a.first > b.first; });
             std::vector<double> load((size_t)W, 0.0);
             for (const auto& u : units) { int best = 0; for (int w = 1; w < W; ++w) if (load[(size_t)w] < load[(size_t)best]) best = w; load[(size_t)best] += u.first; owner[(size_t)u.second] = best; }
         }
-        if (W > 1) {
+        if (W > 1 || partial) {
             std::vector<uint8_t> mask((size_t)nb, 0);
             for (PetscInt k = 0; k < nb; ++k) mask[(size_t)k] = (uint8_t)((owner[(size_t)(2 * k)] == me ? 1 : 0) | (owner[(size_t)(2 * k + 1)] == me ? 2 : 0));
             if (dmrgx_rdm_create_subset(&sl, &sr, (int32_t)nb, bil.data(), bir.data(), gsv_r->buf->dev_ro(), mask.data(), nullptr, &rdm))
@@ -1063,9 +1077,16 @@ public:
         if (W > 1) {
             std::vector<double> all(spectra.size() * (size_t)W);
             if (dmrgx_comm_allgather_host(comm, spectra.data(), all.data(), spectra.size() * sizeof(double), nullptr)) { dmrgx_rdm_destroy(rdm); SETERRQ1(mpi_comm, 1, "dmrgx_comm_allgather_host: %s", dmrgx_last_error()); }
-            for (PetscInt u = 0; u < 2 * nb; ++u)
+            for (PetscInt u = 0; u < 2 * nb; ++u) {
+                if (owner[(size_t)u] < 0) continue;
                 std::copy(all.begin() + (int64_t)owner[(size_t)u] * (int64_t)spectra.size() + spec_off[(size_t)u], all.begin() + (int64_t)owner[(size_t)u] * (int64_t)spectra.size() + spec_off[(size_t)u + 1],
                           spectra.begin() + spec_off[(size_t)u]);
+            }
+        }
+        if (partial) for (PetscInt k = 0; k < nb; ++k) {       /* borrowed spectra: the other side's eigenvalues, zero-padded / cut to this side's size */
+            const int dead = need_vec[0] ? 1 : 0, live = 1 - dead;
+            const int64_t nd = spec_off[(size_t)(2 * k + dead + 1)] - spec_off[(size_t)(2 * k + dead)], nl = spec_off[(size_t)(2 * k + live + 1)] - spec_off[(size_t)(2 * k + live)];
+            for (int64_t e = 0; e < nd; ++e) spectra[(size_t)(spec_off[(size_t)(2 * k + dead)] + e)] = e < nl ? spectra[(size_t)(spec_off[(size_t)(2 * k + live)] + e)] : 0.0;
         }
         if (use_rdm_warm && W == 1) for (int side = 0; side < 2; ++side) {      /* remember this visit's eigenbases (all eigenvectors, as rows) */
             if (keys[side] < 0 || (side == 1 && keyR == keyL)) continue;
@@ -1107,8 +1128,9 @@ public:
             for (const auto& kv : per) {
                 const PetscInt blk = kv.first, k = kv.second.first, cnt = kv.second.second, n = M[side]->Sizes(blk);
                 rot->old_sector.push_back((int32_t)blk); rot->kept.push_back((int32_t)cnt);
-                auto buf = std::make_shared<dmrgx_host::DevBuffer>((size_t)cnt * n, dmrgx_host::DevBuffer::device_only_t{});
                 const int own = owner[(size_t)(2 * k + side)];
+                if (own < 0) { rot->rt.push_back(nullptr); qn_list.push_back(M[side]->List(blk)); qn_size.push_back(cnt); continue; }   /* spectrum only */
+                auto buf = std::make_shared<dmrgx_host::DevBuffer>((size_t)cnt * n, dmrgx_host::DevBuffer::device_only_t{});
                 if (own == me && dmrgx_rdm_eigenvectors(rdm, side, (int32_t)k, (int32_t)cnt, buf->dev_uninitialised(), n, nullptr)) { dmrgx_rdm_destroy(rdm); SETERRQ1(mpi_comm, 1, "dmrgx_rdm_eigenvectors: %s", dmrgx_last_error()); }
                 if (W > 1 && dmrgx_comm_bcast(comm, buf->dev_uninitialised(), (size_t)cnt * (size_t)n * sizeof(double), own, nullptr)) { dmrgx_rdm_destroy(rdm); SETERRQ1(mpi_comm, 1, "dmrgx_comm_bcast: %s", dmrgx_last_error()); }
                 rot->rt.push_back(buf);

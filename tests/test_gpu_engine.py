@@ -210,17 +210,32 @@ def test_multi_rank_engine_sweep_reproduces_the_single_rank_run(tmp_path):
     assert len(c1["values"]) == len(c3["values"]) == 2
 
 
-def test_pruned_and_unpruned_operator_sets_give_identical_steps(tmp_path):
-    """-prune_ops 0 rotates and keeps every Sz(i)/Sp(i) of every block, as the reference does; the default keeps the sites a
-    later inter-block term or a registered correlator can touch and skips the blocks no later step reads.  Every row of
-    DMRGSteps.json and every correlator value must be identical, bit for bit (J1-J2 6x4, m = 48, truncating)."""
-    model = ["-Lx", 6, "-Ly", 4, "-J1", 1, "-Jz1", 1, "-J2", 0.5, "-Jz2", 0.5, "-mwarmup", 48, "-nsweeps", 2]
-    ra, _, ta = run_engine(tmp_path / "a", *model)
-    rb, _, tb = run_engine(tmp_path / "b", *model, "-prune_ops", 0)
-    assert ra == rb and len(ra) == 8 + 2 * 20
+def test_pruned_and_unpruned_operator_sets_agree(tmp_path):
+    """-prune_ops 0 rotates and keeps every Sz(i)/Sp(i) of every block and diagonalises both density matrices of every KronBlock,
+    as the reference does; the default keeps the sites a later inter-block term or a registered correlator can touch, does not
+    rotate the blocks no later step reads and takes their spectrum from the other side of the KronBlock.  On a parity case with
+    well-defined cuts (4x4 J1-J2, Sz = 1, m = 4; pinned to the oracle above in the default mode) every step agrees at the
+    north-star tolerance; on a larger run (6x4, m = 48, where edge steps keep numerically-zero states picked by rounding noise)
+    energies agree at the truncation-error scale and the rotation work drops."""
+    small = ["-Lx", 4, "-Ly", 4, "-J1", 1, "-Jz1", 1, "-J2", 0.5, "-Jz2", 0.5, "-qn_sector", 1, "-mwarmup", 4, "-nsweeps", 2, "-H_eps_tol", 1e-13]
+    ra, _, _ = run_engine(tmp_path / "a", *small)
+    rb, _, _ = run_engine(tmp_path / "b", *small, "-prune_ops", 0)
+    assert len(ra) == len(rb) == 4 + 2 * 12
+    for a, b in zip(ra, rb):
+        assert {k: v for k, v in a.items() if k not in ("TruncErr_Sys", "TruncErr_Env", "GSEnergy")} == {k: v for k, v in b.items() if k not in ("TruncErr_Sys", "TruncErr_Env", "GSEnergy")}
+        assert abs(a["GSEnergy"] - b["GSEnergy"]) <= 1e-10 * abs(b["GSEnergy"])
+        for k in ("TruncErr_Sys", "TruncErr_Env"):
+            assert abs(a[k] - b[k]) <= 1e-10 * abs(b[k]) + 1e-13, (a["GlobIdx"], k, a[k], b[k])
     ca, cb = (json.load(open(str(tmp_path / d) + "/Correlations.json")) for d in ("a", "b"))
-    assert ca["values"] == cb["values"] and len(ca["values"]) == 3
-    assert max(r["TruncErr_Sys"] for r in ra) > 1e-8
+    assert np.abs(np.array(ca["values"]) - np.array(cb["values"])).max() <= 1e-10
+    model = ["-Lx", 6, "-Ly", 4, "-J1", 1, "-Jz1", 1, "-J2", 0.5, "-Jz2", 0.5, "-mwarmup", 48, "-nsweeps", 2]
+    rc, _, tc = run_engine(tmp_path / "c", *model)
+    rd, _, td = run_engine(tmp_path / "d", *model, "-prune_ops", 0)
+    assert len(rc) == len(rd) == 8 + 2 * 20
+    trunc = max(r["TruncErr_Sys"] for r in rd)
+    assert trunc > 1e-8
+    for a, b in zip(rc, rd):
+        assert abs(a["GSEnergy"] - b["GSEnergy"]) <= 10.0 * trunc * abs(b["GSEnergy"]), (a["GlobIdx"], a["GSEnergy"], b["GSEnergy"])
 
 
 def test_correlators_match_exact_diagonalisation(tmp_path):
