@@ -118,6 +118,7 @@ SIGNATURES = {
     "dmrgx_rotate_ops": (C.c_int32, [C.POINTER(Sectors), C.POINTER(Rotation), C.c_int32, C.POINTER(SecOp), C.POINTER(C.POINTER(C.c_void_p)), C.c_void_p]),
     "dmrgx_malloc": (C.c_int32, [C.POINTER(C.c_void_p), C.c_size_t]),
     "dmrgx_free": (C.c_int32, [C.c_void_p]),
+    "dmrgx_mem_stats": (C.c_int32, [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "dmrgx_memcpy_h2d": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "dmrgx_memcpy_d2h": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "dmrgx_memcpy_d2d": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

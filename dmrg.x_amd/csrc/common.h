@@ -41,6 +41,7 @@ inline int32_t stripe_cut(int32_t n, int32_t W, int32_t w) { return (int32_t)(((
 hipError_t pool_malloc(void** out, size_t bytes);
 hipError_t pool_free(void* p);
 hipError_t zero_async(void* p, size_t bytes, hipStream_t st);
+void pool_stats(size_t* in_use, size_t* cached, size_t* peak);
 hipError_t h2d_async(void* dst, const void* src, size_t bytes, hipStream_t st);   // pinned-ring staged, never blocks on the copy
 
 // RAII device buffer owned by a plan.

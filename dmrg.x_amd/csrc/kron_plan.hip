@@ -248,7 +248,11 @@ struct Builder {
             total += (double)ksteps(g) * ((G.M + GG_BM - 1) / GG_BM) * ((G.N + GG_BN - 1) / GG_BN);
         }
         static const double units = getenv("DMRGX_SPLIT_UNITS") ? atof(getenv("DMRGX_SPLIT_UNITS")) : 8192.0;
-        static const double min_seg = getenv("DMRGX_SPLIT_MIN") ? atof(getenv("DMRGX_SPLIT_MIN")) : 16.0;
+        // Shortest segment worth its 32 KB slab: 16 k-steps when the launch has work for every workgroup slot anyway; a small
+        // superblock (m <= 512: a few thousand tile-k-steps in all) is latency-bound by its longest segment instead, so the
+        // floor drops until about 1024 units exist (4 k-steps at least).
+        static const double min_seg_env = getenv("DMRGX_SPLIT_MIN") ? atof(getenv("DMRGX_SPLIT_MIN")) : 0.0;
+        const double min_seg = min_seg_env > 0.0 ? min_seg_env : std::min(16.0, std::max(4.0, total / 1024.0));
         const double seg_target = std::max(total / units, min_seg);
         static const int taper = getenv("DMRGX_SPLIT_TAPER") ? atoi(getenv("DMRGX_SPLIT_TAPER")) : 0;
         const size_t ng = stage2_groups.size();

@@ -103,6 +103,11 @@ extern "C" dmrgx_status dmrgx_malloc(void** p, size_t bytes)
     if (e != hipSuccess) { *p = nullptr; DMRGX_FAIL(DMRGX_ERR_MEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e)); }
     return DMRGX_OK;
 }
+extern "C" dmrgx_status dmrgx_mem_stats(size_t* in_use, size_t* cached, size_t* peak_in_use)
+{
+    dmrgx::pool_stats(in_use, cached, peak_in_use);
+    return DMRGX_OK;
+}
 extern "C" dmrgx_status dmrgx_free(void* p) { if (p) DMRGX_HIP(dmrgx::pool_free(p)); return DMRGX_OK; }
 extern "C" dmrgx_status dmrgx_memcpy_h2d(void* d, const void* s, size_t n, void* st)
 { if (n) DMRGX_HIP(dmrgx::h2d_async(d, s, n, (hipStream_t)st)); return DMRGX_OK; }

@@ -24,6 +24,7 @@ struct Pool {
     std::unordered_map<void*, uint64_t> freed_at;    // cached blocks: value of `clock` when they came back (LRU order of the trim)
     uint64_t clock = 0;
     size_t cached = 0;
+    size_t in_use = 0, peak_in_use = 0;              // bytes handed out (by size class) now / at most so far
     const bool enabled = !(getenv("DMRGX_POOL") && atoi(getenv("DMRGX_POOL")) == 0);
     const size_t cache_limit = (size_t)(getenv("DMRGX_POOL_LIMIT_GB") ? atof(getenv("DMRGX_POOL_LIMIT_GB")) : 64.0) << 30;
 
@@ -84,6 +85,7 @@ hipError_t pool_malloc(void** out, size_t bytes)
         it->second.pop_back();
         P.cached -= it->first;
         P.freed_at.erase(*out);
+        P.in_use += it->first; P.peak_in_use = std::max(P.peak_in_use, P.in_use);
         return hipSuccess;
     }
     static const bool trace = getenv("DMRGX_POOL_TRACE") != nullptr;     // developer aid: driver allocations that miss the cache
@@ -96,7 +98,7 @@ hipError_t pool_malloc(void** out, size_t bytes)
         P.trim_locked(0);
         e = hipMalloc(out, c);
     }
-    if (e == hipSuccess) P.size_of[*out] = c;
+    if (e == hipSuccess) { P.size_of[*out] = c; P.in_use += c; P.peak_in_use = std::max(P.peak_in_use, P.in_use); }
     else *out = nullptr;
     return e;
 }
@@ -112,6 +114,7 @@ hipError_t pool_free(void* p)
     P.free_by_size[it->second].push_back(p);
     P.freed_at[p] = ++P.clock;
     P.cached += it->second;
+    P.in_use -= std::min(P.in_use, it->second);
     if (P.cached > P.cache_limit) P.trim_locked(P.cache_limit / 4 * 3);
     return hipSuccess;
 }
@@ -166,6 +169,15 @@ hipError_t h2d_async(void* dst, const void* src, size_t bytes, hipStream_t st)
     // large or unstaged: the source must outlive the copy and the callers drop it on return
     hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st);
     return e != hipSuccess ? e : hipStreamSynchronize(st);
+}
+
+void pool_stats(size_t* in_use, size_t* cached, size_t* peak)
+{
+    Pool& P = pool();
+    std::lock_guard<std::mutex> lock(P.mu);
+    if (in_use) *in_use = P.in_use;
+    if (cached) *cached = P.cached;
+    if (peak) *peak = P.peak_in_use;
 }
 
 hipError_t zero_async(void* p, size_t bytes, hipStream_t st)

@@ -414,6 +414,43 @@ public:
             SzData[i] = nullptr; SpData[i] = nullptr;         /* cells are shared_ptr views: the buffers go when the last view goes */
             if (init_Sm) SmData[i] = nullptr;
         }
+        return CompactStorage();
+    }
+    /** The rotated operators of a block are views of ONE device arena (RotateOperators): dropping some of them frees nothing
+        while the others keep the arena alive.  When less than 3/4 of the referenced storage is still in use, the surviving dense
+        cells are copied into a new arena of exactly their size (one batched device copy) and the old one is released. */
+    PetscErrorCode CompactStorage()
+    {
+        std::vector<Mat> live;
+        for (PetscInt i = 0; i < num_sites; ++i) { if (SzData[i]) live.push_back(SzData[i]); if (SpData[i]) live.push_back(SpData[i]); }
+        if (H) live.push_back(H);
+        std::map<dmrgx_host::DevBuffer*, size_t> arena_size;
+        size_t used = 0;
+        for (const Mat& m : live)
+            for (const dmrgx_host::MatCell& c : m->cells)
+                if (c.kind == DMRGX_CELL_DENSE && c.buf) { arena_size[c.buf.get()] = c.buf->size(); used += (size_t)c.nr * (size_t)c.nc; }
+        size_t held = 0;
+        for (const auto& kv : arena_size) held += kv.second;
+        if (held == 0 || used * 4 >= held * 3 || held * sizeof(double) < ((size_t)1 << 20)) return 0;
+        std::shared_ptr<dmrgx_host::DevBuffer> arena;
+        try { arena = std::make_shared<dmrgx_host::DevBuffer>(used, dmrgx_host::DevBuffer::device_only_t{}); }
+        catch (const std::exception& e) { SETERRQ1(mpi_comm, PETSC_ERR_MEM, "operator storage: %s", e.what()); }
+        double* base = arena->dev_uninitialised();
+        if (dmrgx_memset_zero(base, used * sizeof(double), nullptr)) SETERRQ1(mpi_comm, 1, "%s", dmrgx_last_error());
+        std::vector<dmrgx_axpy_task> tasks;
+        std::vector<std::shared_ptr<dmrgx_host::DevBuffer>> old;         /* released when this function returns (stream-ordered pool) */
+        size_t cursor = 0;
+        for (const Mat& m : live)
+            for (dmrgx_host::MatCell& c : m->cells) {
+                if (c.kind != DMRGX_CELL_DENSE || !c.buf) continue;
+                dmrgx_axpy_task t;
+                t.dst = base + cursor; t.dst_base = nullptr; t.src = c.buf->dev_ro() + c.off; t.ldd = c.nc; t.lds = c.ld; t.nr = c.nr; t.nc = c.nc; t.transposed = 0; t.alpha = 1.0;
+                tasks.push_back(t);
+                old.push_back(c.buf);
+                c.buf = arena; c.off = (int64_t)cursor; c.ld = c.nc;
+                cursor += (size_t)c.nr * (size_t)c.nc;
+            }
+        if (!tasks.empty() && dmrgx_cells_axpy((int32_t)tasks.size(), tasks.data(), nullptr)) SETERRQ1(mpi_comm, 1, "dmrgx_cells_axpy: %s", dmrgx_last_error());
         return 0;
     }
     PetscInt NumResidentSites() const { PetscInt n = 0; for (PetscInt i = 0; i < num_sites; ++i) n += (SzData[i] && SpData[i]); return n; }

@@ -339,6 +339,7 @@ public:
         if (!mpi_rank) printf("SWEEP DONE  steps=%lld  time=%.6f s  sites/s=%.3f  MatMults=%lld  E=%.12g\n", LLD(GlobIdx - steps0), ts1 - ts0,
                               (GlobIdx - steps0) / (ts1 - ts0), LLD(total_matmults - mm0), gse);
         last_sweep_seconds = ts1 - ts0; last_sweep_steps = GlobIdx - steps0; last_sweep_matmults = total_matmults - mm0;
+        dmrgx_mem_stats(&device_bytes_after_sweep, nullptr, nullptr);      /* what stays resident between sweeps: the stored blocks */
         ierr = SaveSweepsData(); CHKERRQ(ierr);
         ++LoopIdx;
         return 0;
@@ -360,8 +361,11 @@ public:
         if (fp_data) {
             fprintf(fp_data, ",\n  \"Sweeps\": [");
             for (size_t i = 0; i < sweeps_mstates.size(); ++i) fprintf(fp_data, "%s%lld", i ? ", " : "", LLD(sweeps_mstates[i]));
-            fprintf(fp_data, "],\n  \"GSEnergy\": %.16g,\n  \"MatMults\": %lld,\n  \"LastSweepSeconds\": %.9g,\n  \"LastSweepSteps\": %lld,\n  \"LastSweepMatMults\": %lld,\n  \"EigensolveSeconds\": %.9g\n}\n",
-                    gse, LLD(total_matmults), last_sweep_seconds, LLD(last_sweep_steps), LLD(last_sweep_matmults), total_eigs_seconds);
+            size_t in_use = 0, cached = 0, peak = 0;
+            dmrgx_mem_stats(&in_use, &cached, &peak);
+            fprintf(fp_data, "],\n  \"GSEnergy\": %.16g,\n  \"MatMults\": %lld,\n  \"LastSweepSeconds\": %.9g,\n  \"LastSweepSteps\": %lld,\n  \"LastSweepMatMults\": %lld,\n  \"EigensolveSeconds\": %.9g,\n"
+                             "  \"DeviceBytesResidentAfterSweep\": %zu,\n  \"DeviceBytesPeak\": %zu,\n  \"DeviceBytesCached\": %zu,\n  \"Ranks\": %d\n}\n",
+                    gse, LLD(total_matmults), last_sweep_seconds, LLD(last_sweep_steps), LLD(last_sweep_matmults), total_eigs_seconds, device_bytes_after_sweep, peak, cached, (int)mpi_size);
             fclose(fp_data); fp_data = NULL;
         }
         init = PETSC_FALSE;
@@ -1315,6 +1319,7 @@ private:
     PetscLogDouble t0abs = 0.0;
     PetscInt total_matmults = 0, last_sweep_steps = 0, last_sweep_matmults = 0;
     double total_eigs_seconds = 0.0, last_sweep_seconds = 0.0;
+    size_t device_bytes_after_sweep = 0;
     struct Correlator {
         PetscInt idx = 0;
         std::vector<Op> SysOps, EnvOps;     /**< operators on the (enlarged) system / environment block, block-local site index */

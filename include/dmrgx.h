@@ -291,6 +291,9 @@ dmrgx_status dmrgx_rotate_ops(const dmrgx_sectors* old_sectors, const dmrgx_rota
  * between (the engine and the Python wrappers use a single stream).  DMRGX_POOL=0 makes every free a plain hipFree. */
 dmrgx_status dmrgx_malloc(void** dev_ptr, size_t bytes);
 dmrgx_status dmrgx_free(void* dev_ptr);
+/* device bytes handed out by the pool now, cached for reuse, and the high-water mark of the first (what the reference's
+ * disk spill bounds: src/DMRGBlock.cpp:1090-1103); any pointer may be NULL */
+dmrgx_status dmrgx_mem_stats(size_t* in_use, size_t* cached, size_t* peak_in_use);
 dmrgx_status dmrgx_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes, void* stream);
 dmrgx_status dmrgx_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes, void* stream);   /* synchronises the stream */
 dmrgx_status dmrgx_memcpy_d2d(void* dst_dev, const void* src_dev, size_t bytes, void* stream);
