@@ -35,7 +35,21 @@ void set_error(const char* fmt, ...);
     } while (0)
 
 // Stripe rule of the multi-GPU layout: rank w owns columns [stripe_cut(n,W,w), stripe_cut(n,W,w+1)) of a KronBlock.
-inline int32_t stripe_cut(int32_t n, int32_t W, int32_t w) { return (int32_t)(((int64_t)n * w) / W); }
+// Cuts sit on multiples of the GEMM tile width (64 columns) when every rank still gets at least one tile, else on multiples of
+// the MFMA block width (16), else on the even split: a stripe of 128.5 columns would otherwise cost every rank a third,
+// almost empty tile per KronBlock and operator (the ragged remainder of n stays with the last rank, as on one GPU).
+inline int32_t stripe_cut(int32_t n, int32_t W, int32_t w)
+{
+    if (w <= 0) return 0;
+    if (w >= W) return n;
+    const int64_t even = ((int64_t)n * w) / W;
+    for (int32_t g : {64, 16}) {
+        if ((int64_t)n < (int64_t)g * W) continue;
+        const int64_t units = n / g;                       // whole g-column units, dealt evenly; the remainder goes to the last rank
+        return (int32_t)(((units * w) / W) * g);
+    }
+    return (int32_t)even;
+}
 
 // Pooled device memory and a fill kernel (pool.hip): pool_free never synchronises, recycling is stream-ordered.
 hipError_t pool_malloc(void** out, size_t bytes);

@@ -390,6 +390,9 @@ extern "C" dmrgx_status dmrgx_eigs_lowest(dmrgx_kron_plan* plan, const dmrgx_eig
     DMRGX_HIP(hipMemcpyAsync(nrm, c1, sizeof(double), hipMemcpyDeviceToDevice, st));
     DMRGX_CHK(normalise_into(vec(0)));
 
+    // how often the Ritz pair of a caller-supplied start vector is looked at: a look costs one small copy + a stream sync
+    // (~50 us), a MatMult that turns out unnecessary 0.1 .. 10 ms
+    const int check_every = N >= 500000 ? 1 : (N >= 100000 ? 2 : 4);
     std::vector<double> T((size_t)m * m, 0.0), theta, Q, hbuf((size_t)(m + 1) * row);
     int k = 0, n_matvec = 0, restarts = 0, converged = 0;
     double beta_m = 0.0, resid = 0.0, lambda = 0.0;
@@ -423,7 +426,7 @@ extern "C" dmrgx_status dmrgx_eigs_lowest(dmrgx_kron_plan* plan, const dmrgx_eig
             DMRGX_HIP(hipGetLastError());
             // A start vector supplied by the caller (the sweep engine's transformed ground state) is usually within a few
             // Lanczos steps of convergence: look at the Ritz pair every 4 steps instead of only at the end of the cycle.
-            if (opts->use_initial && opts->max_matvec <= 0 && j + 1 < m && (j + 1 - k) % 4 == 0) {
+            if (opts->use_initial && opts->max_matvec <= 0 && j + 1 < m && (j + 1 - k) % check_every == 0) {
                 DMRGX_HIP(hipMemcpyAsync(hbuf.data(), dScal.p, (size_t)(m + 1) * row * sizeof(double), hipMemcpyDeviceToHost, st));
                 DMRGX_HIP(hipStreamSynchronize(st));
                 const int mm = j + 1;

@@ -65,7 +65,7 @@ def test_sector_profile_and_term_counts(pkg):
 def test_stripe_bounds_partition(pkg):
     import ctypes as C
     lib = pkg._capi.lib()
-    for n in (0, 1, 5, 64, 850, 1693):
+    for n in (0, 1, 5, 64, 130, 272, 850, 1028, 1693):
         for W in (1, 2, 3, 8):
             cuts = []
             for r in range(W):
@@ -74,7 +74,12 @@ def test_stripe_bounds_partition(pkg):
                 cuts.append((a.value, b.value))
             assert cuts[0][0] == 0 and cuts[-1][1] == n
             assert all(cuts[i][1] == cuts[i + 1][0] for i in range(W - 1))
-            assert max(b - a for a, b in cuts) - min(b - a for a, b in cuts) <= 1
+            # cuts sit on whole GEMM tiles (64 columns) when every rank gets one, else on MFMA blocks (16), else the even split;
+            # the ragged remainder of n stays with the last rank
+            g = 64 if n >= 64 * W else 16 if n >= 16 * W else 1
+            assert all(a % g == 0 for a, _ in cuts)
+            widths = [b - a for a, b in cuts]
+            assert max(widths[:-1] + [widths[-1] - n % g]) - min(widths[:-1] + [widths[-1] - n % g]) <= g
     a, b = C.c_int32(), C.c_int32()
     assert lib.dmrgx_stripe_bounds(10, 2, 2, C.byref(a), C.byref(b)) == pkg._capi.DMRGX_ERR_ARG
 
