@@ -72,8 +72,35 @@ ggemm_kernel(const GTile* __restrict__ tiles, const GGroup* __restrict__ groups,
         for (int ni = 0; ni < TC; ++ni) acc[mi][ni] = (d4){0.0, 0.0, 0.0, 0.0};
 
     // ---- scaled-copy products (identity operator cells): acc += alpha * S[tile] ------------------------
+    // Two products per pass with all their loads issued before the first use: a scaled copy is a descriptor load followed by
+    // a tile load, and one at a time the chain of both latencies (~2.5 us) is paid per product.
     int p = g.prod_begin;
-    for (int e = p + g.n_axpy; p < e; ++p) {
+    const int axpy_end = p + g.n_axpy;
+    if (TR * TC <= 4) {
+        for (; p + 1 < axpy_end; p += 2) {
+            const GProd pa = prods[p], pb = prods[p + 1];
+            gptr Sa = (gptr)(pa.B + (size_t)m0 * pa.ldb + n0);
+            gptr Sb = (gptr)(pb.B + (size_t)m0 * pb.ldb + n0);
+            double va[TR][TC][4], vb[TR][TC][4];
+#pragma unroll
+            for (int mi = 0; mi < TR; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < TC; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = min(wrow + mi * 16 + l4 + 4 * r, mrem - 1), col = min(wcol + ni * 16 + l15, nrem - 1);   // clamped: in bounds, never stored
+                        va[mi][ni][r] = Sa[(size_t)row * pa.ldb + col];
+                        vb[mi][ni][r] = Sb[(size_t)row * pb.ldb + col];
+                    }
+#pragma unroll
+            for (int mi = 0; mi < TR; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < TC; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { acc[mi][ni][r] += pa.alpha * va[mi][ni][r]; acc[mi][ni][r] += pb.alpha * vb[mi][ni][r]; }
+        }
+    }
+    for (; p < axpy_end; ++p) {
         const GProd pr = prods[p];
         gptr S = (gptr)(pr.B + (size_t)m0 * pr.ldb + n0);
 #pragma unroll

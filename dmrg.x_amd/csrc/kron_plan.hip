@@ -294,7 +294,10 @@ struct Builder {
             for (int32_t sidx = 0; sidx < S; ++sidx) {
                 const int32_t hi = cuts[sidx];
                 const int32_t nb = (int32_t)prods.size();
-                if (sidx == 0) for (int32_t q = 0; q < n_axpy; ++q) { const RelProd ax = prods[axpy_begin + q]; prods.push_back(ax); }
+                // the scaled-copy products (identity operator cells, 1 (x) H_R) are dealt over the segments: each is a dependent
+                // descriptor + tile load of its own, and all of them on segment 0 made that unit the tail of its tile
+                int32_t n_axpy_seg = 0;
+                for (int32_t q = sidx; q < n_axpy; q += S) { const RelProd ax = prods[axpy_begin + q]; prods.push_back(ax); ++n_axpy_seg; }
                 while (pcur < gemm_end && pstart[pcur - gemm_begin] + (prods[pcur].K + GG_BK - 1) / GG_BK <= lo) ++pcur;   // products are in stream order
                 for (int32_t p = pcur; p < gemm_end; ++p) {
                     const int32_t ps = pstart[p - gemm_begin], pe = ps + (prods[p].K + GG_BK - 1) / GG_BK;
@@ -308,16 +311,16 @@ struct Builder {
                 }
                 const int32_t ne = (int32_t)prods.size();
                 if (sidx == 0) {
-                    groups[g].prod_begin = nb; groups[g].prod_end = ne;
-                    ggemm_append_tiles_mixed(tiles2b, tiles2, g, groups[g].M, groups[g].N, (hi - lo) + n_axpy, big);
+                    groups[g].prod_begin = nb; groups[g].prod_end = ne; groups[g].n_axpy = n_axpy_seg;
+                    ggemm_append_tiles_mixed(tiles2b, tiles2, g, groups[g].M, groups[g].N, (hi - lo) + n_axpy_seg, big);
                 } else {
                     RelGroup ng2 = groups[g];
                     ng2.c_base = BASE_ARENA;
                     ng2.c_off = slab_base + slab_elems + (int64_t)(sidx - 1) * mn;
                     ng2.ldc = ng2.N;
-                    ng2.prod_begin = nb; ng2.prod_end = ne; ng2.n_axpy = 0; ng2.accumulate = 0;
+                    ng2.prod_begin = nb; ng2.prod_end = ne; ng2.n_axpy = n_axpy_seg; ng2.accumulate = 0;
                     groups.push_back(ng2);
-                    ggemm_append_tiles_mixed(tiles2b, tiles2, (int32_t)groups.size() - 1, ng2.M, ng2.N, hi - lo, big);
+                    ggemm_append_tiles_mixed(tiles2b, tiles2, (int32_t)groups.size() - 1, ng2.M, ng2.N, (hi - lo) + n_axpy_seg, big);
                 }
                 lo = hi;
             }
