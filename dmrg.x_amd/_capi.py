@@ -82,7 +82,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_voi
 class EigsOpts(C.Structure):
     _fields_ = [("ncv", C.c_int32), ("max_it", C.c_int32), ("tol", C.c_double), ("seed", C.c_uint64),
                 ("use_initial", C.c_int32), ("max_matvec", C.c_int32), ("allgather", ALLGATHER_FN), ("allreduce_sum", ALLREDUCE_FN), ("user", C.c_void_p),
-                ("comm", C.c_void_p)]
+                ("comm", C.c_void_p), ("method", C.c_int32)]
 
 
 class EigsStats(C.Structure):
@@ -99,6 +99,7 @@ SIGNATURES = {
     "dmrgx_kron_plan_info": (C.c_int32, [C.c_void_p, C.POINTER(KronInfo)]),
     "dmrgx_kron_apply": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dmrgx_kron_plan_destroy": (C.c_int32, [C.c_void_p]),
+    "dmrgx_kron_diag": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "dmrgx_kron_plan_timing": (C.c_int32, [C.c_void_p, C.c_int32]),
     "dmrgx_kron_plan_timing_read": (C.c_int32, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "dmrgx_kron_vec_to_striped": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -128,6 +128,32 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const RedTile* __restr
     for (int i = 0; i < NE; ++i) if (e0 + (uint32_t)i * 256u < mn) *d[i] = v[i];
 }
 
+// ---- diagonal of the superblock Hamiltonian (preconditioner of the generalized-Davidson solver) --------------------------
+// diag(H)[(l, r) of KronBlock k] = sum_t dA_t[l] * dB_t[r] over the "diagonal terms": H_L (x) 1, 1 (x) H_R and every merged
+// operator pair with sector shift 0 (the Sz Sz terms).  dA_t / dB_t are the diagonals of the plan's own operator copies.
+struct DiagSrc { int64_t off; int32_t ld, n, round; int64_t dst; double scale; };     // off < 0: scaled identity
+struct DiagSeg { int64_t out_off; int32_t nrow, ncol; int64_t l0, r0; };
+__global__ void __launch_bounds__(256) diag_gather_kernel(const DiagSrc* __restrict__ src, int nsrc, int round, const double* __restrict__ arena, double* __restrict__ dvec)
+{
+    const int t = blockIdx.x;
+    if (t >= nsrc) return;
+    const DiagSrc s = src[t];
+    if (s.round != round) return;
+    for (int i = threadIdx.x; i < s.n; i += 256) dvec[s.dst + i] += s.off >= 0 ? arena[s.off + (int64_t)i * (s.ld + 1)] : s.scale;
+}
+__global__ void __launch_bounds__(256) diag_fill_kernel(const DiagSeg* __restrict__ segs, const double* __restrict__ dA, const double* __restrict__ dB,
+                                                         int nterms, int64_t NL, int64_t NR, double* __restrict__ out)
+{
+    const DiagSeg s = segs[blockIdx.y];
+    const int64_t n = (int64_t)s.nrow * s.ncol;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+        const int64_t l = e / s.ncol, r = e % s.ncol;
+        double d = 0.0;
+        for (int t = 0; t < nterms; ++t) d += dA[(int64_t)t * NL + s.l0 + l] * dB[(int64_t)t * NR + s.r0 + r];
+        out[s.out_off + e] = d;
+    }
+}
+
 }  // namespace
 }  // namespace dmrgx
 
@@ -183,6 +209,10 @@ struct dmrgx_kron_plan {
     int32_t nlayout = 0;
     DevBuf d_red_tasks, d_red_tiles;    // split-K fix-up tables
     int32_t n_red_tiles = 0;
+    std::vector<DiagSrc> diag_src;      // dmrgx_kron_diag: where the diagonals of the operator copies sit in the arena
+    std::vector<DiagSeg> diag_segs;     // this rank's panels of every KronBlock
+    int32_t diag_terms = 0, diag_rounds = 0;
+    int64_t diag_NL = 0, diag_NR = 0;
     bool timing = false;                // per-stage HIP-event timing (dmrgx_kron_plan_timing)
     std::vector<hipEvent_t> ev;         // 3 events per recorded apply
     size_t ev_used = 0;
@@ -653,6 +683,54 @@ extern "C" dmrgx_status dmrgx_kron_plan_create(const dmrgx_kron_desc* d, void* s
         DMRGX_CHK(upload(P->d_layout, segs, st));
     }
 
+    {   // diagonal terms (dmrgx_kron_diag): t = 0: H_L (x) 1, t = 1: 1 (x) H_R, then the shift-0 groups
+        std::vector<int64_t> offL(SL.nsec + 1, 0), offR(SR.nsec + 1, 0);
+        for (int i = 0; i < SL.nsec; ++i) offL[i + 1] = offL[i] + SL.size[i];
+        for (int i = 0; i < SR.nsec; ++i) offR[i + 1] = offR[i] + SR.size[i];
+        P->diag_NL = offL[SL.nsec]; P->diag_NR = offR[SR.nsec];
+        int32_t nt = 2;
+        for (auto& g : G) if (g.sA == 0 && g.sB == 0) ++nt;
+        P->diag_terms = nt;
+        const int64_t baseB = (int64_t)nt * P->diag_NL;                       // dvec = [dA (nt x NL) | dB (nt x NR)]
+        std::map<std::tuple<int32_t, int32_t, int32_t>, int32_t> rounds;      // (side, term, sector) -> sources so far
+        auto add_cells = [&](const std::vector<PCell>& cells, int side, int32_t t, const std::vector<int64_t>& off, bool transposed_storage) {
+            for (const PCell& c : cells) {
+                // block (q -> q): the diagonal crosses the cell where r0 + i == c0 + j (transposed storage swaps the roles, same set)
+                const int32_t lo = std::max(c.r0, c.c0), hi = std::min(c.r0 + c.nr, c.c0 + c.nc);
+                if (lo >= hi) continue;
+                DiagSrc d;
+                d.n = hi - lo; d.scale = c.scale; d.ld = c.nc;
+                d.off = c.kind == DMRGX_CELL_DENSE ? c.off + (int64_t)(lo - c.r0) * c.nc + (lo - c.c0) : -1;
+                d.dst = (side == 0 ? (int64_t)t * P->diag_NL : baseB + (int64_t)t * P->diag_NR) + off[c.q] + lo;
+                d.round = rounds[std::make_tuple(side, t, c.q)]++;
+                P->diag_rounds = std::max(P->diag_rounds, d.round + 1);
+                P->diag_src.push_back(d);
+                (void)transposed_storage;
+            }
+        };
+        auto add_ones = [&](int side, int32_t t, const dmrgx_sectors& S, const std::vector<int64_t>& off) {
+            for (int32_t q = 0; q < S.nsec; ++q) {
+                DiagSrc d;
+                d.n = S.size[q]; d.scale = 1.0; d.ld = 0; d.off = -1; d.round = rounds[std::make_tuple(side, t, q)]++;
+                d.dst = (side == 0 ? (int64_t)t * P->diag_NL : baseB + (int64_t)t * P->diag_NR) + off[q];
+                P->diag_rounds = std::max(P->diag_rounds, d.round + 1);
+                P->diag_src.push_back(d);
+            }
+        };
+        add_cells(PHL, 0, 0, offL, false); add_ones(1, 0, SR, offR);
+        add_ones(0, 1, SL, offL); add_cells(PHRT, 1, 1, offR, true);
+        int32_t t = 2;
+        for (auto& g : G) {
+            if (g.sA != 0 || g.sB != 0) continue;
+            add_cells(g.left, 0, t, offL, false); add_cells(g.rightT, 1, t, offR, true);
+            ++t;
+        }
+        for (int32_t k = 0; k < nb; ++k) {
+            if (panel_ld(k, me) <= 0) continue;
+            P->diag_segs.push_back(DiagSeg{seg_off[me][k], nLk(k), panel_ld(k, me), offL[d->block_il[k]], offR[d->block_ir[k]] + cb(k, me)});
+        }
+    }
+
     dmrgx_kron_info& I = P->info;
     I.n_states = N; I.vec_len = (W == 1) ? N : (int64_t)W * seg_stride; I.local_offset = (int64_t)me * seg_stride;
     I.local_len = (W == 1) ? N : seg_stride; I.seg_stride = seg_stride;
@@ -769,3 +847,27 @@ extern "C" dmrgx_status dmrgx_kron_vec_to_striped(const dmrgx_kron_plan* plan, c
 
 extern "C" dmrgx_status dmrgx_kron_vec_from_striped(const dmrgx_kron_plan* plan, const double* v_full_dev, double* v_ref_dev, void* stream)
 { return layout_copy(plan, v_full_dev, v_ref_dev, 0, (hipStream_t)stream); }
+
+extern "C" dmrgx_status dmrgx_kron_diag(dmrgx_kron_plan* P, double* d_local, void* stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (!P || !d_local) DMRGX_FAIL(DMRGX_ERR_ARG, "kron_diag: null argument");
+    DevBuf dvec, d_src, d_segs;
+    const size_t nvec = (size_t)P->diag_terms * (size_t)(P->diag_NL + P->diag_NR);
+    DMRGX_CHK(dvec.alloc(std::max<size_t>(nvec, 1) * sizeof(double)));
+    DMRGX_HIP(zero_async(dvec.p, dvec.bytes, st));
+    DMRGX_HIP(zero_async(d_local, (size_t)P->info.local_len * sizeof(double), st));
+    DMRGX_CHK(upload(d_src, P->diag_src, st));
+    DMRGX_CHK(upload(d_segs, P->diag_segs, st));
+    for (int32_t r = 0; r < P->diag_rounds; ++r) {
+        hipLaunchKernelGGL(diag_gather_kernel, dim3((unsigned)P->diag_src.size()), dim3(256), 0, st, d_src.as<DiagSrc>(), (int)P->diag_src.size(), r,
+                           (const double*)P->arena.as<double>(), dvec.as<double>());
+        DMRGX_HIP(hipGetLastError());
+    }
+    if (!P->diag_segs.empty()) {
+        hipLaunchKernelGGL(diag_fill_kernel, dim3(64, (unsigned)P->diag_segs.size()), dim3(256), 0, st, d_segs.as<DiagSeg>(), (const double*)dvec.as<double>(),
+                           (const double*)(dvec.as<double>() + (size_t)P->diag_terms * P->diag_NL), P->diag_terms, P->diag_NL, P->diag_NR, d_local);
+        DMRGX_HIP(hipGetLastError());
+    }
+    return DMRGX_OK;
+}

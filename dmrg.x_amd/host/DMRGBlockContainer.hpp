@@ -111,6 +111,14 @@ public:
         ierr = PetscOptionsGetReal(NULL, NULL, "-H_eps_tol", &eps_tol, NULL); CHKERRQ(ierr);
         ierr = PetscOptionsGetInt(NULL, NULL, "-H_eps_ncv", &eps_ncv, NULL); CHKERRQ(ierr);
         ierr = PetscOptionsGetInt(NULL, NULL, "-H_eps_max_it", &eps_max_it, NULL); CHKERRQ(ierr);
+        {   /* SLEPc's solver choice for the superblock problem: krylovschur (its default; here thick-restart Lanczos) or gd */
+            char type[64] = "krylovschur"; PetscBool set = PETSC_FALSE;
+            ierr = PetscOptionsGetString(NULL, NULL, "-H_eps_type", type, sizeof(type), &set); CHKERRQ(ierr);
+            const std::string t(type);
+            if (t == "gd") eps_method = 1;
+            else if (t == "krylovschur" || t == "lanczos") eps_method = 0;
+            else SETERRQ1(mpi_comm, PETSC_ERR_SUP, "-H_eps_type %s is not available (krylovschur, lanczos, gd).", type);
+        }
         if (no_symm) SETERRQ(mpi_comm, PETSC_ERR_SUP, "Unsupported option: no_symm.");
         ierr = PetscOptionsGetBool(NULL, NULL, "-debug_check_symmetry", &debug_symm, NULL); CHKERRQ(ierr);
         ierr = PetscOptionsGetBool(NULL, NULL, "-wavefunction_guess", &use_guess, NULL); CHKERRQ(ierr);
@@ -445,6 +453,7 @@ public:
             dmrgx_eigs_opts o;
             memset(&o, 0, sizeof(o));
             o.ncv = (int32_t)eps_ncv; o.max_it = (int32_t)eps_max_it; o.tol = eps_tol; o.seed = 0x9E3779B9u + (uint64_t)GlobIdx;
+            o.method = eps_method;
             bool guessed = false;
             try { ierr = TransformedGuess(KronBlocks, SysBlock, EnvBlock, gsv_r, guessed); CHKERRQ(ierr); }
             catch (const std::exception& e) { SETERRQ1(mpi_comm, 1, "wavefunction transformation: %s", e.what()); }
@@ -1297,6 +1306,7 @@ private:
     PetscReal qn_sector = 0.0;
     PetscReal eps_tol = 1.0e-8;     /* SLEPc's default relative residual tolerance */
     PetscInt eps_ncv = 16, eps_max_it = 1000;
+    int32_t eps_method = 0;         /* -H_eps_type: 0 krylovschur (thick-restart Lanczos), 1 gd (generalized Davidson, diagonal preconditioner) */
     std::string scratch_dir, data_dir;
     FILE *fp_step = NULL, *fp_timings = NULL, *fp_entanglement = NULL, *fp_data = NULL, *fp_corr = NULL, *fp_kron = NULL;
     PetscInt kron_rows = 0;

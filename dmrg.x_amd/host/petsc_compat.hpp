@@ -111,7 +111,7 @@ inline int CommBootstrap()
 {
     const char* ws = getenv("WORLD_SIZE");
     const int world = ws ? atoi(ws) : 1;
-    if (world <= 1) return 0;
+    if (world <= 1 && !getenv("DMRGX_FORCE_COMM")) return 0;      /* DMRGX_FORCE_COMM=1: a one-rank communicator (tests the RCCL start-up path on one GPU) */
     const int rank = getenv("RANK") ? atoi(getenv("RANK")) : 0;
     const int local = getenv("LOCAL_RANK") ? atoi(getenv("LOCAL_RANK")) : rank;
     const std::string mode = getenv("DMRGX_COMM") ? getenv("DMRGX_COMM") : "rccl";

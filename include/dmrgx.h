@@ -166,6 +166,11 @@ dmrgx_status dmrgx_kron_plan_info(const dmrgx_kron_plan* plan, dmrgx_kron_info* 
  * rank's segment of a full vector or at a separate buffer of local_len doubles.  world_size==1: y = H x. */
 dmrgx_status dmrgx_kron_apply(dmrgx_kron_plan* plan, const double* x_full, double* y_local, void* stream);
 dmrgx_status dmrgx_kron_plan_destroy(dmrgx_kron_plan* plan);
+/* d_local[e] <- <e| H |e> for the basis states of this rank's segment (local_len doubles, padding 0): the diagonal of the
+ * superblock Hamiltonian, = sum over H_L (x) 1, 1 (x) H_R and the sector-diagonal terms (Sz Sz) of diag(A)[l] diag(B)[r]
+ * -- what a diagonally preconditioned eigensolver (SLEPc: -H_eps_type gd, -H_st_pc_type jacobi) asks MatGetDiagonal for; the
+ * reference's shell matrix does not implement it (src/DMRGKron.cpp:1912-1914 registers MATOP_MULT only). */
+dmrgx_status dmrgx_kron_diag(dmrgx_kron_plan* plan, double* d_local_dev, void* stream);
 /* Optional per-launch timing of the two GEMM stages with HIP events recorded on the apply's own stream
  * (the reference's analogue is the -DDMRG_KRON_TIMINGS accumulators, include/MiscTools.hpp:17-59).
  * enable != 0 resets and starts recording (up to 4096 applies), enable == 0 stops. */
@@ -214,6 +219,12 @@ typedef struct {
     /* native collectives: when `comm` is set (and the hooks are NULL) the solver calls dmrgx_comm_allgather /
      * dmrgx_comm_allreduce_sum itself -- the product path; the hooks remain for harnesses that own their communicator */
     dmrgx_comm* comm;
+    /* 0: thick-restart Lanczos (SLEPc's default for this solve, -H_eps_type krylovschur).  1: generalized Davidson with the
+     * diagonal of H_sb as preconditioner (-H_eps_type gd with a Jacobi preconditioner): same convergence criterion (true
+     * residual), about a quarter fewer MatMults from the engine's transformed start vectors, two host looks per iteration
+     * (worth it only when a MatMult costs milliseconds).  Applies when use_initial is set; from a random start the Lanczos
+     * path is used (the preconditioned iteration is twice as slow there). */
+    int32_t method;
 } dmrgx_eigs_opts;
 
 typedef struct {

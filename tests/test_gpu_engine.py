@@ -210,6 +210,25 @@ def test_multi_rank_engine_sweep_reproduces_the_single_rank_run(tmp_path):
     assert len(c1["values"]) == len(c3["values"]) == 2
 
 
+def test_engine_with_generalized_davidson_solver(tmp_path):
+    """-H_eps_type gd (the option name SLEPc users of the reference have): ED energy of the 4x4 J1-J2 lattice and the oracle's
+    per-step energies of a well-defined truncating 2-D case at the north-star tolerance, on one rank and on two."""
+    rows, run, _ = run_engine(tmp_path / "ed", "-Lx", 4, "-Ly", 4, "-J1", 1, "-Jz1", 1, "-J2", 0.5, "-Jz2", 0.5, "-mwarmup", 128, "-nsweeps", 2,
+                              "-H_eps_tol", 1e-12, "-H_eps_type", "gd")
+    assert abs(min(r["GSEnergy"] for r in rows if r["NSites_SysEnl"] + r["NSites_EnvEnl"] == 16) - (-13.8884952588612)) <= 1e-10 * 13.89
+    H = J1J2XXZModel_SquareLattice(Lx=6, Ly=2, J1=0.7, Jz1=1.0, J2=0.4, Jz2=0.6)
+    orc = DMRGOracle(H, 4, qn_sector=1.0)
+    orc.Warmup()
+    orc.Sweeps(nsweeps=2)
+    for ranks in (1, 2):
+        rows, _, _ = run_engine(tmp_path / ("gd%d" % ranks), "-Lx", 6, "-Ly", 2, "-J1", 0.7, "-Jz1", 1.0, "-J2", 0.4, "-Jz2", 0.6, "-qn_sector", 1,
+                                "-mwarmup", 4, "-nsweeps", 2, "-H_eps_tol", 1e-13, "-H_eps_type", "gd", ranks=ranks)
+        assert len(rows) == len(orc.steps)
+        for r, o in zip(rows, orc.steps):
+            assert r["NumStates_H"] == o["NumStates_H"] and abs(r["GSEnergy"] - o["GSEnergy"]) <= 1e-10 * abs(o["GSEnergy"]), r["GlobIdx"]
+            assert abs(r["TruncErr_Sys"] - o["TruncErr_Sys"]) <= 1e-10 * abs(o["TruncErr_Sys"]) + 1e-13
+
+
 def test_pruned_and_unpruned_operator_sets_agree(tmp_path):
     """-prune_ops 0 rotates and keeps every Sz(i)/Sp(i) of every block and diagonalises both density matrices of every KronBlock,
     as the reference does; the default keeps the sites a later inter-block term or a registered correlator can touch, does not
@@ -409,6 +428,18 @@ def test_native_communicator_host_staged_ranks_on_one_gpu(world):
     outs = [p.communicate(timeout=600)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)[-3000:]
     assert "native %d-rank eigensolve ok" % world in outs[0]
+
+
+def test_engine_starts_rccl_communicator(tmp_path):
+    """The C++ engine's own start-up of the RCCL back-end (petsc_compat.hpp::CommBootstrap: device selection, id through the
+    rendezvous file, ncclCommInitRank from a process without torch), with the one rank the test box can give it."""
+    d = str(tmp_path) + "/"
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", DMRGX_FORCE_COMM="1", DMRGX_RDZV_FILE=d + "rdzv", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([EXE] + [str(o) for o in ("-Lx", 4, "-Ly", 2, "-heisenberg", 1, "-mwarmup", 32, "-nsweeps", 1, "-H_eps_tol", 1e-12, "-data_dir", d)],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    run = json.load(open(d + "DMRGRun.json"))
+    assert abs(run["GSEnergy"] - (-6.6682766346354)) <= 1e-10 * 6.67 and run["Ranks"] == 1 and not os.path.exists(d + "rdzv")
 
 
 def test_rccl_hooks_single_rank():

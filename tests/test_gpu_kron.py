@@ -138,6 +138,64 @@ def test_eigs_lowest_vs_dense(mods):
     plan.destroy()
 
 
+def test_kron_diag_matches_dense_diagonal(mods):
+    """dmrgx_kron_diag (the preconditioner of the generalized-Davidson option) against the diagonal of the densely assembled
+    superblock Hamiltonian, unstriped and reassembled from the stripes of 3 ranks; identity cells, merged operators and both
+    merge directions included."""
+    import ctypes as C
+    sbm, wl, capi = mods
+    L = capi.lib()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for kw in (dict(name="cfg2", m=32, Ly=3, seed=3), dict(name="cfg1", m=12, Ly=1, seed=4), dict(name="cfg5", m=40, Ly=2, seed=5)):
+        sb = wl.synthetic_superblock(kw["name"], m=kw["m"], Ly=kw["Ly"], seed=kw["seed"])
+        n = sb.n_states
+        H = np.stack([wl.apply_factored_numpy(sb, e) for e in np.eye(n)], axis=1)
+        want = np.diag(H).copy()
+        plan = sbm.KronPlan(sb)
+        d = torch.full((n,), float("nan"), dtype=torch.float64, device="cuda")
+        capi.check(L.dmrgx_kron_diag(plan._handle, C.c_void_p(d.data_ptr()), st))
+        torch.cuda.synchronize()
+        assert np.abs(d.cpu().numpy() - want).max() <= 1e-13 * max(1.0, np.abs(want).max())
+        plan.destroy()
+        W = 3
+        plans = [sbm.KronPlan(sb, world_size=W, rank=r) for r in range(W)]
+        info = plans[0].info
+        ds = torch.zeros(info.vec_len, dtype=torch.float64, device="cuda")
+        for p_ in plans:
+            capi.check(L.dmrgx_kron_diag(p_._handle, C.c_void_p(ds[p_.info.local_offset:].data_ptr()), st))
+        dref = torch.zeros(n, dtype=torch.float64, device="cuda")
+        plans[0].from_striped(ds, dref)
+        torch.cuda.synchronize()
+        assert np.abs(dref.cpu().numpy() - want).max() <= 1e-13 * max(1.0, np.abs(want).max())
+        for p_ in plans:
+            p_.destroy()
+
+
+def test_eigs_generalized_davidson_vs_dense_and_lanczos(mods):
+    """opts.method = 1 (SLEPc users: -H_eps_type gd): same eigenpair as the dense solve and as the Lanczos path, from a random
+    start and from a perturbed eigenvector; a restart is forced by a small search space."""
+    sbm, wl, _ = mods
+    sb = wl.synthetic_superblock("cfg2", m=32, Ly=2, seed=3)
+    plan = sbm.KronPlan(sb)
+    n = sb.n_states
+    H = np.stack([wl.apply_factored_numpy(sb, e) for e in np.eye(n)], axis=1)
+    w, v = np.linalg.eigh(H)
+    rng = np.random.default_rng(1)
+    # (without a start vector the option falls through to Lanczos; a random psi0 exercises the Davidson iteration from far away)
+    for kwargs in (dict(psi0=torch.from_numpy(rng.standard_normal(n)).cuda()), dict(psi0=torch.from_numpy(rng.standard_normal(n)).cuda(), ncv=6),
+                   dict(psi0=torch.from_numpy(v[:, 0] + 1e-3 * rng.standard_normal(n)).cuda()), dict(seed=9)):
+        e0, psi, stats = plan.eigs_lowest(tol=1e-12, method=1, **kwargs)
+        assert stats.converged == 1 and stats.n_matvec > 0
+        assert abs(e0 - w[0]) <= 1e-10 * abs(w[0])
+        r = torch.empty_like(psi)
+        plan.apply(psi, r)
+        assert float((r - e0 * psi).norm()) <= 1e-8 * abs(e0) and abs(float(psi.norm()) - 1.0) < 1e-12
+        assert abs(abs(float(psi.cpu().numpy() @ v[:, 0])) - 1.0) < 1e-8
+    e_l, _, st_l = plan.eigs_lowest(tol=1e-12, seed=9)
+    assert abs(e_l - e0) <= 1e-10 * abs(e0)
+    plan.destroy()
+
+
 def test_eigs_tiny_problem_smaller_than_ncv(mods):
     sbm, wl, _ = mods
     sb = wl.synthetic_superblock("cfg1", m=4, Ly=1, seed=3)
