@@ -18,6 +18,7 @@
 // RCCL all-gather of equal-sized segments rebuilds x for the next apply.
 #include "ggemm.h"
 #include <algorithm>
+#include <functional>
 #include <map>
 #include <set>
 #include <tuple>
@@ -451,7 +452,48 @@ extern "C" dmrgx_status dmrgx_kron_plan_create(const dmrgx_kron_desc* d, void* s
             DMRGX_FAIL(DMRGX_ERR_ARG, "term %d does not conserve Sz (shifts %d,%d)", t, d->left_ops[T.left_op].shift, d->right_ops[T.right_op].shift);
         if (T.a != 0.0) { usedL.insert(T.left_op); usedR.insert(T.right_op); }
     }
-    const bool key_right = usedR.size() <= usedL.size();   // groups keyed by right op => left ops get merged
+    // Term groups = a minimum vertex cover of the bipartite graph (distinct left operators) -- terms -- (distinct right operators):
+    // a covered right operator B_j keys the group  (sum_t a_t A_t) (x) B_j  of its terms (left operators merged, the map the
+    // reference builds at src/DMRGKron.cpp:955-960), a covered left operator A_i the group  A_i (x) (sum_t a_t B_t).  Merging on
+    // one side only costs min(#left, #right) groups; at a cut in the middle of a column of the J1-J2 cylinder that is 9-10 sites
+    // per operator type against a cover of 8 (Koenig: maximum matching, alternating paths from the unmatched left vertices).
+    static const bool one_sided = getenv("DMRGX_MERGE_ONE_SIDED") != nullptr;      // developer aid: the round-1 rule
+    std::vector<char> coverL(d->n_left_ops, 0), coverR(d->n_right_ops, 0);
+    {
+        std::vector<std::vector<int32_t>> adj(d->n_left_ops);
+        for (int32_t t = 0; t < d->nterms; ++t) if (d->terms[t].a != 0.0) adj[d->terms[t].left_op].push_back(d->terms[t].right_op);
+        std::vector<int32_t> matchR(d->n_right_ops, -1), matchL(d->n_left_ops, -1);
+        std::vector<char> seen;
+        std::function<bool(int32_t)> augment = [&](int32_t l) -> bool {
+            for (int32_t r : adj[l]) {
+                if (seen[r]) continue;
+                seen[r] = 1;
+                if (matchR[r] < 0 || augment(matchR[r])) { matchR[r] = l; matchL[l] = r; return true; }
+            }
+            return false;
+        };
+        for (int32_t l : usedL) { seen.assign(d->n_right_ops, 0); augment(l); }
+        // Z = vertices reachable from unmatched left vertices along alternating paths; cover = (L \ Z) u (R n Z)
+        std::vector<char> zL(d->n_left_ops, 0), zR(d->n_right_ops, 0);
+        std::vector<int32_t> stack;
+        for (int32_t l : usedL) if (matchL[l] < 0) { zL[l] = 1; stack.push_back(l); }
+        while (!stack.empty()) {
+            const int32_t l = stack.back(); stack.pop_back();
+            for (int32_t r : adj[l]) {
+                if (zR[r] || matchL[l] == r) continue;
+                zR[r] = 1;
+                const int32_t l2 = matchR[r];
+                if (l2 >= 0 && !zL[l2]) { zL[l2] = 1; stack.push_back(l2); }
+            }
+        }
+        for (int32_t l : usedL) coverL[l] = !zL[l];
+        for (int32_t r : usedR) coverR[r] = zR[r];
+        if (one_sided) {
+            const bool key_right = usedR.size() <= usedL.size();
+            for (int32_t l : usedL) coverL[l] = !key_right;
+            for (int32_t r : usedR) coverR[r] = key_right;
+        }
+    }
     struct Group { int32_t sA, sB; std::vector<PCell> left, rightT; };   // rightT: cells of Bhat^T
     std::vector<Group> G;
     std::vector<CopyTask> copies;
@@ -491,18 +533,24 @@ extern "C" dmrgx_status dmrgx_kron_plan_create(const dmrgx_kron_desc* d, void* s
     };
 
     {
-        std::map<int32_t, std::vector<int32_t>> by_key;   // key op -> term indices
-        for (int32_t t = 0; t < d->nterms; ++t) if (d->terms[t].a != 0.0) by_key[key_right ? d->terms[t].right_op : d->terms[t].left_op].push_back(t);
+        std::map<std::pair<int32_t, int32_t>, std::vector<int32_t>> by_key;   // (side: 1 = keyed by right op, 0 = by left op; op) -> term indices
+        for (int32_t t = 0; t < d->nterms; ++t) {
+            const dmrgx_term& T = d->terms[t];
+            if (T.a == 0.0) continue;
+            if (coverR[T.right_op]) by_key[{1, T.right_op}].push_back(t);
+            else if (coverL[T.left_op]) by_key[{0, T.left_op}].push_back(t);
+            else DMRGX_FAIL(DMRGX_ERR_INTERNAL, "kron_plan_create: term %d is not covered", t);
+        }
         for (auto& kv : by_key) {
             Group g;
             std::vector<std::pair<double, const std::vector<NCell>*>> cl, cr;
-            if (key_right) {
-                g.sB = d->right_ops[kv.first].shift; g.sA = -g.sB;
-                cr.push_back({1.0, &Rops[kv.first]});
+            if (kv.first.first == 1) {
+                g.sB = d->right_ops[kv.first.second].shift; g.sA = -g.sB;
+                cr.push_back({1.0, &Rops[kv.first.second]});
                 for (int32_t t : kv.second) cl.push_back({d->terms[t].a, &Lops[d->terms[t].left_op]});
             } else {
-                g.sA = d->left_ops[kv.first].shift; g.sB = -g.sA;
-                cl.push_back({1.0, &Lops[kv.first]});
+                g.sA = d->left_ops[kv.first.second].shift; g.sB = -g.sA;
+                cl.push_back({1.0, &Lops[kv.first.second]});
                 for (int32_t t : kv.second) cr.push_back({d->terms[t].a, &Rops[d->terms[t].right_op]});
             }
             build_side(cl, false, g.left);

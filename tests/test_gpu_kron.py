@@ -352,7 +352,7 @@ def test_cells_axpy_vs_numpy(mods):
     assert np.abs(Dd.cpu().numpy() - ref).max() < 1e-14
 
 
-@pytest.mark.parametrize("mode", ["few_left", "few_right"])
+@pytest.mark.parametrize("mode", ["few_left", "few_right", "mixed_cover"])
 def test_apply_when_one_side_has_fewer_distinct_operators(mods, mode):
     """Both merge directions of the plan (terms grouped by the side with fewer distinct operators, the other side's
     operators pre-summed): a mid-column cut where one site couples to every site of the other block, so the MERGED
@@ -360,13 +360,22 @@ def test_apply_when_one_side_has_fewer_distinct_operators(mods, mode):
     sbm, wl, _ = mods
     sb = wl.synthetic_superblock("cfg2", m=48, Ly=3, seed=77)
     terms = []
+    if mode == "mixed_cover":
+        # left site 0 couples to right sites 0 and 1, left sites 1 and 2 couple to right site 2: the minimum vertex cover of the
+        # term graph is {left 0, right 2} per operator type -- a left-keyed group (right operators merged) and a right-keyed
+        # group (left operators merged) in one plan, 6 groups where merging on one side needs 9
+        for (i, r, a) in ((0, 0, 0.7), (0, 1, 0.8), (1, 2, 0.9), (2, 2, 1.1)):
+            terms += [(a, wl.OpSp, i, wl.OpSm, r), (a, wl.OpSm, i, wl.OpSp, r), (0.3 + 0.1 * i, wl.OpSz, i, wl.OpSz, r)]
     for j in range(3):
+        if mode == "mixed_cover":
+            break
         for i in ([2] if mode == "few_left" else [0, 1, 2]):
             jj = [j] if mode == "few_left" else [2]
             for r in jj:
                 terms += [(0.7 + 0.1 * j, wl.OpSp, i, wl.OpSm, r), (0.7 + 0.1 * j, wl.OpSm, i, wl.OpSp, r), (0.3, wl.OpSz, i, wl.OpSz, r)]
     sb.terms = terms
     plan = sbm.KronPlan(sb)
+    assert plan.info.n_groups == (6 if mode == "mixed_cover" else 3)
     ref = ShellApplyC(oracle_shell_from_superblock(sb))
     x = np.random.default_rng(3).standard_normal(sb.n_states)
     y, y_ref = _apply(plan, x), ref.apply(x)
