@@ -146,7 +146,7 @@ def sweep_legs():
         e = [run["SweepEnergies"][k] for k in sorted(run["SweepEnergies"])]
         tol = 10.0 * max(run["MaxTruncErr"], 1e-12) * abs(e[-1])
         assert all(b <= a + tol for a, b in zip(e, e[1:])), ("sweep energies rise", e)
-        assert abs(run["GSEnergy"] - e[-1]) <= 1e-12 * abs(e[-1])
+        assert abs(run["GSEnergy"] - e[-1]) <= 1e-10 * abs(e[-1])          # DMRGSteps.json prints 12 significant digits
         out["sweep_energies"] = e
         return out
     j1j2 = ["-J1", 1, "-Jz1", 1, "-J2", 0.5, "-Jz2", 0.5]

@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstring>
 
 namespace dmrgx {
 namespace {
@@ -674,6 +675,25 @@ static dmrgx_status eigs_davidson(dmrgx_kron_plan* plan, const dmrgx_eigs_opts* 
         if (trace) fprintf(stderr, "[eigs gd] matvec %d: theta %.12f  |r| %.3e  (target %.3e)\n", n_matvec, lambda, resid, tol * std::fabs(lambda));
         if (resid <= tol * std::max(std::fabs(lambda), 1e-300) || mm == N) { converged = 1; break; }
         if (n_matvec >= max_mv) break;
+        if (n_matvec >= 6 * m) {
+            // a start vector that was not close after all (the preconditioned iteration then trails Lanczos, see above): hand the
+            // current Ritz vector to the Lanczos path instead of iterating on
+            ydev.assign((size_t)mm, 0.0);
+            for (int i = 0; i < mm; ++i) ydev[(size_t)i] = Y[(size_t)i * mm + 0];
+            DMRGX_HIP(h2d_async(dY.p, ydev.data(), ydev.size() * sizeof(double), st));
+            hipLaunchKernelGGL(basis_rotate_kernel, dim3(1024, 1), dim3(DOT_THREADS), 0, st, (const double*)V, n, mm, (const double*)dY.as<double>(), 1, 1,
+                               dist ? psi_full + I.local_offset : psi_full, n, n);
+            DMRGX_HIP(hipGetLastError());
+            DMRGX_HIP(hipStreamSynchronize(st));
+            dmrgx_eigs_opts o2 = *opts;
+            o2.method = 0; o2.use_initial = 1;
+            dmrgx_eigs_stats s2;
+            memset(&s2, 0, sizeof(s2));
+            const dmrgx_status rc = dmrgx_eigs_lowest(plan, &o2, e0, psi_full, &s2, (void*)st);
+            if (stats) { *stats = s2; stats->n_matvec += n_matvec; stats->n_restart += restarts;
+                         stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(); }
+            return rc;
+        }
         if (mm == m) {
             // thick restart: the kk lowest Ritz vectors span the new basis (V <- V Y, W <- W Y, G <- diag(theta))
             static const int kk_env = getenv("DMRGX_GD_KEEP") ? atoi(getenv("DMRGX_GD_KEEP")) : 0;
