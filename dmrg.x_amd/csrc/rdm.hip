@@ -84,19 +84,26 @@ __device__ __forceinline__ double fast_rsqrt(double x)
     return y;
 }
 
-// Jacobi rotation annihilating a_pq: with d = (a_qq - a_pp)/2 and h = hypot(d, a_pq), cos(2 theta) = |d|/h, so
-// c^2 = (1 + |d|/h)/2 and s = sign(d a_pq) |a_pq| / (2 h c)  -- two rsqrt, no division, c^2 + s^2 = 1 by construction.
+// Jacobi rotation annihilating a_pq: with d = (a_qq - a_pp)/2 and h = hypot(d, a_pq), tan(theta) = sign(d) a_pq / (|d| + h)
+// (the smaller root), c = 1/sqrt(1 + t^2), s = t c.  Division-free and as short as the dependency chain gets (it is what a
+// sub-solve round costs): h and 1/(|d| + h) come from the hardware estimates v_rsq_f64 / v_rcp_f64 with one Newton step --
+// an error in t only leaves a_pq' = O(eps a_pq) behind, far below what the next sweep removes -- while c gets the two Newton
+// steps of full precision, so that c^2 + s^2 = c^2 (1 + t^2) = 1 to round-off and R stays orthogonal.
 __device__ __forceinline__ void jacobi_rotation(double apq, double app, double aqq, double& c, double& s)
 {
     c = 1.0; s = 0.0;
     const double apq2 = apq * apq;
     if (apq2 > 1e-300 && apq2 > 1e-36 * fabs(app * aqq)) {
         const double d = 0.5 * (aqq - app);
-        const double ih = fast_rsqrt(d * d + apq2);
-        const double c2 = 0.5 + 0.5 * fabs(d) * ih;
-        const double ic = fast_rsqrt(c2);
-        c = c2 * ic;
-        s = ((d >= 0.0) == (apq >= 0.0) ? 0.5 : -0.5) * fabs(apq) * ih * ic;
+        const double x = d * d + apq2;
+        double ih = __builtin_amdgcn_rsq(x);
+        ih = ih * (1.5 - 0.5 * x * ih * ih);
+        const double den = fabs(d) + x * ih;
+        double rd = __builtin_amdgcn_rcp(den);
+        rd = rd * (2.0 - den * rd);
+        const double t = (d >= 0.0 ? apq : -apq) * rd;
+        c = fast_rsqrt(1.0 + t * t);
+        s = t * c;
     }
 }
 
@@ -205,21 +212,7 @@ jacobi_sub_kernel(const MatDesc* __restrict__ mats, const PairRef* __restrict__ 
     for (int e = tid; e < JS * JS; e += SUB_THREADS) Rout[e] = Rf[(e / JS) * JLD + (e % JS)];
 }
 
-// One 16 x 16 block (block row wr, block column wc) of L * M for two JS x JS operands in LDS (row stride JLD), on the MFMA
-// pipe: 8 x v_mfma_f64_16x16x4_f64 per wave.  Fragment maps as in ggemm.hip: A[i = l&15][k = l>>4], B[k = l>>4][j = l&15],
-// result col = l&15, row = (l>>4) + 4 reg.  (The plain-FMA version of this product was LDS-bandwidth bound: the update
-// kernel ran at ~12 TF/s and took 70 % of the eigensolve at m = 2048.)
 typedef double jd4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ jd4 mfma_block(const double* L, const double* M, int wr, int wc, int lane)
-{
-    static_assert(JS == 32, "mfma_block: a 32 x 32 tile is covered by 2 x 2 waves");
-    const int l15 = lane & 15, l4 = lane >> 4;
-    jd4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int kk = 0; kk < JS; kk += 4)
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(L[(16 * wr + l15) * JLD + kk + l4], M[(kk + l4) * JLD + 16 * wc + l15], acc, 0, 0, 0);
-    return acc;
-}
 
 // One launch per round applies all rotations of the round:
 //   kind 0 (A, two-sided): block (P,Q), P <= Q, of the pair-block partition:  A[P,Q] <- R_P^T . A[P,Q] . R_Q, and its
@@ -227,10 +220,17 @@ __device__ __forceinline__ jd4 mfma_block(const double* L, const double* M, int 
 //                          column and the row update of the textbook formulation fuse into one pass over the upper
 //                          triangle, and A stays symmetric to the last bit;
 //   kind 1 (V, one-sided): rows [JS*t, JS*t+JS) x pair-block Q:      V[t,Q] <- V[t,Q] . R_Q
+// 256 threads = 2 x 2 waves, each wave owns a (JS/2) x (JS/2) quarter of the tile as NBK x NBK v_mfma_f64_16x16x4 accumulators
+// (fragment maps as in ggemm.hip: A[i = l&15][k = l>>4], B[k = l>>4][j = l&15], result col = l&15, row = (l>>4) + 4 reg); the
+// tile X goes through LDS, R_Q and R_P^T go from global memory straight into MFMA fragments.  (The plain-FMA version of these
+// products was LDS-bandwidth bound: the update ran at ~12 TF/s and took 70 % of the eigensolve at m = 2048.)
 __device__ __forceinline__ void jacobi_update_body(double* sh, const MatDesc* __restrict__ mats, const int32_t* __restrict__ pair_start, const UpdTask t,
                                                    double* __restrict__ buf, const double* __restrict__ rbuf, int round)
 {
-    double* X = sh;                                   // the only LDS tile: R_Q and R_P^T go from global memory straight into MFMA fragments
+    static_assert(JS == 32 || JS == 64, "update tile: 2 x 2 waves of (JS/32)^2 MFMA blocks");
+    constexpr int NBK = JS / 32, HALF = JS / 2, KG = JS / 4;
+    if (threadIdx.x >= 256) return;                   // riding along in a larger (sub-solve) workgroup: the first four waves work
+    double* X = sh;
     const MatDesc m = mats[t.mat];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
     int IQ, JQ, IP = 0, JP = 0;
@@ -242,36 +242,69 @@ __device__ __forceinline__ void jacobi_update_body(double* sh, const MatDesc* __
     auto cq = [&](int j) { return j < JB ? IQ * JB + j : JQ * JB + j - JB; };
     auto rp = [&](int i) { return t.kind == 0 ? (i < JB ? IP * JB + i : JP * JB + i - JB) : t.p * JS + i; };
     const int l15 = lane & 15, l4 = lane >> 4;
-    // fragments (as in mfma_block): B operand of X . R_Q is R_Q[k][16 wc + l15]; A operand of R_P^T . Y is R_P[k][16 wr + l15]
-    double bq[JS / 4], ap[JS / 4];
+    // fragments: B operand of X . R_Q is R_Q[k][HALF wc + 16 nj + l15]; A operand of R_P^T . Y is R_P[k][HALF wr + 16 mi + l15]
+    double bq[KG][NBK], ap[KG][NBK];
 #pragma unroll
-    for (int g = 0; g < JS / 4; ++g) {
-        bq[g] = Rq[(4 * g + l4) * JS + 16 * wc + l15];
-        ap[g] = (t.kind == 0) ? Rp[(4 * g + l4) * JS + 16 * wr + l15] : 0.0;
-    }
+    for (int g = 0; g < KG; ++g)
+#pragma unroll
+        for (int b = 0; b < NBK; ++b) {
+            bq[g][b] = Rq[(4 * g + l4) * JS + HALF * wc + 16 * b + l15];
+            ap[g][b] = (t.kind == 0) ? Rp[(4 * g + l4) * JS + HALF * wr + 16 * b + l15] : 0.0;
+        }
     for (int e = tid; e < JS * JS; e += 256) {
         const int i = e / JS, j = e % JS;
         X[i * JLD + j] = M[(int64_t)rp(i) * m.npad + cq(j)];
     }
     __syncthreads();
-    jd4 acc = {0.0, 0.0, 0.0, 0.0};
+    jd4 acc[NBK][NBK];
 #pragma unroll
-    for (int g = 0; g < JS / 4; ++g) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(X[(16 * wr + l15) * JLD + 4 * g + l4], bq[g], acc, 0, 0, 0);      // X . R_Q
+    for (int mi = 0; mi < NBK; ++mi)
+#pragma unroll
+        for (int nj = 0; nj < NBK; ++nj) acc[mi][nj] = (jd4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int g = 0; g < KG; ++g)
+#pragma unroll
+        for (int mi = 0; mi < NBK; ++mi) {
+            const double xa = X[(HALF * wr + 16 * mi + l15) * JLD + 4 * g + l4];
+#pragma unroll
+            for (int nj = 0; nj < NBK; ++nj) acc[mi][nj] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa, bq[g][nj], acc[mi][nj], 0, 0, 0);      // X . R_Q
+        }
     if (t.kind == 0) {
         __syncthreads();
 #pragma unroll
-        for (int r = 0; r < 4; ++r) X[(16 * wr + l4 + 4 * r) * JLD + 16 * wc + l15] = acc[r];
-        __syncthreads();
-        acc = (jd4){0.0, 0.0, 0.0, 0.0};
+        for (int mi = 0; mi < NBK; ++mi)
 #pragma unroll
-        for (int g = 0; g < JS / 4; ++g) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[g], X[(4 * g + l4) * JLD + 16 * wc + l15], acc, 0, 0, 0);  // R_P^T . (X . R_Q)
+            for (int nj = 0; nj < NBK; ++nj)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) X[(HALF * wr + 16 * mi + l4 + 4 * r) * JLD + HALF * wc + 16 * nj + l15] = acc[mi][nj][r];
+        __syncthreads();
+#pragma unroll
+        for (int mi = 0; mi < NBK; ++mi)
+#pragma unroll
+            for (int nj = 0; nj < NBK; ++nj) acc[mi][nj] = (jd4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int g = 0; g < KG; ++g)
+#pragma unroll
+            for (int nj = 0; nj < NBK; ++nj) {
+                const double yb = X[(4 * g + l4) * JLD + HALF * wc + 16 * nj + l15];
+#pragma unroll
+                for (int mi = 0; mi < NBK; ++mi) acc[mi][nj] = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[g][mi], yb, acc[mi][nj], 0, 0, 0);  // R_P^T . (X . R_Q)
+            }
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) M[(int64_t)rp(16 * wr + l4 + 4 * r) * m.npad + cq(16 * wc + l15)] = acc[r];
+    for (int mi = 0; mi < NBK; ++mi)
+#pragma unroll
+        for (int nj = 0; nj < NBK; ++nj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) M[(int64_t)rp(HALF * wr + 16 * mi + l4 + 4 * r) * m.npad + cq(HALF * wc + 16 * nj + l15)] = acc[mi][nj][r];
     if (t.kind == 0 && t.p != t.q) {                              // mirror: A[Q,P] = (A[P,Q])^T, staged through LDS for row-wise stores
         __syncthreads();
 #pragma unroll
-        for (int r = 0; r < 4; ++r) X[(16 * wr + l4 + 4 * r) * JLD + 16 * wc + l15] = acc[r];
+        for (int mi = 0; mi < NBK; ++mi)
+#pragma unroll
+            for (int nj = 0; nj < NBK; ++nj)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) X[(HALF * wr + 16 * mi + l4 + 4 * r) * JLD + HALF * wc + 16 * nj + l15] = acc[mi][nj][r];
         __syncthreads();
         for (int e = tid; e < JS * JS; e += 256) {
             const int i = e / JS, j = e % JS;                     // element (i, j) of the transposed block
@@ -525,6 +558,12 @@ static dmrgx_status rdm_create_impl(const dmrgx_sectors* left, const dmrgx_secto
     DMRGX_CHK(upload(d_pairs, pairs, st));
     DMRGX_CHK(upload(d_tiles, tiles, st));
     DMRGX_CHK(upload(d_vtiles, vtiles, st));
+    // JB = 16: the eigenvector updates of a round ride along with the next round's sub-solves (4-wave workgroups, CUs mostly idle).
+    // JB = 32: the sub-solve workgroups have 16 waves and 133 KB of LDS -- no room for riders -- so the eigenvector updates join
+    // the update launch of their own round.
+    constexpr bool RIDE = (JB == 16);
+    DevBuf d_alltiles;
+    if (!RIDE) { std::vector<UpdTask> all(tiles); all.insert(all.end(), vtiles.begin(), vtiles.end()); DMRGX_CHK(upload(d_alltiles, all, st)); }
     DMRGX_CHK(upload(d_pstart, pair_start, st));
     for (auto& v : diag_off) v += diag_base;
     DMRGX_CHK(upload(d_doff, diag_off, st));
@@ -705,8 +744,14 @@ static dmrgx_status rdm_create_impl(const dmrgx_sectors* left, const dmrgx_secto
         for (int r = 0; r < rounds; ++r) {
             double* rcur = buf + rbuf_off + slot * rbuf_len;
             const double* rprev = buf + rbuf_off + (slot ^ 1) * rbuf_len;
-            hipLaunchKernelGGL(jacobi_sub_kernel, dim3((unsigned)(pairs.size() + (pending_v ? vtiles.size() : 0))), dim3(SUB_THREADS), 0, st, dm, d_pairs.as<PairRef>(),
+            hipLaunchKernelGGL(jacobi_sub_kernel, dim3((unsigned)(pairs.size() + (RIDE && pending_v ? vtiles.size() : 0))), dim3(SUB_THREADS), 0, st, dm, d_pairs.as<PairRef>(),
                                (int)pairs.size(), buf, rcur, r, d_vtiles.as<UpdTask>(), d_pstart.as<int32_t>(), rprev, prev_round);
+            if (!RIDE) {
+                hipLaunchKernelGGL(jacobi_update_kernel, dim3((unsigned)(tiles.size() + vtiles.size())), dim3(256), 0, st, dm, d_pstart.as<int32_t>(), d_alltiles.as<UpdTask>(), buf, (const double*)rcur, r);
+                DMRGX_HIP(hipGetLastError());
+                prev_round = r; slot ^= 1;
+                continue;
+            }
             hipLaunchKernelGGL(jacobi_update_kernel, dim3((unsigned)tiles.size()), dim3(256), 0, st, dm, d_pstart.as<int32_t>(), d_tiles.as<UpdTask>(), buf, (const double*)rcur, r);
             DMRGX_HIP(hipGetLastError());
             pending_v = !vtiles.empty(); prev_round = r; slot ^= 1;
