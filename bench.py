@@ -64,7 +64,7 @@ def cpu_baseline(sb, budget_s=15.0):
                       f"({total_flops / 1e9:.0f} GF per MatMult)"}
 
 
-def cpu_baseline_factored(sb, reps=3):
+def cpu_baseline_factored(sb, reps=5):
     """the same MatMult in factored, operator-merged form (oracle/kron_factored.py: per-sector numpy / OpenBLAS GEMMs,
     exactly F_alg flops) on this host's cores, timed IN FULL (every row of the superblock; median of `reps` after one warm-up)."""
     from oracle.kron_factored import FactoredApplyCPU

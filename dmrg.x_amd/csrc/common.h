@@ -58,6 +58,11 @@ hipError_t zero_async(void* p, size_t bytes, hipStream_t st);
 void pool_stats(size_t* in_use, size_t* cached, size_t* peak);
 hipError_t h2d_async(void* dst, const void* src, size_t bytes, hipStream_t st);   // pinned-ring staged, never blocks on the copy
 
+// Which stripe of KronBlock k rank w owns: the stripes are dealt round the ranks block by block, so that the rank holding the
+// last stripe of a block -- the one with the ragged remainder of n, i.e. an extra, almost empty tile column -- changes from block
+// to block instead of always being rank W-1 (measured on one GPU, W = 8: slowest rank 0.66 ms against 0.44 ms for the fastest).
+inline int32_t stripe_of_rank(int32_t W, int32_t w, int32_t k) { return (w + k) % W; }
+
 // RAII device buffer owned by a plan.
 struct DevBuf {
     void* p = nullptr;

@@ -421,17 +421,18 @@ extern "C" dmrgx_status dmrgx_kron_plan_create(const dmrgx_kron_desc* d, void* s
     const int64_t N = ref_off[nb];
     auto nLk = [&](int32_t k) { return SL.size[d->block_il[k]]; };
     auto nRk = [&](int32_t k) { return SR.size[d->block_ir[k]]; };
-    // stripes: columns [cb(k,w), cb(k,w+1)) of block k belong to rank w
-    auto cb = [&](int32_t k, int32_t w) { return stripe_cut(nRk(k), W, w); };
+    // stripes: columns [cbeg(k,w), cend(k,w)) of block k belong to rank w (stripe (w + k) mod W: see stripe_of_rank)
+    auto cbeg = [&](int32_t k, int32_t w) { return stripe_cut(nRk(k), W, stripe_of_rank(W, w, k)); };
+    auto cend = [&](int32_t k, int32_t w) { return stripe_cut(nRk(k), W, stripe_of_rank(W, w, k) + 1); };
     std::vector<std::vector<int64_t>> seg_off(W, std::vector<int64_t>(nb + 1, 0));
     int64_t max_seg = 0;
     for (int32_t w = 0; w < W; ++w) {
-        for (int32_t k = 0; k < nb; ++k) seg_off[w][k + 1] = seg_off[w][k] + (int64_t)nLk(k) * (cb(k, w + 1) - cb(k, w));
+        for (int32_t k = 0; k < nb; ++k) seg_off[w][k + 1] = seg_off[w][k] + (int64_t)nLk(k) * (cend(k, w) - cbeg(k, w));
         max_seg = std::max(max_seg, seg_off[w][nb]);
     }
     const int64_t seg_stride = (W == 1) ? N : ((max_seg + 63) / 64) * 64;
     auto panel_off = [&](int32_t k, int32_t w) { return (int64_t)w * seg_stride + seg_off[w][k]; };   // in a full vector
-    auto panel_ld = [&](int32_t k, int32_t w) { return cb(k, w + 1) - cb(k, w); };
+    auto panel_ld = [&](int32_t k, int32_t w) { return cend(k, w) - cbeg(k, w); };
 
     // ---- operators ---------------------------------------------------------------------------------------
     if (d->n_left_ops < 0 || d->n_right_ops < 0 || d->nterms < 0) DMRGX_FAIL(DMRGX_ERR_ARG, "negative count");
@@ -586,7 +587,7 @@ extern "C" dmrgx_status dmrgx_kron_plan_create(const dmrgx_kron_desc* d, void* s
     //           per output-column SEGMENT with a product list -- never one overwriting group per cell.
     auto stage1 = [&](const std::vector<PCell>& cellsT, int32_t sB, int32_t k, int32_t ksrc, int64_t toff) {
         (void)sB;
-        const int32_t ir = d->block_ir[k], cs = cb(k, me), ce = cb(k, me + 1), w = ce - cs;
+        const int32_t ir = d->block_ir[k], cs = cbeg(k, me), ce = cend(k, me), w = ce - cs;
         if (w <= 0) return;
         const int32_t M = nLk(ksrc);
         std::set<int32_t> cuts = {cs, ce};
@@ -595,7 +596,7 @@ extern "C" dmrgx_status dmrgx_kron_plan_create(const dmrgx_kron_desc* d, void* s
             if (c.q != ir) continue;
             cuts.insert(clampc(c.c0)); cuts.insert(clampc(c.c0 + c.nc));
             if (c.kind == DMRGX_CELL_IDENT)        // a scaled copy must read ONE source panel: cut at panel borders too
-                for (int32_t p = 1; p < W; ++p) { const int32_t sc = cb(ksrc, p); if (sc > c.r0 && sc < c.r0 + c.nr) cuts.insert(clampc(c.c0 + (sc - c.r0))); }
+                for (int32_t p = 0; p < W; ++p) { const int32_t sc = cbeg(ksrc, p); if (sc > c.r0 && sc < c.r0 + c.nr) cuts.insert(clampc(c.c0 + (sc - c.r0))); }
         }
         std::vector<int32_t> cv(cuts.begin(), cuts.end());
         for (size_t s = 0; s + 1 < cv.size(); ++s) {
@@ -609,16 +610,16 @@ extern "C" dmrgx_status dmrgx_kron_plan_create(const dmrgx_kron_desc* d, void* s
                 if (c.q != ir || c.c0 > o0 || c.c0 + c.nc < o1) continue;
                 if (c.kind == DMRGX_CELL_DENSE) {
                     for (int32_t p = 0; p < W; ++p) {            // contraction index r' in [c.r0, c.r0+c.nr) split over source panels
-                        const int32_t k0 = std::max(c.r0, cb(ksrc, p)), k1 = std::min(c.r0 + c.nr, cb(ksrc, p + 1));
+                        const int32_t k0 = std::max(c.r0, cbeg(ksrc, p)), k1 = std::min(c.r0 + c.nr, cend(ksrc, p));
                         if (k0 >= k1) continue;
-                        B.add_gemm(BASE_X, panel_off(ksrc, p) + (k0 - cb(ksrc, p)), panel_ld(ksrc, p),
+                        B.add_gemm(BASE_X, panel_off(ksrc, p) + (k0 - cbeg(ksrc, p)), panel_ld(ksrc, p),
                                    BASE_ARENA, c.off + (int64_t)(k0 - c.r0) * c.nc + (o0 - c.c0), c.nc, k1 - k0);
                     }
                 } else {                                         // identity cell: T[:, o] += scale * X_src[:, c.r0 + (o - c.c0)]
                     const int32_t s0 = c.r0 + (o0 - c.c0);
                     int32_t p = 0;
-                    while (p + 1 < W && cb(ksrc, p + 1) <= s0) ++p;
-                    B.add_axpy(BASE_X, panel_off(ksrc, p) + (s0 - cb(ksrc, p)), panel_ld(ksrc, p), c.scale);
+                    for (int32_t pp = 0; pp < W; ++pp) if (cbeg(ksrc, pp) <= s0 && s0 < cend(ksrc, pp)) p = pp;
+                    B.add_axpy(BASE_X, panel_off(ksrc, p) + (s0 - cbeg(ksrc, p)), panel_ld(ksrc, p), c.scale);
                 }
             }
             B.close(g, 1);
@@ -725,7 +726,7 @@ extern "C" dmrgx_status dmrgx_kron_plan_create(const dmrgx_kron_desc* d, void* s
         std::vector<LayoutSeg> segs;
         for (int32_t k = 0; k < nb; ++k) for (int32_t w = 0; w < W; ++w) {
             if (panel_ld(k, w) <= 0) continue;
-            segs.push_back(LayoutSeg{ref_off[k] + cb(k, w), panel_off(k, w), nLk(k), panel_ld(k, w), nRk(k), panel_ld(k, w)});
+            segs.push_back(LayoutSeg{ref_off[k] + cbeg(k, w), panel_off(k, w), nLk(k), panel_ld(k, w), nRk(k), panel_ld(k, w)});
         }
         P->nlayout = (int32_t)segs.size();
         DMRGX_CHK(upload(P->d_layout, segs, st));
@@ -775,7 +776,7 @@ extern "C" dmrgx_status dmrgx_kron_plan_create(const dmrgx_kron_desc* d, void* s
         }
         for (int32_t k = 0; k < nb; ++k) {
             if (panel_ld(k, me) <= 0) continue;
-            P->diag_segs.push_back(DiagSeg{seg_off[me][k], nLk(k), panel_ld(k, me), offL[d->block_il[k]], offR[d->block_ir[k]] + cb(k, me)});
+            P->diag_segs.push_back(DiagSeg{seg_off[me][k], nLk(k), panel_ld(k, me), offL[d->block_il[k]], offR[d->block_ir[k]] + cbeg(k, me)});
         }
     }
 

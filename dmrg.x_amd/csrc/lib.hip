@@ -41,6 +41,15 @@ extern "C" dmrgx_status dmrgx_stripe_bounds(int32_t n_right, int32_t world_size,
     return DMRGX_OK;
 }
 
+extern "C" dmrgx_status dmrgx_stripe_bounds_of_block(int32_t n_right, int32_t world_size, int32_t rank, int32_t block, int32_t* c0, int32_t* c1)
+{
+    if (!c0 || !c1 || n_right < 0 || world_size <= 0 || rank < 0 || rank >= world_size || block < 0) DMRGX_FAIL(DMRGX_ERR_ARG, "stripe_bounds_of_block: bad argument");
+    const int32_t j = dmrgx::stripe_of_rank(world_size, rank, block);
+    *c0 = dmrgx::stripe_cut(n_right, world_size, j);
+    *c1 = dmrgx::stripe_cut(n_right, world_size, j + 1);
+    return DMRGX_OK;
+}
+
 extern "C" dmrgx_status dmrgx_dgemm_nn(int32_t M, int32_t N, int32_t K, const double* A, int64_t lda,
                                        const double* B, int64_t ldb, double* C, int64_t ldc, void* stream)
 {

@@ -183,9 +183,12 @@ dmrgx_status dmrgx_kron_plan_timing_read(dmrgx_kron_plan* plan, double* ms4, int
 dmrgx_status dmrgx_kron_vec_to_striped(const dmrgx_kron_plan* plan, const double* v_ref_dev, double* v_full_dev, void* stream);
 dmrgx_status dmrgx_kron_vec_from_striped(const dmrgx_kron_plan* plan, const double* v_full_dev, double* v_ref_dev, void* stream);
 
-/* Host-only helper (no device needed): columns [*c0, *c1) of a KronBlock whose right sector has n_right states
- * belong to rank `rank` of `world_size` -- the stripe rule used by every plan. */
+/* Host-only helper (no device needed): columns [*c0, *c1) are stripe number `rank` of a KronBlock whose right sector has n_right
+ * states cut for `world_size` ranks -- the cut rule used by every plan (cuts on whole GEMM tiles where possible). */
 dmrgx_status dmrgx_stripe_bounds(int32_t n_right, int32_t world_size, int32_t rank, int32_t* c0, int32_t* c1);
+/* The columns rank `rank` owns in the KronBlock number `block` (position in desc->block_il/ir): stripe (rank + block) mod world_size
+ * of dmrgx_stripe_bounds -- the stripes are dealt round the ranks block by block so that the ragged last stripe moves around. */
+dmrgx_status dmrgx_stripe_bounds_of_block(int32_t n_right, int32_t world_size, int32_t rank, int32_t block, int32_t* c0, int32_t* c1);
 
 /* ---- generic grouped f64 GEMM (used by K1/K3/K6; exposed for tests) ---------------------------------- */
 /* C[M x N] (row-major, ldc) = A[M x K] (row-major, lda) * B[K x N] (row-major, ldb), device pointers. */

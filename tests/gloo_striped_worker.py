@@ -23,9 +23,9 @@ x = np.random.default_rng(3).standard_normal(sb.n_states)
 y_full = wl.apply_factored_numpy(sb, x)
 
 
-def bounds(n, r):
+def bounds(n, r, k):
     a, b = C.c_int32(), C.c_int32()
-    assert lib.dmrgx_stripe_bounds(n, world, r, C.byref(a), C.byref(b)) == 0
+    assert lib.dmrgx_stripe_bounds_of_block(n, world, r, k, C.byref(a), C.byref(b)) == 0
     return a.value, b.value
 
 
@@ -33,7 +33,7 @@ def segment(vec, r):
     """rank r's segment of a full vector: for every KronBlock the columns of its stripe, row-major."""
     parts = []
     for k, (il, ir) in enumerate(sb.blocks):
-        c0, c1 = bounds(sb.right_sizes[ir], r)
+        c0, c1 = bounds(sb.right_sizes[ir], r, k)
         parts.append(vec[off[k]:off[k + 1]].reshape(sb.left_sizes[il], sb.right_sizes[ir])[:, c0:c1].ravel())
     return np.concatenate(parts)
 
@@ -51,7 +51,7 @@ y = np.zeros(sb.n_states)
 for r in range(world):
     pos = r * stride
     for k, (il, ir) in enumerate(sb.blocks):
-        c0, c1 = bounds(sb.right_sizes[ir], r)
+        c0, c1 = bounds(sb.right_sizes[ir], r, k)
         n = sb.left_sizes[il] * (c1 - c0)
         y[off[k]:off[k + 1]].reshape(sb.left_sizes[il], sb.right_sizes[ir])[:, c0:c1] = g[pos:pos + n].reshape(sb.left_sizes[il], c1 - c0)
         pos += n

@@ -82,6 +82,16 @@ def test_stripe_bounds_partition(pkg):
             assert max(widths[:-1] + [widths[-1] - n % g]) - min(widths[:-1] + [widths[-1] - n % g]) <= g
     a, b = C.c_int32(), C.c_int32()
     assert lib.dmrgx_stripe_bounds(10, 2, 2, C.byref(a), C.byref(b)) == pkg._capi.DMRGX_ERR_ARG
+    # per KronBlock the stripes are dealt round the ranks: rank r owns stripe (r + block) mod W, every stripe exactly once
+    for W in (2, 3, 8):
+        for blk in range(5):
+            got = []
+            for r in range(W):
+                assert lib.dmrgx_stripe_bounds_of_block(1028, W, r, blk, C.byref(a), C.byref(b)) == 0
+                got.append((a.value, b.value))
+                c, d = C.c_int32(), C.c_int32()
+                assert lib.dmrgx_stripe_bounds(1028, W, (r + blk) % W, C.byref(c), C.byref(d)) == 0 and (c.value, d.value) == got[-1]
+            assert sorted(got)[0][0] == 0 and sorted(got)[-1][1] == 1028 and all(x[1] == y[0] for x, y in zip(sorted(got), sorted(got)[1:]))
 
 
 def test_world_size_2_striped_apply_over_gloo():

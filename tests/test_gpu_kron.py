@@ -274,6 +274,43 @@ def _secop_from(op, keep):
     return s
 
 
+def test_rdm_subset_matches_full_solve_and_refuses_unselected(mods):
+    """dmrgx_rdm_create_subset (multi-GPU dealing; sides whose spectrum the engine borrows from the other side): a selected density
+    matrix gets the spectrum of the full solve, an unselected one is refused with DMRGX_ERR_ARG, and the spectra of the two sides of a
+    KronBlock agree up to zeros (Psi Psi^T vs Psi^T Psi) -- the identity the engine's borrowing rests on."""
+    import ctypes as C
+    sbm, wl, capi = mods
+    L = capi.lib()
+    ls, rs, blocks = [70, 33, 5], [20, 64, 41], [(0, 1), (1, 2), (2, 0)]
+    n = sum(ls[a] * rs[b] for a, b in blocks)
+    psi = torch.from_numpy(np.random.default_rng(5).standard_normal(n)).cuda()
+    psi /= psi.norm()
+    full = sbm.ReducedDensityMatrices(ls, rs, blocks, psi)
+    lsz, rsz = (C.c_int32 * 3)(*ls), (C.c_int32 * 3)(*rs)
+    sl, sr = capi.Sectors(3, lsz), capi.Sectors(3, rsz)
+    bil, bir = (C.c_int32 * 3)(*[b[0] for b in blocks]), (C.c_int32 * 3)(*[b[1] for b in blocks])
+    mask = (C.c_uint8 * 3)(1, 2, 0)                      # block 0: left only, block 1: right only, block 2: nothing
+    h = C.c_void_p()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    capi.check(L.dmrgx_rdm_create_subset(C.byref(sl), C.byref(sr), 3, bil, bir, C.c_void_p(psi.data_ptr()), C.cast(mask, C.c_void_p), st, C.byref(h)))
+    for k, side in ((0, 0), (1, 1)):
+        nn = (ls[blocks[k][0]], rs[blocks[k][1]])[side]
+        out = (C.c_double * nn)()
+        capi.check(L.dmrgx_rdm_eigenvalues(h, side, k, out))
+        assert np.abs(np.array(out) - full.eigenvalues(side, k)).max() <= 1e-14
+        other = full.eigenvalues(1 - side, k)
+        m = min(len(other), nn)
+        assert np.abs(np.array(out)[:m] - other[:m]).max() <= 1e-14 and np.abs(np.array(out)[m:]).max(initial=0.0) <= 1e-14
+    out = (C.c_double * 70)()
+    for k, side in ((0, 1), (1, 0), (2, 0), (2, 1)):
+        assert L.dmrgx_rdm_eigenvalues(h, side, k, out) == capi.DMRGX_ERR_ARG
+    capi.check(L.dmrgx_rdm_destroy(h))
+    full.destroy()
+    a, b, c = C.c_size_t(), C.c_size_t(), C.c_size_t()
+    capi.check(L.dmrgx_mem_stats(C.byref(a), C.byref(b), C.byref(c)))
+    assert c.value > 0 and c.value >= a.value            # peak of the pool; nothing of it is in use once the handles are gone
+
+
 def test_rotate_ops_vs_numpy(mods):
     """K6 vs numpy: O' = RotMatT . O . RotMat (src/DMRGBlock.cpp:766-771) for Sz-, Sp- and H-type operators with
     structurally sparse cells, an identity cell, and a sector dropped by the truncation."""
