@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B of two library builds on the RDM phase: tools/ab/lib_old.so vs lib_new.so (RDM parity with each, then engine sweeps)
 set -o pipefail
-root=$(pwd); out=$root/gpurun_out/r02_ab_rdm; mkdir -p $out
+root=$(pwd); out=$root/gpurun_out/ab_engine; mkdir -p $out
 exe=$root/dmrg.x_amd/dmrgx-square-lattice
 for v in new old; do
   cp tools/ab/lib_$v.so dmrg.x_amd/libdmrgx_hip.so

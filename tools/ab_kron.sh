@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B of tools/ab/lib_old.so vs lib_new.so on one box: kron parity with the new build, then bench lines per workload
 set -o pipefail
-out=gpurun_out/r02_ab; mkdir -p $out
+out=gpurun_out/ab_kron; mkdir -p $out
 cp tools/ab/lib_new.so dmrg.x_amd/libdmrgx_hip.so
 timeout -k 10 600 python -m pytest tests/test_gpu_kron.py -x -q > $out/kron_tests.log 2>&1; rc=$?
 tail -3 $out/kron_tests.log

@@ -1,8 +1,8 @@
 #!/bin/bash
-# round-2 GPU session 2: full parity tier (incl. multi-rank rehearsals) + default bench
+# one GPU session: the whole parity tier (incl. the multi-rank rehearsals), then the default bench line
 set -o pipefail
 root=$(pwd)
-out=$root/gpurun_out/r02_run2
+out=$root/gpurun_out/check
 mkdir -p $out
 timeout -k 10 900 python -m pytest tests -m gpu -x -q > $out/gpu_tests.log 2>&1; rc=$?
 tail -25 $out/gpu_tests.log
