@@ -23,15 +23,16 @@ namespace {
 #ifndef DMRGX_JB
 #define DMRGX_JB 16
 #endif
-constexpr int JB = DMRGX_JB, JS = 2 * JB;          // block size, sub-problem size.  Every outer round costs one sub-solve plus one
-                                             // update launch of pure latency (~20 + 13 us at any matrix size); 32 x 32
-                                             // sub-problems (31 dependent rotation rounds on 256 threads) measured best:
-                                             // JB = 32 halves the rounds but its 63-round, 1024-thread solve is > 2x slower
-                                             // (one cyclic sweep per visit: the outer sweeps finish the job)
+constexpr int JB = DMRGX_JB, JS = 2 * JB;          // block size, sub-problem size.  Every outer round costs ONE launch of pure
+                                             // latency (~25 us at any matrix size: the sub-solves of the next round next to the
+                                             // updates of this one); 32 x 32 sub-problems (31 dependent rotation rounds on 256
+                                             // threads) measured best: JB = 32 halves the rounds but its 63-round, 1024-thread
+                                             // solve is > 2x slower (one cyclic sweep per visit: the outer sweeps finish the job)
+static_assert(JB == 16, "the fused round launch sizes its workgroups (256 threads, 34 KB of LDS) for 32 x 32 sub-problems");
 constexpr int JLD = JS + 1;
 constexpr int SUB_THREADS = JB * JB;           // sub-solve: one thread per pair of rotation pairs
 
-struct MatDesc { int64_t a_off, v_off; int32_t n, npad, nb, pad; };
+struct MatDesc { int64_t a_off, a2_off, v_off; int32_t n, npad, nb, pad; };    // A lives in two buffers (a_off, a2_off): a round reads one, writes the other
 struct PairRef { int32_t mat, j; };
 
 __device__ __forceinline__ void pair_blocks(int nb, int r, int j, int& I, int& J)
@@ -44,6 +45,19 @@ __device__ __forceinline__ void pair_blocks(int nb, int r, int j, int& I, int& J
     if (I > J) { const int t = I; I = J; J = t; }
 }
 
+// inverse of pair_blocks: the pair j of round r that block b sits in, and whether it is that pair's first (0) or second (1) block
+__device__ __forceinline__ void block_seat(int nb, int r, int b, int& j, int& half)
+{
+    const int m1 = nb - 1;
+    if (m1 == 0) { j = 0; half = 0; return; }
+    const int rr = r % m1;
+    if (b == m1 || b == rr) j = 0;
+    else { const int d = (b - rr + m1) % m1; j = d <= (m1 - 1) / 2 ? d : m1 - d; }
+    int I, J;
+    pair_blocks(nb, r, j, I, J);
+    half = (b == I) ? 0 : 1;
+}
+
 // A <- 0 on the padding (it stays exactly decoupled: rotations with a_pq == 0 are skipped, so the real eigenvectors are
 // the columns [0,n) of V and the convergence norms only see the real matrix); V <- identity
 __global__ void rdm_init_kernel(const MatDesc* __restrict__ mats, double* __restrict__ buf)
@@ -53,7 +67,7 @@ __global__ void rdm_init_kernel(const MatDesc* __restrict__ mats, double* __rest
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (int64_t)gridDim.x * blockDim.x) {
         const int i = (int)(e / m.npad), j = (int)(e % m.npad);
         buf[m.v_off + e] = (i == j) ? 1.0 : 0.0;
-        if (i >= m.n || j >= m.n) buf[m.a_off + e] = 0.0;
+        if (i >= m.n || j >= m.n) buf[m.a_off + e] = 0.0;       // (the second buffer is written whole by the first round)
     }
 }
 
@@ -107,11 +121,24 @@ __device__ __forceinline__ void jacobi_rotation(double apq, double app, double a
     }
 }
 
-// Solve the JS x JS symmetric sub-problem of block pair (I,J) by cyclic Jacobi in LDS; R (row-major JS x JS) such
-// that R^T S R is diagonal is written to rbuf[pair].
+// One Jacobi round = ONE launch of jacobi_round_kernel with three kinds of workgroups:
+//   [0, n_sub)   sub-solves of round `round_next`: R (row-major JS x JS) with R^T S R diagonal for every block pair -> rbuf_next;
+//   the rest     updates of round `round` (rotations in rbuf): kind 0  A_next[P,Q] = R_P^T A_cur[P,Q] R_Q over the upper triangle
+//                of pair blocks + mirror;  kind 1  the eigenvectors V[t,Q] <- V[t,Q] R_Q in place.
+// The sub-problem (I',J') of the next round does not wait for the update.  Block b of it sits in exactly one pair p(b) of this
+// round, so its off-diagonal block is one rotated tile, which the sub-solve workgroup computes itself from A_cur,
+//      S'[I',J'] = ( R_p(I')^T . A_cur[p(I'), p(J')] . R_p(J') ) [half(I'), half(J')],
+// and its two diagonal blocks are diagonal blocks of the matrices S_p = R_p^T S R_p that the sub-solves of this round ended with:
+// they are handed on through dbuf (they differ from the blocks of A_next by the rounding of a different summation order, i.e.
+// the rotation angles by a relative 1e-15 -- convergence is judged on A itself).  The dependency chain of a round is therefore
+// one launch (~20 us of sub-solve latency) with the updates -- bound by the traffic of A and V through the Infinity Cache --
+// beside it, where it used to be a sub-solve launch and an update launch back to back.  A is double-buffered for that (the
+// updates write A_next while the sub-solves read A_cur).  The update needs ~7 workgroups per CU in flight to pull its traffic, so
+// the sub-solve path is kept as light as the update path: S and R rotate in place (17 KB of LDS), one MFMA tile, <= 72 registers
+// (a first fused version with double-buffered S and R and three FMA-rotated tiles, 34 KB / 100 registers, ran the launch in
+// 39.5 us; the two kernels on two streams were slower than back to back because of the cross-stream waits).
 struct UpdTask { int32_t mat, p, q, kind; };     // p: pair index (kind 0) or row tile (kind 1); q: pair index (both local to mat)
-__device__ __forceinline__ void jacobi_update_body(double* sh, const MatDesc* __restrict__ mats, const int32_t* __restrict__ pair_start, const UpdTask t,
-                                                   double* __restrict__ buf, const double* __restrict__ rbuf, int round);
+typedef double jd4 __attribute__((ext_vector_type(4)));
 
 // Seat permutation of the round-robin tournament in "neighbours play" form: the JS indices sit in two rows of JB seats, seat
 // 2t above seat 2t+1, and seat 2t always plays seat 2t+1.  After a round everybody except seat 0 moves one seat clockwise;
@@ -123,41 +150,151 @@ __device__ __forceinline__ int jacobi_next_seat(int s)
     if (s & 1) return s - 2;                 // lower row moves left
     return s == JS - 2 ? JS - 1 : s + 2;     // upper row moves right, the last one drops to the lower row
 }
+// "Cross" form, for a visit that only rotates the pairs BETWEEN the two blocks (the pairs inside a block are rotated once per
+// sweep, in the full visits of its first round): block I sits in the upper row (even seats) and stays, block J in the lower row
+// moves one seat left per round, and after JB rounds every (i, j) has met once and everybody is back.
+__device__ __forceinline__ int jacobi_next_seat_cross(int s) { return (s & 1) ? (s + JS - 2) % JS : s; }
+// seat of index j of the sub-problem ([block I; block J]) at the start (and at the end) of a visit
+__device__ __forceinline__ int jacobi_seat_of(int j, int cross) { return cross ? (j < JB ? 2 * j : 2 * (j - JB) + 1) : j; }
 
-// Workgroups [0, npairs): the sub-problems of round `round` (rotations to rbuf).  Workgroups past npairs: the eigenvector
-// updates V <- V R of the PREVIOUS round (vtasks, rbuf_prev, round_prev) -- nothing in this round depends on them, so they
-// fill the CUs that the latency-bound sub-solves leave idle instead of lengthening the update launch.
-//
+// acc = R_P^T . M[rows, cols] . R_Q (two_sided) or M[rows, cols] . R_Q for one JS x JS tile, rows = blocks (IP, JP) of JB rows or
+// JS consecutive rows from row0 (IP < 0), cols = blocks (IQ, JQ).  256 threads = 2 x 2 waves, each wave owns a 16 x 16 quarter
+// of the tile as one v_mfma_f64_16x16x4 accumulator (fragment maps as in ggemm.hip: A[i = l&15][k = l>>4], B[k = l>>4][j = l&15],
+// result col = l&15, row = (l>>4) + 4 reg); the tile goes through LDS (X, JS x JLD), R_Q and R_P^T go from global memory
+// straight into MFMA fragments.  (The plain-FMA version of these products was LDS-bandwidth bound: the update ran at ~12 TF/s
+// and took 70 % of the eigensolve at m = 2048.)  Leaves the once-rotated tile in X; ends without a barrier.
+static_assert(JS == 32, "tile rotation: 2 x 2 waves of one 16 x 16 MFMA block each");
+__device__ __forceinline__ jd4 tile_rotate(double* X, const double* __restrict__ M, int npad, int IP, int JP, int row0, int IQ, int JQ,
+                                           const double* __restrict__ Rq, const double* __restrict__ Rp, bool two_sided)
+{
+    constexpr int KG = JS / 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    auto cq = [&](int j) { return j < JB ? IQ * JB + j : JQ * JB + j - JB; };
+    auto rp = [&](int i) { return IP >= 0 ? (i < JB ? IP * JB + i : JP * JB + i - JB) : row0 + i; };
+    // fragments: B operand of X . R_Q is R_Q[k][16 wc + l15]; A operand of R_P^T . Y is R_P[k][16 wr + l15]
+    double bq[KG], ap[KG];
+#pragma unroll
+    for (int g = 0; g < KG; ++g) {
+        bq[g] = Rq[(4 * g + l4) * JS + 16 * wc + l15];
+        ap[g] = two_sided ? Rp[(4 * g + l4) * JS + 16 * wr + l15] : 0.0;
+    }
+    for (int e = tid; e < JS * JS; e += 256) {
+        const int i = e / JS, j = e % JS;
+        X[i * JLD + j] = M[(int64_t)rp(i) * npad + cq(j)];
+    }
+    __syncthreads();
+    jd4 acc = (jd4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int g = 0; g < KG; ++g) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(X[(16 * wr + l15) * JLD + 4 * g + l4], bq[g], acc, 0, 0, 0);      // X . R_Q
+    if (two_sided) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) X[(16 * wr + l4 + 4 * r) * JLD + 16 * wc + l15] = acc[r];
+        __syncthreads();
+        acc = (jd4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int g = 0; g < KG; ++g) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[g], X[(4 * g + l4) * JLD + 16 * wc + l15], acc, 0, 0, 0);  // R_P^T . (X . R_Q)
+    }
+    return acc;
+}
+
+//   kind 0 (A, two-sided): block (P,Q), P <= Q, of the pair-block partition:  A_next[P,Q] = R_P^T . A_cur[P,Q] . R_Q, and its
+//                          transpose is written to A_next[Q,P] -- every JS x JS block is written by exactly one workgroup, the
+//                          column and the row update of the textbook formulation fuse into one pass over the upper
+//                          triangle, and A stays symmetric to the last bit;
+//   kind 1 (V, one-sided): rows [JS*t, JS*t+JS) x pair-block Q:      V[t,Q] <- V[t,Q] . R_Q
+__device__ __forceinline__ void jacobi_update_body(double* X, const MatDesc* __restrict__ mats, const int32_t* __restrict__ pair_start, const UpdTask t,
+                                                   double* __restrict__ buf, const double* __restrict__ rbuf, int round, int flip)
+{
+    const MatDesc m = mats[t.mat];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1, l15 = lane & 15, l4 = lane >> 4;
+    int IQ, JQ, IP = -1, JP = -1;
+    pair_blocks(m.nb, round, t.q, IQ, JQ);
+    if (t.kind == 0) pair_blocks(m.nb, round, t.p, IP, JP);
+    const double* Rq = rbuf + (int64_t)(pair_start[t.mat] + t.q) * JS * JS;
+    const double* Rp = rbuf + (int64_t)(pair_start[t.mat] + t.p) * JS * JS;
+    const double* M = buf + (t.kind == 0 ? (flip ? m.a2_off : m.a_off) : m.v_off);       // A: read the current buffer,
+    double* Mo = buf + (t.kind == 0 ? (flip ? m.a_off : m.a2_off) : m.v_off);            //    write the other one; V: in place
+    const jd4 acc = tile_rotate(X, M, m.npad, IP, JP, t.p * JS, IQ, JQ, Rq, Rp, t.kind == 0);
+    auto cq = [&](int j) { return j < JB ? IQ * JB + j : JQ * JB + j - JB; };
+    auto rp = [&](int i) { return t.kind == 0 ? (i < JB ? IP * JB + i : JP * JB + i - JB) : t.p * JS + i; };
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Mo[(int64_t)rp(16 * wr + l4 + 4 * r) * m.npad + cq(16 * wc + l15)] = acc[r];
+    if (t.kind == 0 && t.p != t.q) {                              // mirror: A[Q,P] = (A[P,Q])^T, staged through LDS for row-wise stores
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) X[(16 * wr + l4 + 4 * r) * JLD + 16 * wc + l15] = acc[r];
+        __syncthreads();
+        for (int e = tid; e < JS * JS; e += 256) {
+            const int i = e / JS, j = e % JS;                     // element (i, j) of the transposed block
+            Mo[(int64_t)cq(i) * m.npad + rp(j)] = X[j * JLD + i];
+        }
+    }
+}
+
 // The sub-solve is a chain of JS-1 dependent rotation rounds; what a round costs is instructions issued (several sub-problems
 // share a CU) plus two LDS round trips.  So the loop carries no index arithmetic at all: thread (k, l) always owns the 2 x 2
-// block of seats {2k, 2k+1} x {2l, 2l+1} of S and rows 2k, 2k+1 x columns {2l, 2l+1} of R, reads it from fixed addresses and
-// writes the rotated block to the fixed addresses of the seats its rows / columns move to (double-buffered S and R); the JB
-// rotations of a round are computed once, by the first JB lanes of wave 0 from the fixed pivot positions (2t, 2t+1), and
-// handed over through LDS.
+// block of seats {2k, 2k+1} x {2l, 2l+1} of S and rows 2k, 2k+1 x columns {2l, 2l+1} of R, reads it from fixed addresses and,
+// after the barrier that also hands over the rotations, writes the rotated block to the fixed addresses of the seats its rows /
+// columns move to (in place: every read of a round precedes that barrier, every write follows it); the JB rotations of a
+// round are computed once, by the first JB lanes of wave 0 from the fixed pivot positions (2t, 2t+1), and handed over through LDS.
+//
+// flip: which buffer of A is current.  has_prev == 0: no rotation is pending (very first round): S' is A_cur itself and the
+// launch holds sub-solves only.  dbuf / dbuf_next: per pair the two JB x JB diagonal blocks of the S it ended with.
 __global__ void __launch_bounds__(SUB_THREADS)
-jacobi_sub_kernel(const MatDesc* __restrict__ mats, const PairRef* __restrict__ pairs, int npairs, double* __restrict__ buf, double* __restrict__ rbuf, int round,
-                  const UpdTask* __restrict__ vtasks, const int32_t* __restrict__ pair_start, const double* __restrict__ rbuf_prev, int round_prev)
+jacobi_round_kernel(const MatDesc* __restrict__ mats, const PairRef* __restrict__ pairs, int n_sub, double* __restrict__ buf, int flip,
+                    const double* __restrict__ rbuf, const double* __restrict__ dbuf, int round, int has_prev,
+                    double* __restrict__ rbuf_next, double* __restrict__ dbuf_next, int round_next, int cross,
+                    const UpdTask* __restrict__ tasks, const int32_t* __restrict__ pair_start)
 {
-    __shared__ double sh[4 * JS * JLD];               // S and R, double-buffered
+    constexpr int BUFSZ = JS * JLD;
+    __shared__ double sh[2 * BUFSZ];                  // S and R
     __shared__ double red0[SUB_THREADS / 64], red1[SUB_THREADS / 64];
     __shared__ double rot_c[JB], rot_s[JB];
-    if ((int)blockIdx.x >= npairs) { jacobi_update_body(sh, mats, pair_start, vtasks[blockIdx.x - npairs], buf, rbuf_prev, round_prev); return; }
+    if ((int)blockIdx.x >= n_sub) { jacobi_update_body(sh, mats, pair_start, tasks[blockIdx.x - n_sub], buf, rbuf, round, flip); return; }
     double* S = sh;
-    double* R = sh + 2 * JS * JLD;
+    double* R = sh + BUFSZ;
     const PairRef pr = pairs[blockIdx.x];
     const MatDesc m = mats[pr.mat];
     int I, J;
-    pair_blocks(m.nb, round, pr.j, I, J);
+    pair_blocks(m.nb, round_next, pr.j, I, J);
     const int tid = threadIdx.x;
-    double* A = buf + m.a_off;
-    for (int e = tid; e < JS * JS; e += SUB_THREADS) {
-        const int i = e / JS, j = e % JS;
-        const int gi = (i < JB ? I * JB + i : J * JB + i - JB), gj = (j < JB ? I * JB + j : J * JB + j - JB);
-        S[i * JLD + j] = A[(int64_t)gi * m.npad + gj];
-        R[i * JLD + j] = (i == j) ? 1.0 : 0.0;
+    const double* A = buf + (flip ? m.a2_off : m.a_off);
+    if (!has_prev) {
+        for (int e = tid; e < JS * JS; e += SUB_THREADS) {
+            const int i = e / JS, j = e % JS;
+            const int gi = (i < JB ? I * JB + i : J * JB + i - JB), gj = (j < JB ? I * JB + j : J * JB + j - JB);
+            S[jacobi_seat_of(i, cross) * JLD + jacobi_seat_of(j, cross)] = A[(int64_t)gi * m.npad + gj];
+        }
+    } else {
+        // blocks (I, J) of the coming round, as they are once this round's rotations are applied
+        int jp0, hp0, jp1, hp1, PI0, PJ0, PI1, PJ1;
+        block_seat(m.nb, round, I, jp0, hp0);
+        block_seat(m.nb, round, J, jp1, hp1);
+        pair_blocks(m.nb, round, jp0, PI0, PJ0);
+        pair_blocks(m.nb, round, jp1, PI1, PJ1);
+        const int64_t g0 = pair_start[pr.mat] + jp0, g1 = pair_start[pr.mat] + jp1;
+        // diagonal blocks: loads issued before the tile rotation, stored after it
+        double dv[2 * JB * JB / SUB_THREADS];
+#pragma unroll
+        for (int u = 0; u < 2 * JB * JB / SUB_THREADS; ++u)
+            dv[u] = dbuf[(u == 0 ? g0 * 2 + hp0 : g1 * 2 + hp1) * (JB * JB) + tid];
+        const jd4 acc = tile_rotate(R, A, m.npad, PI0, PJ0, 0, PI1, PJ1, rbuf + g1 * JS * JS, rbuf + g0 * JS * JS, true);
+        const int lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+        if ((wave >> 1) == hp0 && (wave & 1) == hp1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int si = jacobi_seat_of(l4 + 4 * r, cross), sj = jacobi_seat_of(JB + l15, cross);
+                S[si * JLD + sj] = acc[r]; S[sj * JLD + si] = acc[r];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2 * JB * JB / SUB_THREADS; ++u) S[jacobi_seat_of(u * JB + tid / JB, cross) * JLD + jacobi_seat_of(u * JB + tid % JB, cross)] = dv[u];
+        __syncthreads();                                // the staging tile (in R) is read no more
     }
+    for (int e = tid; e < JS * JS; e += SUB_THREADS) R[(e / JS) * JLD + jacobi_seat_of(e % JS, cross)] = (e / JS == e % JS) ? 1.0 : 0.0;
     __syncthreads();
-    int final_buf = 0;
     {
         // convergence: off-diagonal mass relative to the diagonal (wave-uniform decision); the outer sweeps finish the job
         double off = 0.0, dg = 0.0;
@@ -175,158 +312,50 @@ jacobi_sub_kernel(const MatDesc* __restrict__ mats, const PairRef* __restrict__ 
             const int k = tid / JB, l = tid % JB;
             // loop-invariant LDS offsets (elements): the block this thread reads, and where its two rows / columns go
             const int r0 = 2 * k, r1 = 2 * k + 1, c0 = 2 * l, c1 = 2 * l + 1;
-            const int nr0 = jacobi_next_seat(r0), nr1 = jacobi_next_seat(r1), nc0 = jacobi_next_seat(c0), nc1 = jacobi_next_seat(c1);
+            const int nr0 = cross ? jacobi_next_seat_cross(r0) : jacobi_next_seat(r0), nr1 = cross ? jacobi_next_seat_cross(r1) : jacobi_next_seat(r1);
+            const int nc0 = cross ? jacobi_next_seat_cross(c0) : jacobi_next_seat(c0), nc1 = cross ? jacobi_next_seat_cross(c1) : jacobi_next_seat(c1);
+            const int nrounds = cross ? JB : JS - 1;
             const int in00 = r0 * JLD + c0, in01 = r0 * JLD + c1, in10 = r1 * JLD + c0, in11 = r1 * JLD + c1;
             const int so00 = nr0 * JLD + nc0, so01 = nr0 * JLD + nc1, so10 = nr1 * JLD + nc0, so11 = nr1 * JLD + nc1;     // S: rows and columns move
             const int ro00 = r0 * JLD + nc0, ro01 = r0 * JLD + nc1, ro10 = r1 * JLD + nc0, ro11 = r1 * JLD + nc1;         // R: only columns move
             const int piv = (2 * tid) * JLD + 2 * tid;                                                                  // lane t < JB: pivot block (2t, 2t+1)
-            constexpr int BUFSZ = JS * JLD;
-            int cur = 0;
 #pragma unroll 1
-            for (int rr = 0; rr < JS - 1; ++rr) {
-                const double* Sc = S + cur * BUFSZ; double* Sn = S + (cur ^ 1) * BUFSZ;
-                const double* Rc = R + cur * BUFSZ; double* Rn = R + (cur ^ 1) * BUFSZ;
+            for (int rr = 0; rr < nrounds; ++rr) {
                 if (tid < JB) {                                            // wave 0, JB lanes: one rotation each
                     double c, sn;
-                    jacobi_rotation(Sc[piv + 1], Sc[piv], Sc[piv + JLD + 1], c, sn);
+                    jacobi_rotation(S[piv + 1], S[piv], S[piv + JLD + 1], c, sn);
                     rot_c[tid] = c; rot_s[tid] = sn;
                 }
-                const double b00 = Sc[in00], b01 = Sc[in01], b10 = Sc[in10], b11 = Sc[in11];
-                const double q00 = Rc[in00], q01 = Rc[in01], q10 = Rc[in10], q11 = Rc[in11];
+                const double b00 = S[in00], b01 = S[in01], b10 = S[in10], b11 = S[in11];
+                const double q00 = R[in00], q01 = R[in01], q10 = R[in10], q11 = R[in11];
                 __syncthreads();
                 const double ck = rot_c[k], sk = rot_s[k], cl = rot_c[l], sl = rot_s[l];
                 const double t00 = cl * b00 - sl * b01, t01 = sl * b00 + cl * b01;
                 const double t10 = cl * b10 - sl * b11, t11 = sl * b10 + cl * b11;
-                Sn[so00] = ck * t00 - sk * t10; Sn[so01] = ck * t01 - sk * t11;
-                Sn[so10] = sk * t00 + ck * t10; Sn[so11] = sk * t01 + ck * t11;
-                Rn[ro00] = cl * q00 - sl * q01; Rn[ro01] = sl * q00 + cl * q01;
-                Rn[ro10] = cl * q10 - sl * q11; Rn[ro11] = sl * q10 + cl * q11;
+                S[so00] = ck * t00 - sk * t10; S[so01] = ck * t01 - sk * t11;
+                S[so10] = sk * t00 + ck * t10; S[so11] = sk * t01 + ck * t11;
+                R[ro00] = cl * q00 - sl * q01; R[ro01] = sl * q00 + cl * q01;
+                R[ro10] = cl * q10 - sl * q11; R[ro11] = sl * q10 + cl * q11;
                 __syncthreads();
-                cur ^= 1;
             }
-            final_buf = cur;
         }
     }
-    const double* Rf = R + final_buf * JS * JLD;
-    double* Rout = rbuf + (int64_t)blockIdx.x * JS * JS;
-    for (int e = tid; e < JS * JS; e += SUB_THREADS) Rout[e] = Rf[(e / JS) * JLD + (e % JS)];
-}
-
-typedef double jd4 __attribute__((ext_vector_type(4)));
-
-// One launch per round applies all rotations of the round:
-//   kind 0 (A, two-sided): block (P,Q), P <= Q, of the pair-block partition:  A[P,Q] <- R_P^T . A[P,Q] . R_Q, and its
-//                          transpose is written to A[Q,P] -- every JS x JS block of A is written by exactly one workgroup, the
-//                          column and the row update of the textbook formulation fuse into one pass over the upper
-//                          triangle, and A stays symmetric to the last bit;
-//   kind 1 (V, one-sided): rows [JS*t, JS*t+JS) x pair-block Q:      V[t,Q] <- V[t,Q] . R_Q
-// 256 threads = 2 x 2 waves, each wave owns a (JS/2) x (JS/2) quarter of the tile as NBK x NBK v_mfma_f64_16x16x4 accumulators
-// (fragment maps as in ggemm.hip: A[i = l&15][k = l>>4], B[k = l>>4][j = l&15], result col = l&15, row = (l>>4) + 4 reg); the
-// tile X goes through LDS, R_Q and R_P^T go from global memory straight into MFMA fragments.  (The plain-FMA version of these
-// products was LDS-bandwidth bound: the update ran at ~12 TF/s and took 70 % of the eigensolve at m = 2048.)
-__device__ __forceinline__ void jacobi_update_body(double* sh, const MatDesc* __restrict__ mats, const int32_t* __restrict__ pair_start, const UpdTask t,
-                                                   double* __restrict__ buf, const double* __restrict__ rbuf, int round)
-{
-    static_assert(JS == 32 || JS == 64, "update tile: 2 x 2 waves of (JS/32)^2 MFMA blocks");
-    constexpr int NBK = JS / 32, HALF = JS / 2, KG = JS / 4;
-    if (threadIdx.x >= 256) return;                   // riding along in a larger (sub-solve) workgroup: the first four waves work
-    double* X = sh;
-    const MatDesc m = mats[t.mat];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
-    int IQ, JQ, IP = 0, JP = 0;
-    pair_blocks(m.nb, round, t.q, IQ, JQ);
-    if (t.kind == 0) pair_blocks(m.nb, round, t.p, IP, JP);
-    const double* Rq = rbuf + (int64_t)(pair_start[t.mat] + t.q) * JS * JS;
-    const double* Rp = rbuf + (int64_t)(pair_start[t.mat] + t.p) * JS * JS;
-    double* M = buf + (t.kind == 0 ? m.a_off : m.v_off);
-    auto cq = [&](int j) { return j < JB ? IQ * JB + j : JQ * JB + j - JB; };
-    auto rp = [&](int i) { return t.kind == 0 ? (i < JB ? IP * JB + i : JP * JB + i - JB) : t.p * JS + i; };
-    const int l15 = lane & 15, l4 = lane >> 4;
-    // fragments: B operand of X . R_Q is R_Q[k][HALF wc + 16 nj + l15]; A operand of R_P^T . Y is R_P[k][HALF wr + 16 mi + l15]
-    double bq[KG][NBK], ap[KG][NBK];
-#pragma unroll
-    for (int g = 0; g < KG; ++g)
-#pragma unroll
-        for (int b = 0; b < NBK; ++b) {
-            bq[g][b] = Rq[(4 * g + l4) * JS + HALF * wc + 16 * b + l15];
-            ap[g][b] = (t.kind == 0) ? Rp[(4 * g + l4) * JS + HALF * wr + 16 * b + l15] : 0.0;
-        }
-    for (int e = tid; e < JS * JS; e += 256) {
-        const int i = e / JS, j = e % JS;
-        X[i * JLD + j] = M[(int64_t)rp(i) * m.npad + cq(j)];
+    double* Rout = rbuf_next + (int64_t)blockIdx.x * JS * JS;
+    for (int e = tid; e < JS * JS; e += SUB_THREADS) Rout[e] = R[(e / JS) * JLD + jacobi_seat_of(e % JS, cross)];
+    double* Dout = dbuf_next + (int64_t)blockIdx.x * 2 * JB * JB;
+    for (int e = tid; e < 2 * JB * JB; e += SUB_THREADS) {
+        const int h = e / (JB * JB), r = (e % (JB * JB)) / JB, c = e % JB;
+        Dout[e] = S[jacobi_seat_of(h * JB + r, cross) * JLD + jacobi_seat_of(h * JB + c, cross)];
     }
-    __syncthreads();
-    jd4 acc[NBK][NBK];
-#pragma unroll
-    for (int mi = 0; mi < NBK; ++mi)
-#pragma unroll
-        for (int nj = 0; nj < NBK; ++nj) acc[mi][nj] = (jd4){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int g = 0; g < KG; ++g)
-#pragma unroll
-        for (int mi = 0; mi < NBK; ++mi) {
-            const double xa = X[(HALF * wr + 16 * mi + l15) * JLD + 4 * g + l4];
-#pragma unroll
-            for (int nj = 0; nj < NBK; ++nj) acc[mi][nj] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa, bq[g][nj], acc[mi][nj], 0, 0, 0);      // X . R_Q
-        }
-    if (t.kind == 0) {
-        __syncthreads();
-#pragma unroll
-        for (int mi = 0; mi < NBK; ++mi)
-#pragma unroll
-            for (int nj = 0; nj < NBK; ++nj)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) X[(HALF * wr + 16 * mi + l4 + 4 * r) * JLD + HALF * wc + 16 * nj + l15] = acc[mi][nj][r];
-        __syncthreads();
-#pragma unroll
-        for (int mi = 0; mi < NBK; ++mi)
-#pragma unroll
-            for (int nj = 0; nj < NBK; ++nj) acc[mi][nj] = (jd4){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int g = 0; g < KG; ++g)
-#pragma unroll
-            for (int nj = 0; nj < NBK; ++nj) {
-                const double yb = X[(4 * g + l4) * JLD + HALF * wc + 16 * nj + l15];
-#pragma unroll
-                for (int mi = 0; mi < NBK; ++mi) acc[mi][nj] = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[g][mi], yb, acc[mi][nj], 0, 0, 0);  // R_P^T . (X . R_Q)
-            }
-    }
-#pragma unroll
-    for (int mi = 0; mi < NBK; ++mi)
-#pragma unroll
-        for (int nj = 0; nj < NBK; ++nj)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) M[(int64_t)rp(HALF * wr + 16 * mi + l4 + 4 * r) * m.npad + cq(HALF * wc + 16 * nj + l15)] = acc[mi][nj][r];
-    if (t.kind == 0 && t.p != t.q) {                              // mirror: A[Q,P] = (A[P,Q])^T, staged through LDS for row-wise stores
-        __syncthreads();
-#pragma unroll
-        for (int mi = 0; mi < NBK; ++mi)
-#pragma unroll
-            for (int nj = 0; nj < NBK; ++nj)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) X[(HALF * wr + 16 * mi + l4 + 4 * r) * JLD + HALF * wc + 16 * nj + l15] = acc[mi][nj][r];
-        __syncthreads();
-        for (int e = tid; e < JS * JS; e += 256) {
-            const int i = e / JS, j = e % JS;                     // element (i, j) of the transposed block
-            M[(int64_t)cq(i) * m.npad + rp(j)] = X[j * JLD + i];
-        }
-    }
-}
-
-__global__ void __launch_bounds__(256)
-jacobi_update_kernel(const MatDesc* __restrict__ mats, const int32_t* __restrict__ pair_start, const UpdTask* __restrict__ tasks,
-                     double* __restrict__ buf, const double* __restrict__ rbuf, int round)
-{
-    __shared__ double sh[JS * JLD];
-    jacobi_update_body(sh, mats, pair_start, tasks[blockIdx.x], buf, rbuf, round);
 }
 
 // per matrix and block of the grid: out[(mat*NORM_BLOCKS + b)*2] = partial sum of squares off the diagonal, [..+1] = on it
 constexpr int NORM_BLOCKS = 32;
-__global__ void __launch_bounds__(256) offnorm_kernel(const MatDesc* __restrict__ mats, const double* __restrict__ buf, double* __restrict__ out)
+__global__ void __launch_bounds__(256) offnorm_kernel(const MatDesc* __restrict__ mats, const double* __restrict__ buf, double* __restrict__ out, int flip)
 {
     __shared__ double r0[4], r1[4];
-    const MatDesc m = mats[blockIdx.y];
+    MatDesc m = mats[blockIdx.y];
+    if (flip) m.a_off = m.a2_off;
     double off = 0.0, dg = 0.0;
     const int64_t tot = (int64_t)m.npad * m.npad;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < tot; e += 256 * NORM_BLOCKS) {
@@ -499,6 +528,7 @@ static dmrgx_status rdm_create_impl(const dmrgx_sectors* left, const dmrgx_secto
             m.npad = ((m.n + JS - 1) / JS) * JS;
             m.nb = m.npad / JB;
             m.a_off = total; total += (int64_t)m.npad * m.npad;
+            m.a2_off = total; total += (int64_t)m.npad * m.npad;
             m.v_off = total; total += (int64_t)m.npad * m.npad;
             m.pad = 0;
             P->mats.push_back(m);
@@ -508,7 +538,7 @@ static dmrgx_status rdm_create_impl(const dmrgx_sectors* left, const dmrgx_secto
     const int64_t psiT_off = total; total += N;
     const int nm = (int)P->mats.size();
     std::vector<PairRef> pairs;
-    std::vector<UpdTask> tiles, vtiles;      // A updates (on the critical path of a round) / V updates (ride along with the next round's sub-solves)
+    std::vector<UpdTask> tiles;              // the A updates of a round, then its V updates
     std::vector<int32_t> pair_start(nm);
     int max_nb = 2;
     for (int mi = 0; mi < nm; ++mi) {
@@ -518,9 +548,13 @@ static dmrgx_status rdm_create_impl(const dmrgx_sectors* left, const dmrgx_secto
         const int np = m.nb / 2;
         for (int j = 0; j < np; ++j) pairs.push_back(PairRef{mi, j});
         for (int p = 0; p < np; ++p) for (int q = p; q < np; ++q) tiles.push_back(UpdTask{mi, p, q, 0});     // upper triangle; the kernel mirrors
-        for (int t = 0; t < m.npad / JS; ++t) for (int q = 0; q < np; ++q) vtiles.push_back(UpdTask{mi, t, q, 1});
     }
-    const int64_t rbuf_off = total, rbuf_len = (int64_t)pairs.size() * JS * JS; total += 2 * rbuf_len;    // two slots: round r and r-1
+    for (int mi = 0; mi < nm; ++mi) {
+        const MatDesc& m = P->mats[mi];
+        for (int t = 0; t < m.npad / JS; ++t) for (int q = 0; q < m.nb / 2; ++q) tiles.push_back(UpdTask{mi, t, q, 1});
+    }
+    const int64_t rbuf_off = total, rbuf_len = (int64_t)pairs.size() * JS * JS; total += 2 * rbuf_len;    // two slots: round r and r+1
+    const int64_t dbuf_off = total, dbuf_len = (int64_t)pairs.size() * 2 * JB * JB; total += 2 * dbuf_len;  // diagonal blocks handed from round to round
     const int64_t norm_off = total; total += 2 * nm * NORM_BLOCKS;
     std::vector<int64_t> diag_off(nm);
     int64_t dtot = 0;
@@ -553,17 +587,10 @@ static dmrgx_status rdm_create_impl(const dmrgx_sectors* left, const dmrgx_secto
     for (int mi = 0; mi < nm; ++mi) if (warm_src[mi] || qmats[mi].n) { const int64_t nn = (int64_t)P->mats[mi].n * P->mats[mi].n; warm_w[mi] = total; total += nn; warm_et[mi] = total; total += nn; }
     DMRGX_CHK(P->buf.alloc((size_t)total * sizeof(double)));
     double* buf = P->buf.as<double>();
-    DevBuf d_pairs, d_tiles, d_vtiles, d_doff, d_pstart;
+    DevBuf d_pairs, d_tiles, d_doff, d_pstart;
     DMRGX_CHK(upload(P->d_mats, P->mats, st));
     DMRGX_CHK(upload(d_pairs, pairs, st));
     DMRGX_CHK(upload(d_tiles, tiles, st));
-    DMRGX_CHK(upload(d_vtiles, vtiles, st));
-    // JB = 16: the eigenvector updates of a round ride along with the next round's sub-solves (4-wave workgroups, CUs mostly idle).
-    // JB = 32: the sub-solve workgroups have 16 waves and 133 KB of LDS -- no room for riders -- so the eigenvector updates join
-    // the update launch of their own round.
-    constexpr bool RIDE = (JB == 16);
-    DevBuf d_alltiles;
-    if (!RIDE) { std::vector<UpdTask> all(tiles); all.insert(all.end(), vtiles.begin(), vtiles.end()); DMRGX_CHK(upload(d_alltiles, all, st)); }
     DMRGX_CHK(upload(d_pstart, pair_start, st));
     for (auto& v : diag_off) v += diag_base;
     DMRGX_CHK(upload(d_doff, diag_off, st));
@@ -721,10 +748,10 @@ static dmrgx_status rdm_create_impl(const dmrgx_sectors* left, const dmrgx_secto
     // ---- batched block Jacobi ------------------------------------------------------------------------------------
     std::vector<double> norms((size_t)2 * nm * NORM_BLOCKS);
     const int rounds = std::max(1, max_nb - 1);
-    int sweep = 0, slot = 0, prev_round = 0;
-    bool pending_v = false;
+    int sweep = 0, slot = 0, flip = 0;
+    bool have_rot = false;                   // rbuf[slot] / dbuf[slot] hold the rotations of the round about to be applied
     for (; sweep < 30; ++sweep) {
-        hipLaunchKernelGGL(offnorm_kernel, dim3(NORM_BLOCKS, nm), dim3(256), 0, st, dm, buf, buf + norm_off);
+        hipLaunchKernelGGL(offnorm_kernel, dim3(NORM_BLOCKS, nm), dim3(256), 0, st, dm, buf, buf + norm_off, flip);
         DMRGX_HIP(hipGetLastError());
         DMRGX_HIP(hipMemcpyAsync(norms.data(), buf + norm_off, norms.size() * sizeof(double), hipMemcpyDeviceToHost, st));
         DMRGX_HIP(hipStreamSynchronize(st));
@@ -741,26 +768,27 @@ static dmrgx_status rdm_create_impl(const dmrgx_sectors* left, const dmrgx_secto
         }
         if (trace) fprintf(stderr, "[rdm] sweep %d: max off^2/total^2 = %.3e\n", sweep, worst);
         if (conv) break;
+        if (pairs.empty()) continue;
         for (int r = 0; r < rounds; ++r) {
             double* rcur = buf + rbuf_off + slot * rbuf_len;
-            const double* rprev = buf + rbuf_off + (slot ^ 1) * rbuf_len;
-            hipLaunchKernelGGL(jacobi_sub_kernel, dim3((unsigned)(pairs.size() + (RIDE && pending_v ? vtiles.size() : 0))), dim3(SUB_THREADS), 0, st, dm, d_pairs.as<PairRef>(),
-                               (int)pairs.size(), buf, rcur, r, d_vtiles.as<UpdTask>(), d_pstart.as<int32_t>(), rprev, prev_round);
-            if (!RIDE) {
-                hipLaunchKernelGGL(jacobi_update_kernel, dim3((unsigned)(tiles.size() + vtiles.size())), dim3(256), 0, st, dm, d_pstart.as<int32_t>(), d_alltiles.as<UpdTask>(), buf, (const double*)rcur, r);
+            double* rnext = buf + rbuf_off + (slot ^ 1) * rbuf_len;
+            double* dcur = buf + dbuf_off + slot * dbuf_len;
+            double* dnext = buf + dbuf_off + (slot ^ 1) * dbuf_len;
+            if (!have_rot) {                 // very first round: sub-solves alone, straight from A
+                hipLaunchKernelGGL(jacobi_round_kernel, dim3((unsigned)pairs.size()), dim3(SUB_THREADS), 0, st, dm, d_pairs.as<PairRef>(), (int)pairs.size(), buf, flip,
+                                   (const double*)rcur, (const double*)dcur, 0, 0, rcur, dcur, r, 0, d_tiles.as<UpdTask>(), d_pstart.as<int32_t>());
                 DMRGX_HIP(hipGetLastError());
-                prev_round = r; slot ^= 1;
-                continue;
+                have_rot = true;
             }
-            hipLaunchKernelGGL(jacobi_update_kernel, dim3((unsigned)tiles.size()), dim3(256), 0, st, dm, d_pstart.as<int32_t>(), d_tiles.as<UpdTask>(), buf, (const double*)rcur, r);
+            // apply round r (A_cur -> A_next, V in place) and, beside it, solve the sub-problems of the round after it
+            const int r_next = (r + 1 == rounds) ? 0 : r + 1;
+            static const bool cross_visits = !(getenv("DMRGX_JACOBI_CROSS") && atoi(getenv("DMRGX_JACOBI_CROSS")) == 0);   // developer aid: =0: every visit is a full cyclic sweep
+            const int cross_next = (cross_visits && r_next != 0) ? 1 : 0;      // the pairs inside a block: once per sweep, in its first round
+            hipLaunchKernelGGL(jacobi_round_kernel, dim3((unsigned)(pairs.size() + tiles.size())), dim3(SUB_THREADS), 0, st, dm, d_pairs.as<PairRef>(), (int)pairs.size(), buf, flip,
+                               (const double*)rcur, (const double*)dcur, r, 1, rnext, dnext, r_next, cross_next, d_tiles.as<UpdTask>(), d_pstart.as<int32_t>());
             DMRGX_HIP(hipGetLastError());
-            pending_v = !vtiles.empty(); prev_round = r; slot ^= 1;
+            slot ^= 1; flip ^= 1;
         }
-    }
-    if (pending_v) {      // the eigenvector update of the very last round
-        hipLaunchKernelGGL(jacobi_update_kernel, dim3((unsigned)vtiles.size()), dim3(256), 0, st, dm, d_pstart.as<int32_t>(), d_vtiles.as<UpdTask>(), buf,
-                           (const double*)(buf + rbuf_off + (slot ^ 1) * rbuf_len), prev_round);
-        DMRGX_HIP(hipGetLastError());
     }
     P->sweeps = sweep;
     if (sweep >= 30) DMRGX_FAIL(DMRGX_ERR_NOTCONV, "rdm_create: block Jacobi did not converge in 30 sweeps");

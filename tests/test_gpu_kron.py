@@ -654,7 +654,9 @@ def test_rdm_graded_spectrum_few_sweeps_and_warm_hints(mods):
     warm1 = sbm.ReducedDensityMatrices(lsz, rsz, blocks, d1, warm=warm)
     junk = {key: torch.from_numpy(np.linalg.qr(rng.standard_normal(tuple(t.shape)))[0]).cuda().contiguous() for key, t in warm.items()}
     junk1 = sbm.ReducedDensityMatrices(lsz, rsz, blocks, d1, warm=junk)
-    assert max(cold0.sweeps, cold1.sweeps, warm1.sweeps, junk1.sweeps) <= 6, (cold0.sweeps, cold1.sweeps, warm1.sweeps, junk1.sweeps)
+    # (a visit rotates the pairs between its two blocks; the pairs inside a block once per sweep -- one sweep more than with a
+    # full cyclic sweep per visit, at half the latency per round)
+    assert max(cold0.sweeps, cold1.sweeps, warm1.sweeps, junk1.sweeps) <= 7, (cold0.sweeps, cold1.sweeps, warm1.sweeps, junk1.sweeps)
     off = 0
     for k, (a, b) in enumerate(blocks):
         Psi = psi1[off:off + lsz[a] * rsz[b]].reshape(lsz[a], rsz[b]); off += lsz[a] * rsz[b]
