@@ -71,49 +71,6 @@ ggemm_kernel(const GTile* __restrict__ tiles, const GGroup* __restrict__ groups,
 #pragma unroll
         for (int ni = 0; ni < TC; ++ni) acc[mi][ni] = (d4){0.0, 0.0, 0.0, 0.0};
 
-    // ---- scaled-copy products (identity operator cells): acc += alpha * S[tile] ------------------------
-    // Two products per pass with all their loads issued before the first use: a scaled copy is a descriptor load followed by
-    // a tile load, and one at a time the chain of both latencies (~2.5 us) is paid per product.
-    int p = g.prod_begin;
-    const int axpy_end = p + g.n_axpy;
-    if (TR * TC <= 4) {
-        for (; p + 1 < axpy_end; p += 2) {
-            const GProd pa = prods[p], pb = prods[p + 1];
-            gptr Sa = (gptr)(pa.B + (size_t)m0 * pa.ldb + n0);
-            gptr Sb = (gptr)(pb.B + (size_t)m0 * pb.ldb + n0);
-            double va[TR][TC][4], vb[TR][TC][4];
-#pragma unroll
-            for (int mi = 0; mi < TR; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < TC; ++ni)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = min(wrow + mi * 16 + l4 + 4 * r, mrem - 1), col = min(wcol + ni * 16 + l15, nrem - 1);   // clamped: in bounds, never stored
-                        va[mi][ni][r] = Sa[(size_t)row * pa.ldb + col];
-                        vb[mi][ni][r] = Sb[(size_t)row * pb.ldb + col];
-                    }
-#pragma unroll
-            for (int mi = 0; mi < TR; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < TC; ++ni)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { acc[mi][ni][r] += pa.alpha * va[mi][ni][r]; acc[mi][ni][r] += pb.alpha * vb[mi][ni][r]; }
-        }
-    }
-    for (; p < axpy_end; ++p) {
-        const GProd pr = prods[p];
-        gptr S = (gptr)(pr.B + (size_t)m0 * pr.ldb + n0);
-#pragma unroll
-        for (int mi = 0; mi < TR; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < TC; ++ni)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = wrow + mi * 16 + l4 + 4 * r, col = wcol + ni * 16 + l15;
-                    if (row < mrem && col < nrem) acc[mi][ni][r] += pr.alpha * S[(size_t)row * pr.ldb + col];
-                }
-    }
-
     // ---- GEMM stream ------------------------------------------------------------------------------------
     // The MFMA pipe and the ordinary VALU do not co-issue on a SIMD (SQ_VALU_MFMA_COEXEC_CYCLES = 0 on gfx950), so every
     // vector integer instruction in the k-step loop is MFMA time lost.  The steady-state k-step therefore contains no
@@ -129,6 +86,7 @@ ggemm_kernel(const GTile* __restrict__ tiles, const GGroup* __restrict__ groups,
     unsigned aoff[NA], boff[NB];                   // per-thread byte offsets inside the current product's panels
     double ra[NA], rb[NB];
     const int pend = g.prod_end;
+    int p = g.prod_begin + g.n_axpy;
     int k0 = 0;
     const double *cA = nullptr, *cB = nullptr;     // current product, wave-uniform -> SGPRs
     int clda = 0, cldb = 0, cK = 0;
@@ -267,6 +225,50 @@ ggemm_kernel(const GTile* __restrict__ tiles, const GGroup* __restrict__ groups,
 #undef GG_PRODUCT
 #undef GG_GLOAD
 #undef GG_LSTORE
+
+    // ---- scaled-copy products (identity operator cells): acc += alpha * S[tile] ------------------------
+    // (after the GEMM stream: its 64 value registers then do not meet the stream's operand / fragment registers)
+    // Two products per pass with all their loads issued before the first use: a scaled copy is a descriptor load followed by
+    // a tile load, and one at a time the chain of both latencies (~2.5 us) is paid per product.
+    int q = g.prod_begin;
+    const int axpy_end = q + g.n_axpy;
+    if (TR * TC <= 4) {
+        for (; q + 1 < axpy_end; q += 2) {
+            const GProd pa = prods[q], pb = prods[q + 1];
+            gptr Sa = (gptr)(pa.B + (size_t)m0 * pa.ldb + n0);
+            gptr Sb = (gptr)(pb.B + (size_t)m0 * pb.ldb + n0);
+            double va[TR][TC][4], vb[TR][TC][4];
+#pragma unroll
+            for (int mi = 0; mi < TR; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < TC; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = min(wrow + mi * 16 + l4 + 4 * r, mrem - 1), col = min(wcol + ni * 16 + l15, nrem - 1);   // clamped: in bounds, never stored
+                        va[mi][ni][r] = Sa[(size_t)row * pa.ldb + col];
+                        vb[mi][ni][r] = Sb[(size_t)row * pb.ldb + col];
+                    }
+#pragma unroll
+            for (int mi = 0; mi < TR; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < TC; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { acc[mi][ni][r] += pa.alpha * va[mi][ni][r]; acc[mi][ni][r] += pb.alpha * vb[mi][ni][r]; }
+        }
+    }
+    for (; q < axpy_end; ++q) {
+        const GProd pr = prods[q];
+        gptr S = (gptr)(pr.B + (size_t)m0 * pr.ldb + n0);
+#pragma unroll
+        for (int mi = 0; mi < TR; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TC; ++ni)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = wrow + mi * 16 + l4 + 4 * r, col = wcol + ni * 16 + l15;
+                    if (row < mrem && col < nrem) acc[mi][ni][r] += pr.alpha * S[(size_t)row * pr.ldb + col];
+                }
+    }
 
     // ---- epilogue ---------------------------------------------------------------------------------------
     gwptr C = (gwptr)(g.C + (size_t)m0 * g.ldc + n0);
