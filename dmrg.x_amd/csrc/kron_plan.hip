@@ -663,7 +663,6 @@ extern "C" dmrgx_status dmrgx_kron_plan_create(const dmrgx_kron_desc* d, void* s
         }
     }
 
-    const int64_t ylen = (W == 1) ? N : seg_stride;
     const int64_t slab_base = arena_ops + arena_T;
     B.finalize_stage2(slab_base);
     const int64_t arena_slabs = B.slab_elems;
