@@ -364,7 +364,7 @@ extern "C" dmrgx_status dmrgx_eigs_lowest(dmrgx_kron_plan* plan, const dmrgx_eig
     double* nrm = c2 + (MAX_NCV + 2);                             // [1]
     auto Hrow = [&](int j) { return dScal.as<double>() + (size_t)j * row; };
     auto vec = [&](int j) { return V + (size_t)j * n; };
-    DMRGX_HIP(zero_async(dV.p, dV.bytes, st));
+    DMRGX_HIP(zero_async(dV.p, dV.bytes, st));        // (the Ritz-vector rotations read all m rows of V against zero-padded coefficients)
     DMRGX_HIP(zero_async(dW.p, dW.bytes, st));
     if (dist) DMRGX_HIP(zero_async(dX.p, dX.bytes, st));
 
@@ -584,8 +584,8 @@ static dmrgx_status eigs_davidson(dmrgx_kron_plan* plan, const dmrgx_eigs_opts* 
     double* nrm = c2 + (MAX_NCV + 2);
     auto vec = [&](int j) { return V + (size_t)j * n; };
     auto wvec = [&](int j) { return W + (size_t)j * n; };
-    DMRGX_HIP(zero_async(dV.p, dV.bytes, st));
-    DMRGX_HIP(zero_async(dW.p, dW.bytes, st));
+    // (every basis vector is written whole before it is read; only the padding of a striped segment relies on the initial zeros)
+    if (dist) { DMRGX_HIP(zero_async(dV.p, dV.bytes, st)); DMRGX_HIP(zero_async(dW.p, dW.bytes, st)); }
     DMRGX_HIP(zero_async(dT.p, dT.bytes, st));
     if (dist) DMRGX_HIP(zero_async(dX.p, dX.bytes, st));
     DMRGX_CHK(dmrgx_kron_diag(plan, dD.as<double>(), st));
