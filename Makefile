@@ -21,11 +21,11 @@ $(PKG)/libdmrgx_hip.so: $(HIP_OBJS)
 
 # host sweep engine (plain C++17 over the C ABI: no HIP headers needed)
 $(PKG)/dmrgx-square-lattice: $(HOST)/DMRG-SquareLattice.cpp $(HOST_HDRS) $(PKG)/libdmrgx_hip.so
-	g++ -std=c++17 -O2 -Wall -Wno-unused-variable -Iinclude -I$(HOST) $< -L$(PKG) -ldmrgx_hip -Wl,-rpath,'$$ORIGIN' -o $@
+	g++ -std=c++17 -O2 -pthread -Wall -Wno-unused-variable -Iinclude -I$(HOST) $< -L$(PKG) -ldmrgx_hip -Wl,-rpath,'$$ORIGIN' -o $@
 
 # host-logic test harness (runs without a GPU)
 $(PKG)/dmrgx-host-tool: $(HOST)/host_tool.cpp $(HOST_HDRS) $(PKG)/libdmrgx_hip.so
-	g++ -std=c++17 -O1 -Wall -Wno-unused-variable -Iinclude -I$(HOST) $< -L$(PKG) -ldmrgx_hip -Wl,-rpath,'$$ORIGIN' -o $@
+	g++ -std=c++17 -O1 -pthread -Wall -Wno-unused-variable -Iinclude -I$(HOST) $< -L$(PKG) -ldmrgx_hip -Wl,-rpath,'$$ORIGIN' -o $@
 
 # the reference's own driver source must compile against these headers (only where the reference tree is present)
 dropin-check:

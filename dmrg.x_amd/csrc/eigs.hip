@@ -566,6 +566,13 @@ static dmrgx_status eigs_davidson(dmrgx_kron_plan* plan, const dmrgx_eigs_opts* 
     const auto t_begin = std::chrono::steady_clock::now();
     const int nblk = DOT_BLOCKS;
 
+    static const bool trace_setup = getenv("DMRGX_EIGS_TRACE") != nullptr;      // developer aid: wall time of the set-up stages (synchronising)
+    auto mark = [&](const char* what) {
+        if (!trace_setup) return;
+        (void)hipStreamSynchronize(st);
+        fprintf(stderr, "[eigs gd] setup %-12s t = %.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
+    };
+    mark("enter");
     DevBuf dV, dW, dT, dX, dD, dTmp, dPartial, dScal, dY;
     DMRGX_CHK(dV.alloc((size_t)(m + 1) * n * sizeof(double)));
     DMRGX_CHK(dW.alloc((size_t)(m + 1) * n * sizeof(double)));
@@ -588,7 +595,9 @@ static dmrgx_status eigs_davidson(dmrgx_kron_plan* plan, const dmrgx_eigs_opts* 
     if (dist) { DMRGX_HIP(zero_async(dV.p, dV.bytes, st)); DMRGX_HIP(zero_async(dW.p, dW.bytes, st)); }
     DMRGX_HIP(zero_async(dT.p, dT.bytes, st));
     if (dist) DMRGX_HIP(zero_async(dX.p, dX.bytes, st));
+    mark("buffers");
     DMRGX_CHK(dmrgx_kron_diag(plan, dD.as<double>(), st));
+    mark("diagonal");
     const bool vec2 = (n % 2 == 0);
     auto allreduce = [&](double* buf, int64_t count) -> dmrgx_status {
         if (!dist) return DMRGX_OK;
@@ -640,6 +649,7 @@ static dmrgx_status eigs_davidson(dmrgx_kron_plan* plan, const dmrgx_eigs_opts* 
         DMRGX_HIP(hipStreamSynchronize(st));
     }
     DMRGX_CHK(orthonormalise_into(0, t, vec(0)));
+    mark("start vector");
 
     std::vector<double> G((size_t)m * m, 0.0), th, Y, hcol((size_t)MAX_NCV + 2), ydev;
     int j = 0, n_matvec = 0, restarts = 0, converged = 0;
@@ -672,7 +682,8 @@ static dmrgx_status eigs_davidson(dmrgx_kron_plan* plan, const dmrgx_eigs_opts* 
         DMRGX_HIP(hipStreamSynchronize(st));                                       // also: ydev may be reused
         resid = std::sqrt(std::max(r2, 0.0));
         static const bool trace = getenv("DMRGX_EIGS_TRACE") != nullptr;
-        if (trace) fprintf(stderr, "[eigs gd] matvec %d: theta %.12f  |r| %.3e  (target %.3e)\n", n_matvec, lambda, resid, tol * std::fabs(lambda));
+        if (trace) fprintf(stderr, "[eigs gd] matvec %d: theta %.12f  |r| %.3e  (target %.3e)  t = %.3f ms\n", n_matvec, lambda, resid, tol * std::fabs(lambda),
+                           std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
         if (resid <= tol * std::max(std::fabs(lambda), 1e-300) || mm == N) { converged = 1; break; }
         if (n_matvec >= max_mv) break;
         if (n_matvec >= 6 * m) {
@@ -737,6 +748,7 @@ static dmrgx_status eigs_davidson(dmrgx_kron_plan* plan, const dmrgx_eigs_opts* 
         stats->n_matvec = n_matvec; stats->n_restart = restarts; stats->converged = converged; stats->residual = resid;
         stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
     }
+    if (getenv("DMRGX_EIGS_TRACE")) fprintf(stderr, "[eigs gd] done: %d MatMults, %.3f ms\n", n_matvec, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
     if (!converged) DMRGX_FAIL(DMRGX_ERR_NOTCONV, "eigs_lowest (gd): not converged after %d MatMults (residual %.3e)", n_matvec, resid);
     return DMRGX_OK;
 }

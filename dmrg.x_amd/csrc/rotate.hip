@@ -185,20 +185,24 @@ extern "C" dmrgx_status dmrgx_rotate_ops(const dmrgx_sectors* old_sectors, const
         ggemm_append_tiles_mixed(tBb, tB, (int32_t)groups.size() - 1, m, mp, cost);
     }
     const auto h1 = std::chrono::steady_clock::now();
-    ggemm_schedule(tA); ggemm_schedule(tAb, 2); ggemm_schedule(tB); ggemm_schedule(tBb, 2);
+    // stage A goes to the device before stage B's tile lists are scheduled: the host work of B (a sort over ~10^4 tiles) then
+    // runs behind A's GEMMs instead of in front of an idle GPU
+    ggemm_schedule(tA); ggemm_schedule(tAb, 2);
     const auto h2 = std::chrono::steady_clock::now();
     DevBuf dp, dg, d1, d2, d3, d4;
     DMRGX_CHK(upload(dp, prods, st)); DMRGX_CHK(upload(dg, groups, st));
-    DMRGX_CHK(upload(d1, tAb, st)); DMRGX_CHK(upload(d2, tA, st)); DMRGX_CHK(upload(d3, tBb, st)); DMRGX_CHK(upload(d4, tB, st));
+    DMRGX_CHK(upload(d1, tAb, st)); DMRGX_CHK(upload(d2, tA, st));
     const auto h3 = std::chrono::steady_clock::now();
     static const bool trace = getenv("DMRGX_ROT_TRACE") != nullptr;      // developer aid: flops and time of the two stages
-    if (trace) fprintf(stderr, "[rotate] host: tables %.3f ms, schedule %.3f ms, uploads %.3f ms\n", std::chrono::duration<double, std::milli>(h1 - h0).count(),
+    if (trace) fprintf(stderr, "[rotate] host: tables %.3f ms, schedule A %.3f ms, uploads A %.3f ms\n", std::chrono::duration<double, std::milli>(h1 - h0).count(),
                        std::chrono::duration<double, std::milli>(h2 - h1).count(), std::chrono::duration<double, std::milli>(h3 - h2).count());
     hipEvent_t ev[3];
     if (trace) { for (auto& e : ev) DMRGX_HIP(hipEventCreate(&e)); DMRGX_HIP(hipEventRecord(ev[0], st)); }
     DMRGX_CHK(ggemm_launch(d1.as<GTile>(), dg.as<GGroup>(), dp.as<GProd>(), (int32_t)tAb.size(), st, 1));
     DMRGX_CHK(ggemm_launch(d2.as<GTile>(), dg.as<GGroup>(), dp.as<GProd>(), (int32_t)tA.size(), st, 0));
     if (trace) DMRGX_HIP(hipEventRecord(ev[1], st));
+    ggemm_schedule(tB); ggemm_schedule(tBb, 2);
+    DMRGX_CHK(upload(d3, tBb, st)); DMRGX_CHK(upload(d4, tB, st));
     DMRGX_CHK(ggemm_launch(d3.as<GTile>(), dg.as<GGroup>(), dp.as<GProd>(), (int32_t)tBb.size(), st, 1));
     DMRGX_CHK(ggemm_launch(d4.as<GTile>(), dg.as<GGroup>(), dp.as<GProd>(), (int32_t)tB.size(), st, 0));
     if (trace) {

@@ -26,6 +26,11 @@
 #include <set>
 #include <string>
 #include <vector>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include "DMRGKron.hpp"
 
 /** One eigenpair of a reduced-density-matrix block */
@@ -44,6 +49,52 @@ struct Op {
     Op_t     OpType;
     PetscInt idx;
     PetscErrorCode PrintInfo() const { std::cout << "  Op" << OpToStr(OpType) << idx << std::endl; return 0; }
+};
+
+/** Formats and writes records off the sweep's critical path: a step's entanglement spectra are ~8 k numbers (1 ms of fprintf
+    at m = 2048, with the GPU idle behind it); the step hands them over and goes on.  One worker, jobs run in submission order;
+    Drain() returns when everything handed over so far is in the file. */
+class BackgroundWriter {
+public:
+    void Push(std::function<void()> job)
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        if (!worker.joinable()) worker = std::thread([this] { Run(); });
+        jobs.push_back(std::move(job));
+        cv.notify_one();
+    }
+    void Drain()
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        idle.wait(lk, [this] { return jobs.empty() && !busy; });
+    }
+    ~BackgroundWriter()
+    {
+        { std::unique_lock<std::mutex> lk(mu); stop = true; cv.notify_one(); }
+        if (worker.joinable()) worker.join();
+    }
+private:
+    void Run()
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv.wait(lk, [this] { return stop || !jobs.empty(); });
+            if (jobs.empty()) return;                       /* stop requested and nothing left */
+            std::function<void()> job = std::move(jobs.front());
+            jobs.pop_front();
+            busy = true;
+            lk.unlock();
+            job();
+            lk.lock();
+            busy = false;
+            if (jobs.empty()) idle.notify_all();
+        }
+    }
+    std::thread worker;
+    std::mutex mu;
+    std::condition_variable cv, idle;
+    std::deque<std::function<void()>> jobs;
+    bool stop = false, busy = false;
 };
 
 template<class Block, class Hamiltonian> class DMRGBlockContainer
@@ -360,6 +411,7 @@ public:
         PetscErrorCode ierr = SingleSite.Destroy(); CHKERRQ(ierr);
         if (fp_step) { fprintf(fp_step, "\n  ]\n}\n"); fclose(fp_step); fp_step = NULL; }
         if (fp_timings) { fprintf(fp_timings, "\n  ]\n}\n"); fclose(fp_timings); fp_timings = NULL; }
+        spectra_writer.Drain();
         if (fp_entanglement) { fprintf(fp_entanglement, "\n]\n"); fclose(fp_entanglement); fp_entanglement = NULL; }
         if (fp_kron) { fprintf(fp_kron, "\n]\n"); fclose(fp_kron); fp_kron = NULL; }
         if (fp_corr) {
@@ -571,18 +623,6 @@ public:
         }
         return 0;
     }
-    /** Transposed copy (n x kept) of a rotation block (kept x n) on the device. */
-    static std::shared_ptr<dmrgx_host::DevBuffer> TransposedCopy(const std::shared_ptr<dmrgx_host::DevBuffer>& rt, int32_t kept, int32_t n)
-    {
-        auto t = std::make_shared<dmrgx_host::DevBuffer>((size_t)kept * n, dmrgx_host::DevBuffer::device_only_t{});
-        if ((size_t)kept * n == 0) return t;
-        if (dmrgx_memset_zero(t->dev_uninitialised(), (size_t)kept * n * sizeof(double), nullptr)) throw std::runtime_error(dmrgx_last_error());
-        dmrgx_axpy_task k;
-        k.dst = t->dev_uninitialised(); k.dst_base = nullptr; k.src = rt->dev_ro(); k.ldd = kept; k.lds = n; k.nr = n; k.nc = kept; k.transposed = 1; k.alpha = 1.0;
-        if (dmrgx_cells_axpy(1, &k, nullptr)) throw std::runtime_error(dmrgx_last_error());
-        return t;
-    }
-
     /** Fills `guess` (device, layout of KronBlocks) from the previous step if the two steps are consecutive positions
         of a sweep; returns used = false (guess untouched) otherwise or when any dimension does not line up. */
     PetscErrorCode TransformedGuess(KronBlocks_t& KronBlocks, Block& SysBlock, Block& EnvBlock, const Vec& guess, bool& used)
@@ -630,7 +670,32 @@ public:
         std::vector<PhiBlock> phis;
         std::vector<dmrgx_gemm_task> t1;
         int64_t phi_total = 0;
-        std::vector<std::shared_ptr<dmrgx_host::DevBuffer>> GT((size_t)nG), ST((size_t)nS);   /* transposed copies, made on demand */
+        /* transposed copies of the rotation blocks (the right-growing case multiplies from the other side): one arena, one
+           memset and one batched transpose instead of a buffer, a memset and a launch per sector */
+        std::vector<const double*> GT((size_t)nG, nullptr), ST((size_t)nS, nullptr);
+        std::shared_ptr<dmrgx_host::DevBuffer> tarena;
+        if (!grow_left) {
+            std::vector<dmrgx_axpy_task> tr;
+            std::vector<int64_t> off;
+            int64_t tot = 0;
+            auto add = [&](const std::shared_ptr<dmrgx_host::DevBuffer>& rt, int32_t kept, int32_t n) {
+                dmrgx_axpy_task k;
+                k.dst = nullptr; k.dst_base = nullptr; k.src = rt->dev_ro(); k.ldd = kept; k.lds = n; k.nr = n; k.nc = kept; k.transposed = 1; k.alpha = 1.0;
+                tr.push_back(k); off.push_back(tot); tot += (int64_t)kept * n;
+            };
+            std::vector<int32_t> ia, ij;
+            for (int32_t a = 0; a < nG; ++a) if (G->kept[(size_t)a] > 0 && G->rt[(size_t)a]) { add(G->rt[(size_t)a], G->kept[(size_t)a], G->old_sizes[(size_t)G->old_sector[(size_t)a]]); ia.push_back(a); }
+            for (int32_t j = 0; j < nS; ++j) if (S->kept[(size_t)j] > 0 && S->rt[(size_t)j]) { add(S->rt[(size_t)j], S->kept[(size_t)j], S->old_sizes[(size_t)S->old_sector[(size_t)j]]); ij.push_back(j); }
+            if (tot > 0) {
+                tarena = std::make_shared<dmrgx_host::DevBuffer>((size_t)tot, dmrgx_host::DevBuffer::device_only_t{});
+                double* base = tarena->dev_uninitialised();
+                if (dmrgx_memset_zero(base, (size_t)tot * sizeof(double), nullptr)) SETERRQ1(mpi_comm, 1, "%s", dmrgx_last_error());
+                for (size_t i = 0; i < tr.size(); ++i) tr[i].dst = base + off[i];
+                if (dmrgx_cells_axpy((int32_t)tr.size(), tr.data(), nullptr)) SETERRQ1(mpi_comm, 1, "wavefunction transformation: %s", dmrgx_last_error());
+                for (size_t i = 0; i < ia.size(); ++i) GT[(size_t)ia[i]] = base + off[i];
+                for (size_t i = 0; i < ij.size(); ++i) ST[(size_t)ij[i]] = base + off[ia.size() + i];
+            }
+        }
         const double* x = prev.psi->buf->dev_ro();
         for (const auto& kb : prev.kb) {
             const int32_t IL = (int32_t)kb[0], IR = (int32_t)kb[1], nL = (int32_t)kb[2], nR = (int32_t)kb[3];
@@ -663,8 +728,8 @@ public:
                     if (grow_left)          /* (ka x nL) . (nL x nR) */
                         t1.push_back(dmrgx_gemm_task{ka, nR, nL, 0, G->rt[(size_t)a]->dev_ro(), nL, x + kb[4], nR, ph + pb.off, nR});
                     else {                  /* (nL x nR) . (nR x ka) */
-                        if (!GT[(size_t)a]) GT[(size_t)a] = TransposedCopy(G->rt[(size_t)a], ka, nR);
-                        t1.push_back(dmrgx_gemm_task{nL, ka, nR, 0, x + kb[4], nR, GT[(size_t)a]->dev_ro(), ka, ph + pb.off, ka});
+                        if (!GT[(size_t)a]) return 0;
+                        t1.push_back(dmrgx_gemm_task{nL, ka, nR, 0, x + kb[4], nR, GT[(size_t)a], ka, ph + pb.off, ka});
                     }
                 }
             }
@@ -691,9 +756,9 @@ public:
                     t2.push_back(dmrgx_gemm_task{pb.rows, nJ, e.size, 0, ph + pb.off + e.off, pb.cols, S->rt[(size_t)j]->dev_ro(), nJ,
                                                  y + base + (int64_t)goff * ldn, ldn});
                 } else {                    /* rows = all of new sys sector Jnew, cols = growing part (ka) at column offset goff */
-                    if (!ST[(size_t)j]) ST[(size_t)j] = TransposedCopy(S->rt[(size_t)j], e.size, nJ);
+                    if (!ST[(size_t)j]) return 0;
                     const int32_t ldn = grow_sizes[(size_t)Inew];
-                    t2.push_back(dmrgx_gemm_task{nJ, pb.cols, e.size, 0, ST[(size_t)j]->dev_ro(), e.size, ph + pb.off + (int64_t)e.off * pb.cols, pb.cols,
+                    t2.push_back(dmrgx_gemm_task{nJ, pb.cols, e.size, 0, ST[(size_t)j], e.size, ph + pb.off + (int64_t)e.off * pb.cols, pb.cols,
                                                  y + base + goff, ldn});
                 }
             }
@@ -1283,19 +1348,32 @@ private:
     /** Per-sector RDM eigenvalues of one side, in the reference's EntanglementSpectra.json layout. */
     PetscErrorCode SaveEntanglementSpectrum(int side, const std::vector<Eigen_t>& eigen, const QuantumNumbers& qn)
     {
-        if (side == 0) fprintf(fp_entanglement, "%s  {\n    \"GlobIdx\": %lld,\n", rows_written ? ",\n" : "", LLD(GlobIdx));
-        fprintf(fp_entanglement, "    \"%s\": [\n", side == 0 ? "Sys" : "Env");
-        PetscInt prev = -1; bool first_sector = true;
-        for (const Eigen_t& e : eigen) {
-            if (e.blkIdx != prev) {
-                if (!first_sector) fprintf(fp_entanglement, "] },\n");
-                fprintf(fp_entanglement, "      {\"sector\": %g, \"vals\": [ %g", qn.List(e.blkIdx), e.eigval);
-                prev = e.blkIdx; first_sector = false;
-            } else fprintf(fp_entanglement, ", %g", e.eigval);
-        }
-        if (!first_sector) fprintf(fp_entanglement, "] }\n");
-        fprintf(fp_entanglement, side == 0 ? "    ],\n" : "    ]\n  }");
-        fflush(fp_entanglement);
+        if (!fp_entanglement || mpi_rank) return 0;
+        /* what the record needs, by value: (sector quantum number, eigenvalue) in the order given */
+        auto rec = std::make_shared<std::vector<std::pair<double, double>>>();
+        rec->reserve(eigen.size());
+        for (const Eigen_t& e : eigen) rec->push_back({(double)qn.List(e.blkIdx), (double)e.eigval});
+        auto blk = std::make_shared<std::vector<PetscInt>>();
+        blk->reserve(eigen.size());
+        for (const Eigen_t& e : eigen) blk->push_back(e.blkIdx);
+        FILE* fp = fp_entanglement;
+        const bool first_row = rows_written == 0;
+        const long long glob = (long long)GlobIdx;
+        spectra_writer.Push([fp, side, first_row, glob, rec, blk] {
+            if (side == 0) fprintf(fp, "%s  {\n    \"GlobIdx\": %lld,\n", first_row ? "" : ",\n", glob);
+            fprintf(fp, "    \"%s\": [\n", side == 0 ? "Sys" : "Env");
+            PetscInt prev = -1; bool first_sector = true;
+            for (size_t i = 0; i < rec->size(); ++i) {
+                if ((*blk)[i] != prev) {
+                    if (!first_sector) fprintf(fp, "] },\n");
+                    fprintf(fp, "      {\"sector\": %g, \"vals\": [ %g", (*rec)[i].first, (*rec)[i].second);
+                    prev = (*blk)[i]; first_sector = false;
+                } else fprintf(fp, ", %g", (*rec)[i].second);
+            }
+            if (!first_sector) fprintf(fp, "] }\n");
+            fprintf(fp, side == 0 ? "    ],\n" : "    ]\n  }");
+            fflush(fp);
+        });
         return 0;
     }
 
@@ -1309,6 +1387,7 @@ private:
     int32_t eps_method = 0;         /* -H_eps_type: 0 krylovschur (thick-restart Lanczos), 1 gd (generalized Davidson, diagonal preconditioner) */
     std::string scratch_dir, data_dir;
     FILE *fp_step = NULL, *fp_timings = NULL, *fp_entanglement = NULL, *fp_data = NULL, *fp_corr = NULL, *fp_kron = NULL;
+    BackgroundWriter spectra_writer;           /* EntanglementSpectra.json records are formatted and written off the critical path */
     PetscInt kron_rows = 0;
     PetscBool prune_ops = PETSC_TRUE;          /* -prune_ops 0: rotate and keep every site operator of every block, as the reference does */
     PetscBool step_profile = PETSC_FALSE;      /* -step_profile 1: HIP-event timing of the GEMM stages of every MatMult (KronStats.json) */
