@@ -373,6 +373,13 @@ def test_container_smoke_of_the_reference(tmp_path):
     assert by_m[40] <= by_m[30] + 1e-9 <= by_m[20] + 2e-9
     for name in ("EntanglementSpectra.json", "Correlations.json", "Timings.json"):
         json.load(open(str(tmp_path) + "/" + name))
+    # the spectra are written by a background writer: one record per step, in step order, both sides, normalised spectra
+    spec = json.load(open(str(tmp_path) + "/EntanglementSpectra.json"))
+    assert [r["GlobIdx"] for r in spec] == [r["GlobIdx"] for r in rows]
+    for r in spec:
+        for side in ("Sys", "Env"):
+            tot = sum(sum(s["vals"]) for s in r[side])
+            assert r[side] and abs(tot - 1.0) <= 1e-5, (r["GlobIdx"], side, tot)
 
 
 def test_spin_one_chain_matches_exact_diagonalisation(tmp_path):
