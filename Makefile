@@ -27,6 +27,16 @@ $(PKG)/dmrgx-square-lattice: $(HOST)/DMRG-SquareLattice.cpp $(HOST_HDRS) $(PKG)/
 $(PKG)/dmrgx-host-tool: $(HOST)/host_tool.cpp $(HOST_HDRS) $(PKG)/libdmrgx_hip.so
 	g++ -std=c++17 -O1 -pthread -Wall -Wno-unused-variable -Iinclude -I$(HOST) $< -L$(PKG) -ldmrgx_hip -Wl,-rpath,'$$ORIGIN' -o $@
 
+# measurement probes (developer tools; not part of `all`): the library kernel on synthetic products, the barrier-free
+# one-wave-per-tile prototype it is compared with, the bare-MFMA ceiling
+probes: tools/ggemm_probe tools/wgemm_probe tools/mfma_f64_probe
+tools/ggemm_probe: tools/ggemm_probe.hip $(PKG)/libdmrgx_hip.so
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -Iinclude -I$(CSRC) $< -L$(PKG) -ldmrgx_hip -Wl,-rpath,'$$ORIGIN/../$(PKG)' -o $@
+tools/wgemm_probe: tools/wgemm_probe.hip
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 $< -o $@
+tools/mfma_f64_probe: tools/mfma_f64_probe.hip
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 $< -o $@
+
 # the reference's own driver source must compile against these headers (only where the reference tree is present)
 dropin-check:
 	g++ -std=c++17 -fsyntax-only -Iinclude -I$(HOST) /root/reference/src/DMRG-SquareLattice.cpp && echo "drop-in OK: reference src/DMRG-SquareLattice.cpp compiles against dmrg.x_amd/host headers"
@@ -38,4 +48,4 @@ oracle/liboracle_kron.so: oracle/kron_ref.c
 clean:
 	rm -f $(HIP_OBJS) $(PKG)/libdmrgx_hip.so $(PKG)/dmrgx-square-lattice $(PKG)/dmrgx-host-tool oracle/liboracle_kron.so
 
-.PHONY: all clean dropin-check
+.PHONY: all clean dropin-check probes
