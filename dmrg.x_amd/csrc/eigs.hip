@@ -655,6 +655,16 @@ static dmrgx_status eigs_davidson(dmrgx_kron_plan* plan, const dmrgx_eigs_opts* 
     int j = 0, n_matvec = 0, restarts = 0, converged = 0;
     double lambda = 0.0, resid = 0.0;
     const double floor_rel = 1e-3;
+    // Ritz problem, warm-started: in the basis [previous Ritz vectors | new direction] the projected matrix is an arrowhead
+    // (diag(theta_prev) bordered by one row), which cyclic Jacobi finishes in 2-3 sweeps instead of 8 from G itself
+    std::vector<double> Yp, thp;                // previous Ritz basis (mp x mp, columns) and values; empty: none
+    int mp = 0;
+    // the residual norm comes back through pinned memory behind an event, so that the orthogonalisation of the next direction is
+    // already queued when the host waits for it
+    static double* h_r2 = nullptr;
+    static hipEvent_t ev_r2 = nullptr;
+    if (!h_r2) { DMRGX_HIP(hipHostMalloc((void**)&h_r2, 64, hipHostMallocDefault)); DMRGX_HIP(hipEventCreateWithFlags(&ev_r2, hipEventDisableTiming)); }
+    bool ritz_is_v0 = false;                    // a restart has just made the Ritz vector the first basis vector
     while (true) {
         DMRGX_CHK(matvec(vec(j), wvec(j)));
         ++n_matvec;
@@ -663,10 +673,28 @@ static dmrgx_status eigs_davidson(dmrgx_kron_plan* plan, const dmrgx_eigs_opts* 
         DMRGX_HIP(hipStreamSynchronize(st));
         for (int i = 0; i <= j; ++i) { G[(size_t)i * m + j] = hcol[(size_t)i]; G[(size_t)j * m + i] = hcol[(size_t)i]; }
         const int mm = j + 1;
-        std::vector<double> A((size_t)mm * mm);
-        for (int a = 0; a < mm; ++a) for (int b = 0; b < mm; ++b) A[(size_t)a * mm + b] = G[(size_t)a * m + b];
-        jacobi_eigh(mm, A, th, Y);
+        std::vector<double> A((size_t)mm * mm, 0.0);
+        if (mp == mm - 1 && mp > 0) {
+            for (int i = 0; i < mp; ++i) {
+                A[(size_t)i * mm + i] = thp[(size_t)i];
+                double bi = 0.0;
+                for (int k = 0; k < mp; ++k) bi += Yp[(size_t)k * mp + i] * G[(size_t)k * m + j];
+                A[(size_t)i * mm + mp] = bi; A[(size_t)mp * mm + i] = bi;
+            }
+            A[(size_t)mp * mm + mp] = G[(size_t)j * m + j];
+            std::vector<double> Qa;
+            jacobi_eigh(mm, A, th, Qa);
+            Y.assign((size_t)mm * mm, 0.0);                                          // Y = blkdiag(Yp, 1) . Qa
+            for (int i = 0; i < mp; ++i)
+                for (int c = 0; c < mm; ++c) { double v = 0.0; for (int k = 0; k < mp; ++k) v += Yp[(size_t)i * mp + k] * Qa[(size_t)k * mm + c]; Y[(size_t)i * mm + c] = v; }
+            for (int c = 0; c < mm; ++c) Y[(size_t)mp * mm + c] = Qa[(size_t)mp * mm + c];
+        } else {
+            for (int a2 = 0; a2 < mm; ++a2) for (int b2 = 0; b2 < mm; ++b2) A[(size_t)a2 * mm + b2] = G[(size_t)a2 * m + b2];
+            jacobi_eigh(mm, A, th, Y);
+        }
+        Yp = Y; thp = th; mp = mm;
         lambda = th[0];
+        ritz_is_v0 = false;
         ydev.assign((size_t)mm, 0.0);
         for (int i = 0; i < mm; ++i) ydev[(size_t)i] = Y[(size_t)i * mm + 0];
         DMRGX_HIP(h2d_async(dY.p, ydev.data(), ydev.size() * sizeof(double), st));
@@ -677,10 +705,37 @@ static dmrgx_status eigs_davidson(dmrgx_kron_plan* plan, const dmrgx_eigs_opts* 
         hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(DOT_THREADS), 0, st, dPartial.as<double>(), nrm, 1, nblk);
         DMRGX_HIP(hipGetLastError());
         DMRGX_CHK(allreduce(nrm, 1));
-        double r2 = 0.0;
-        DMRGX_HIP(hipMemcpyAsync(&r2, nrm, sizeof(double), hipMemcpyDeviceToHost, st));
-        DMRGX_HIP(hipStreamSynchronize(st));                                       // also: ydev may be reused
-        resid = std::sqrt(std::max(r2, 0.0));
+        DMRGX_HIP(hipMemcpyAsync(h_r2, nrm, sizeof(double), hipMemcpyDeviceToHost, st));
+        DMRGX_HIP(hipEventRecord(ev_r2, st));
+        // queued behind the read-back, before the host looks at it: the restart (when the basis is full) and the next direction
+        const bool may_continue = mm < N && n_matvec < max_mv && n_matvec < 6 * m;
+        if (may_continue) {
+            if (mm == m) {
+                // thick restart: the kk lowest Ritz vectors span the new basis (V <- V Y, W <- W Y, G <- diag(theta))
+                static const int kk_env = getenv("DMRGX_GD_KEEP") ? atoi(getenv("DMRGX_GD_KEEP")) : 0;
+                const int kk = std::max(1, std::min(kk_env > 0 ? kk_env : m / 2, m - 1));      // as many as the Lanczos path keeps: a slowly converging solve loses too much with fewer
+                std::vector<double> Q((size_t)m * kk);
+                for (int i = 0; i < m; ++i) for (int b2 = 0; b2 < kk; ++b2) Q[(size_t)i * kk + b2] = Y[(size_t)i * m + b2];
+                DMRGX_HIP(h2d_async(dY.p, Q.data(), Q.size() * sizeof(double), st));
+                for (double* B : {V, W}) {
+                    hipLaunchKernelGGL(basis_rotate_kernel, dim3(1024, (kk + DOT_CHUNK - 1) / DOT_CHUNK), dim3(DOT_THREADS), 0, st, (const double*)B, n, m, (const double*)dY.as<double>(), kk, kk,
+                                       dTmp.as<double>(), n, n);
+                    DMRGX_HIP(hipGetLastError());
+                    DMRGX_HIP(hipMemcpyAsync(B, dTmp.p, (size_t)kk * n * sizeof(double), hipMemcpyDeviceToDevice, st));
+                }
+                std::fill(G.begin(), G.end(), 0.0);
+                for (int i = 0; i < kk; ++i) G[(size_t)i * m + i] = th[(size_t)i];
+                Yp.assign((size_t)kk * kk, 0.0);
+                for (int i = 0; i < kk; ++i) Yp[(size_t)i * kk + i] = 1.0;
+                thp.assign(th.begin(), th.begin() + kk); mp = kk;
+                j = kk - 1;
+                ++restarts;
+                ritz_is_v0 = true;
+            }
+            DMRGX_CHK(orthonormalise_into(j + 1, t, vec(j + 1)));                 // next basis vector from the preconditioned residual
+        }
+        DMRGX_HIP(hipEventSynchronize(ev_r2));
+        resid = std::sqrt(std::max(*h_r2, 0.0));
         static const bool trace = getenv("DMRGX_EIGS_TRACE") != nullptr;
         if (trace) fprintf(stderr, "[eigs gd] matvec %d: theta %.12f  |r| %.3e  (target %.3e)  t = %.3f ms\n", n_matvec, lambda, resid, tol * std::fabs(lambda),
                            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
@@ -705,33 +760,17 @@ static dmrgx_status eigs_davidson(dmrgx_kron_plan* plan, const dmrgx_eigs_opts* 
                          stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(); }
             return rc;
         }
-        if (mm == m) {
-            // thick restart: the kk lowest Ritz vectors span the new basis (V <- V Y, W <- W Y, G <- diag(theta))
-            static const int kk_env = getenv("DMRGX_GD_KEEP") ? atoi(getenv("DMRGX_GD_KEEP")) : 0;
-            const int kk = std::max(1, std::min(kk_env > 0 ? kk_env : m / 2, m - 1));      // as many as the Lanczos path keeps: a slowly converging solve loses too much with fewer
-            std::vector<double> Q((size_t)m * kk);
-            for (int i = 0; i < m; ++i) for (int b = 0; b < kk; ++b) Q[(size_t)i * kk + b] = Y[(size_t)i * m + b];
-            DMRGX_HIP(h2d_async(dY.p, Q.data(), Q.size() * sizeof(double), st));
-            for (double* B : {V, W}) {
-                hipLaunchKernelGGL(basis_rotate_kernel, dim3(1024, (kk + DOT_CHUNK - 1) / DOT_CHUNK), dim3(DOT_THREADS), 0, st, (const double*)B, n, m, (const double*)dY.as<double>(), kk, kk,
-                                   dTmp.as<double>(), n, n);
-                DMRGX_HIP(hipGetLastError());
-                DMRGX_HIP(hipMemcpyAsync(B, dTmp.p, (size_t)kk * n * sizeof(double), hipMemcpyDeviceToDevice, st));
-            }
-            DMRGX_HIP(hipStreamSynchronize(st));                                   // Q goes out of scope
-            std::fill(G.begin(), G.end(), 0.0);
-            for (int i = 0; i < kk; ++i) G[(size_t)i * m + i] = th[(size_t)i];
-            j = kk - 1;
-            ++restarts;
-        }
-        DMRGX_CHK(orthonormalise_into(j + 1, t, vec(j + 1)));                     // next basis vector from the preconditioned residual
         ++j;
     }
+    DMRGX_HIP(hipStreamSynchronize(st));                                           // (host vectors of queued uploads go out of scope below)
     // ---- eigenvector: psi = V y, renormalised --------------------------------------------------------------------------------
     {
-        const int mm = j + 1;
+        // the Ritz vector: V y in the basis the Ritz problem was solved in -- or, when a restart has been queued since, simply the
+        // first vector of the new basis
+        const int mm = ritz_is_v0 ? 1 : j + 1;
         ydev.assign((size_t)mm, 0.0);
-        for (int i = 0; i < mm; ++i) ydev[(size_t)i] = Y[(size_t)i * mm + 0];
+        if (ritz_is_v0) ydev[0] = 1.0;
+        else for (int i = 0; i < mm; ++i) ydev[(size_t)i] = Y[(size_t)i * mm + 0];
         DMRGX_HIP(h2d_async(dY.p, ydev.data(), ydev.size() * sizeof(double), st));
         hipLaunchKernelGGL(basis_rotate_kernel, dim3(1024, 1), dim3(DOT_THREADS), 0, st, (const double*)V, n, mm, (const double*)dY.as<double>(), 1, 1, t, n, n);
         DMRGX_HIP(hipGetLastError());
