@@ -249,8 +249,8 @@ jacobi_round_kernel(const MatDesc* __restrict__ mats, const PairRef* __restrict_
                     const UpdTask* __restrict__ tasks, const int32_t* __restrict__ pair_start)
 {
     constexpr int BUFSZ = JS * JLD;
-    __shared__ double sh[2 * BUFSZ];                  // S and R
-    __shared__ double red0[SUB_THREADS / 64], red1[SUB_THREADS / 64];
+    __shared__ double sh[3 * BUFSZ];                  // S, R and the staging tile of the off-diagonal block (25 KB: the registers cap the
+                                                      // kernel at 6 workgroups per CU anyway)
     __shared__ double rot_c[JB], rot_s[JB];
     if ((int)blockIdx.x >= n_sub) { jacobi_update_body(sh, mats, pair_start, tasks[blockIdx.x - n_sub], buf, rbuf, round, flip); return; }
     double* S = sh;
@@ -261,6 +261,7 @@ jacobi_round_kernel(const MatDesc* __restrict__ mats, const PairRef* __restrict_
     pair_blocks(m.nb, round_next, pr.j, I, J);
     const int tid = threadIdx.x;
     const double* A = buf + (flip ? m.a2_off : m.a_off);
+    for (int e = tid; e < JS * JS; e += SUB_THREADS) R[(e / JS) * JLD + jacobi_seat_of(e % JS, cross)] = (e / JS == e % JS) ? 1.0 : 0.0;
     if (!has_prev) {
         for (int e = tid; e < JS * JS; e += SUB_THREADS) {
             const int i = e / JS, j = e % JS;
@@ -280,7 +281,7 @@ jacobi_round_kernel(const MatDesc* __restrict__ mats, const PairRef* __restrict_
 #pragma unroll
         for (int u = 0; u < 2 * JB * JB / SUB_THREADS; ++u)
             dv[u] = dbuf[(u == 0 ? g0 * 2 + hp0 : g1 * 2 + hp1) * (JB * JB) + tid];
-        const jd4 acc = tile_rotate(R, A, m.npad, PI0, PJ0, 0, PI1, PJ1, rbuf + g1 * JS * JS, rbuf + g0 * JS * JS, true);
+        const jd4 acc = tile_rotate(sh + 2 * BUFSZ, A, m.npad, PI0, PJ0, 0, PI1, PJ1, rbuf + g1 * JS * JS, rbuf + g0 * JS * JS, true);
         const int lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
         if ((wave >> 1) == hp0 && (wave & 1) == hp1) {
 #pragma unroll
@@ -291,24 +292,12 @@ jacobi_round_kernel(const MatDesc* __restrict__ mats, const PairRef* __restrict_
         }
 #pragma unroll
         for (int u = 0; u < 2 * JB * JB / SUB_THREADS; ++u) S[jacobi_seat_of(u * JB + tid / JB, cross) * JLD + jacobi_seat_of(u * JB + tid % JB, cross)] = dv[u];
-        __syncthreads();                                // the staging tile (in R) is read no more
     }
-    for (int e = tid; e < JS * JS; e += SUB_THREADS) R[(e / JS) * JLD + jacobi_seat_of(e % JS, cross)] = (e / JS == e % JS) ? 1.0 : 0.0;
     __syncthreads();
     {
-        // convergence: off-diagonal mass relative to the diagonal (wave-uniform decision); the outer sweeps finish the job
-        double off = 0.0, dg = 0.0;
-        for (int e = tid; e < JS * JS; e += SUB_THREADS) {
-            const int i = e / JS, j = e % JS;
-            const double v = S[i * JLD + j];
-            if (i == j) dg += v * v; else off += v * v;
-        }
-        for (int o = 32; o > 0; o >>= 1) { off += __shfl_down(off, o, 64); dg += __shfl_down(dg, o, 64); }
-        if ((tid & 63) == 0) { red0[tid >> 6] = off; red1[tid >> 6] = dg; }
-        __syncthreads();
-        double offt = 0.0, dgt = 0.0;
-        for (int w = 0; w < SUB_THREADS / 64; ++w) { offt += red0[w]; dgt += red1[w]; }
-        if (offt > 1e-26 * dgt) {
+        // (no convergence test per sub-problem: a launch lasts as long as its slowest sub-solve, rotations of negligible elements are
+        //  skipped one by one in jacobi_rotation, and the test itself -- a reduction and two barriers -- cost 0.7 us of every round)
+        {
             const int k = tid / JB, l = tid % JB;
             // loop-invariant LDS offsets (elements): the block this thread reads, and where its two rows / columns go
             const int r0 = 2 * k, r1 = 2 * k + 1, c0 = 2 * l, c1 = 2 * l + 1;
