@@ -350,71 +350,73 @@ hqr_trailing_kernel(const HqrMat* __restrict__ mats, double* __restrict__ buf, c
 }
 
 
-// The same update on the MFMA pipe (v_mfma_f64_16x16x4): one workgroup per 64 columns, eight waves.
-//   pass 1: W0 (32 x 64) = V^T C -- the waves take the rows four at a time (one MFMA k-step: A = V^T fragment
-//           [reflector l15][row l4], B = C fragment [row l4][column l15], both straight from global memory), 2 x 4 accumulator
+// The same update on the MFMA pipe (v_mfma_f64_16x16x4): one workgroup per TM_COLS columns, eight waves.
+//   pass 1: W0 (32 x TM_COLS) = V^T C -- the waves take the rows four at a time (one MFMA k-step: A = V^T fragment
+//           [reflector l15][row l4], B = C fragment [row l4][column l15], both straight from global memory), 2 x TM_NBW accumulator
 //           blocks per wave, summed over the waves through LDS;
-//   solve : W = S'^-T W0 column by column (64 threads);
+//   solve : W = S'^-T W0 column by column (one thread per column);
 //   pass 2: C -= V W -- the waves take 16-row blocks: A = V fragment [row l15][reflector l4] from global memory,
-//           B = W from LDS, four column blocks of eight k-steps each.
+//           B = W from LDS, TM_NBW column blocks of eight k-steps each.
 typedef double hd4 __attribute__((ext_vector_type(4)));
 constexpr int TM_THREADS = 512, TM_WAVES = TM_THREADS / 64, TM_WLD = 64 + 4;
+constexpr int TM_NBW = 2, TM_COLS = 16 * TM_NBW;      // strip width: 32 columns (64 measured 55 us per launch at n = 1150: one workgroup per strip sweeps all
+                                                     // rows twice, so narrower strips = shorter chains on twice as many CUs)
 
 __global__ void __launch_bounds__(TM_THREADS)
 hqr_trailing_mfma_kernel(const HqrMat* __restrict__ mats, double* __restrict__ buf, const double* __restrict__ vt, int r0)
 {
-    __shared__ double racc[TM_WAVES][4][256];          // one m-block row of partial W0 per wave (64 KB)
+    __shared__ double racc[TM_WAVES][TM_NBW][256];     // one m-block row of partial W0 per wave
     __shared__ double Ws[32 * TM_WLD];
     __shared__ double Ts[32 * 32];
     const HqrMat m = mats[blockIdx.y];
     if (r0 >= m.n) return;
     const int n = m.n, nrem = n - r0, pw = min(32, nrem), ldb = 2 * n;
-    const int nA = (n - r0 - pw + 63) / 64, nI = (n + 63) / 64;
+    const int nA = (n - r0 - pw + TM_COLS - 1) / TM_COLS, nI = (n + TM_COLS - 1) / TM_COLS;
     const int t = blockIdx.x;
     if (t >= nA + nI) return;
     int col0, cend;
-    if (t < nA) { col0 = r0 + pw + t * 64; cend = n; }
-    else { col0 = n + (t - nA) * 64; cend = 2 * n; }
+    if (t < nA) { col0 = r0 + pw + t * TM_COLS; cend = n; }
+    else { col0 = n + (t - nA) * TM_COLS; cend = 2 * n; }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
     double* C = buf + m.b_off + (int64_t)r0 * ldb;
     const double* V = vt + m.v_off;
     for (int e = tid; e < 32 * 32; e += TM_THREADS) Ts[e] = vt[m.t_off + e];
-    // columns of this lane in the four column blocks (clamped: invalid columns are computed on garbage and never stored)
-    int colb[4]; bool cok[4];
+    // columns of this lane in the column blocks (clamped: invalid columns are computed on garbage and never stored)
+    int colb[TM_NBW]; bool cok[TM_NBW];
 #pragma unroll
-    for (int nb = 0; nb < 4; ++nb) { const int c = col0 + 16 * nb + l15; cok[nb] = c < cend; colb[nb] = cok[nb] ? c : col0; }
+    for (int nb = 0; nb < TM_NBW; ++nb) { const int c = col0 + 16 * nb + l15; cok[nb] = c < cend; colb[nb] = cok[nb] ? c : col0; }
 
     // ---- pass 1
-    hd4 acc[2][4];
+    hd4 acc[2][TM_NBW];
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-        for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = (hd4){0.0, 0.0, 0.0, 0.0};
+        for (int nb = 0; nb < TM_NBW; ++nb) acc[mb][nb] = (hd4){0.0, 0.0, 0.0, 0.0};
     const int ksteps = (nrem + 3) / 4;
     for (int ks = wave; ks < ksteps; ks += TM_WAVES) {
         const int r = 4 * ks + l4;
         const bool rok = r < nrem;
         const int rr = rok ? r : 0;
-        double a[2], b[4];
+        double a[2], b[TM_NBW];
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) { const double x = V[(int64_t)rr * 32 + 16 * mb + l15]; a[mb] = rok ? x : 0.0; }
 #pragma unroll
-        for (int nb = 0; nb < 4; ++nb) { const double x = C[(int64_t)rr * ldb + colb[nb]]; b[nb] = rok ? x : 0.0; }
+        for (int nb = 0; nb < TM_NBW; ++nb) { const double x = C[(int64_t)rr * ldb + colb[nb]]; b[nb] = rok ? x : 0.0; }
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-            for (int nb = 0; nb < 4; ++nb) acc[mb][nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mb], b[nb], acc[mb][nb], 0, 0, 0);
+            for (int nb = 0; nb < TM_NBW; ++nb) acc[mb][nb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mb], b[nb], acc[mb][nb], 0, 0, 0);
     }
     // reduce over the waves, one m-block at a time: W0[16 mb + l4 + 4 r][16 nb + l15]
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) {
         __syncthreads();
 #pragma unroll
-        for (int nb = 0; nb < 4; ++nb)
+        for (int nb = 0; nb < TM_NBW; ++nb)
 #pragma unroll
             for (int r = 0; r < 4; ++r) racc[wave][nb][64 * r + lane] = acc[mb][nb][r];
         __syncthreads();
-        for (int e = tid; e < 4 * 256; e += TM_THREADS) {
+        for (int e = tid; e < TM_NBW * 256; e += TM_THREADS) {
             const int nb = e >> 8, q = e & 255, r = q >> 6, ln = q & 63;
             double sum = 0.0;
 #pragma unroll
@@ -424,7 +426,7 @@ hqr_trailing_mfma_kernel(const HqrMat* __restrict__ mats, double* __restrict__ b
     }
     __syncthreads();
     // ---- W = T^T W0 as a forward substitution with S (see hqr_trailing_kernel), one thread per column
-    if (tid < 64) {
+    if (tid < TM_COLS) {
         double w[32];
 #pragma unroll
         for (int k = 0; k < 32; ++k) w[k] = Ws[k * TM_WLD + tid];
@@ -447,7 +449,7 @@ hqr_trailing_mfma_kernel(const HqrMat* __restrict__ mats, double* __restrict__ b
 #pragma unroll
         for (int g = 0; g < 8; ++g) { const double x = V[(int64_t)(aok ? ra : 0) * 32 + 4 * g + l4]; a[g] = aok ? x : 0.0; }
 #pragma unroll
-        for (int nb = 0; nb < 4; ++nb) {
+        for (int nb = 0; nb < TM_NBW; ++nb) {
             hd4 d = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int g = 0; g < 8; ++g) d = __builtin_amdgcn_mfma_f64_16x16x4f64(a[g], Ws[(4 * g + l4) * TM_WLD + 16 * nb + l15], d, 0, 0, 0);
@@ -473,12 +475,13 @@ dmrgx_status hqr_batched(const std::vector<HqrMat>& mats, const HqrMat* d_mats, 
     if (nm == 0) return DMRGX_OK;
     for (int r0 = 0; r0 < max_n; r0 += 32) {
         const int nrem = max_n - r0, pw = std::min(32, nrem);
-        const unsigned tiles = (unsigned)((max_n - r0 - pw + TR_COLS - 1) / TR_COLS + (max_n + TR_COLS - 1) / TR_COLS);
+        static const bool valu_update = getenv("DMRGX_HQR_VALU") != nullptr;      // developer aid: the plain-FMA block-reflector update
+        const int strip = valu_update ? TR_COLS : TM_COLS;
+        const unsigned tiles = (unsigned)((max_n - r0 - pw + strip - 1) / strip + (max_n + strip - 1) / strip);
         bool regs = false, longp = false;                    // panels of up to HR_MAX_ROWS rows (registers) / longer ones
         for (const HqrMat& m : mats) { const int r = m.n - r0; if (r > HR_MAX_ROWS) longp = true; else if (r > 0) regs = true; }
         if (longp) hipLaunchKernelGGL(hqr_panel_kernel, dim3(nm), dim3(HQ_THREADS), 0, st, d_mats, buf, r0);
         if (regs) hipLaunchKernelGGL(hqr_panel_regs_kernel, dim3(nm), dim3(HR_THREADS), 0, st, d_mats, buf, r0);
-        static const bool valu_update = getenv("DMRGX_HQR_VALU") != nullptr;      // developer aid: the plain-FMA block-reflector update
         if (valu_update) hipLaunchKernelGGL(hqr_trailing_kernel, dim3(tiles, nm), dim3(TR_THREADS), 0, st, d_mats, buf, (const double*)buf, r0);
         else hipLaunchKernelGGL(hqr_trailing_mfma_kernel, dim3(tiles, nm), dim3(TM_THREADS), 0, st, d_mats, buf, (const double*)buf, r0);
         DMRGX_HIP(hipGetLastError());
