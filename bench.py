@@ -149,6 +149,7 @@ def sweep_legs():
         assert abs(run["GSEnergy"] - e[-1]) <= 1e-10 * abs(e[-1])          # DMRGSteps.json prints 12 significant digits
         out["sweep_energies"] = e
         return out
+    t_legs = time.perf_counter()
     j1j2 = ["-J1", 1, "-Jz1", 1, "-J2", 0.5, "-Jz2", 0.5]
     # -H_eps_type gd: the generalized-Davidson option of the superblock solve (SLEPc users of the reference have the same
     # option name); same convergence criterion, about a quarter fewer MatMults per step than the default Krylov-Schur / Lanczos
@@ -166,6 +167,19 @@ def sweep_legs():
     # configs[1]: the energy the parity tier ties to the oracle (tests/test_gpu_engine.py::test_baseline_config1_energy_...)
     assert abs(out["configs_1"]["gs_energy"] - (-27.927342512)) <= 1e-6, out["configs_1"]["gs_energy"]
     out["e0_config"] = "configs[0]: Heisenberg 16x1 chain, m=64, 2 sweeps; exact-diagonalisation E0 = -6.9117371455751"
+    # configs[4]: XY 32x8 cylinder at m = 4096 on ONE GPU (93 GB peak; the NNN terms drop out with Jz2 = 0 exactly as in the reference,
+    # SURVEY section 5).  About two minutes (warm-up + one sweep): run unless the legs above already took unusually long on this
+    # box or DMRGX_BENCH_CONFIGS4=0; a failure here is reported, it does not take the bench line down.
+    if os.environ.get("DMRGX_BENCH_CONFIGS4", "1") != "0" and time.perf_counter() - t_legs < 150.0:
+        try:
+            run4 = engine_run(["-Lx", 32, "-Ly", 8, "-J1", 1, "-Jz1", 0, "-J2", 1, "-Jz2", 0, "-mwarmup", 4096, "-nsweeps", 1, "-H_eps_type", "gd"], timeout=900)
+            out["configs_4"] = leg(run4, "configs[4] on one GPU: XY 32x8 cylinder (256 sites), m=4096, warm-up + one finite-system sweep (real engine run, -H_eps_type gd)")
+            out["configs_4"]["device_bytes_peak"] = run4.get("DeviceBytesPeak")
+            out["configs_4"]["device_bytes_resident_after_sweep"] = run4.get("DeviceBytesResidentAfterSweep")
+        except Exception as e:                                    # noqa: BLE001 -- reported in the JSON line
+            out["configs_4"] = {"error": str(e)[-400:]}
+    else:
+        out["configs_4"] = None
     return out
 
 
