@@ -28,7 +28,7 @@ constexpr int JB = DMRGX_JB, JS = 2 * JB;          // block size, sub-problem si
                                              // updates of this one); 32 x 32 sub-problems (31 dependent rotation rounds on 256
                                              // threads) measured best: JB = 32 halves the rounds but its 63-round, 1024-thread
                                              // solve is > 2x slower (one cyclic sweep per visit: the outer sweeps finish the job)
-static_assert(JB == 16, "the fused round launch sizes its workgroups (256 threads, 34 KB of LDS) for 32 x 32 sub-problems");
+static_assert(JB == 16 || JB == 32, "sub-problem of 32 or 64 rows: (JS/16)^2 waves per workgroup");
 constexpr int JLD = JS + 1;
 constexpr int SUB_THREADS = JB * JB;           // sub-solve: one thread per pair of rotation pairs
 
@@ -163,12 +163,13 @@ __device__ __forceinline__ int jacobi_seat_of(int j, int cross) { return cross ?
 // result col = l&15, row = (l>>4) + 4 reg); the tile goes through LDS (X, JS x JLD), R_Q and R_P^T go from global memory
 // straight into MFMA fragments.  (The plain-FMA version of these products was LDS-bandwidth bound: the update ran at ~12 TF/s
 // and took 70 % of the eigensolve at m = 2048.)  Leaves the once-rotated tile in X; ends without a barrier.
-static_assert(JS == 32, "tile rotation: 2 x 2 waves of one 16 x 16 MFMA block each");
+constexpr int JW = JS / 16;                    // the workgroup is a JW x JW grid of waves, one 16 x 16 MFMA block of the tile each
+static_assert(SUB_THREADS == 64 * JW * JW, "one thread per pair of rotation pairs == one wave per 16 x 16 block of the tile");
 __device__ __forceinline__ jd4 tile_rotate(double* X, const double* __restrict__ M, int npad, int IP, int JP, int row0, int IQ, int JQ,
                                            const double* __restrict__ Rq, const double* __restrict__ Rp, bool two_sided)
 {
     constexpr int KG = JS / 4;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave / JW, wc = wave % JW;
     const int l15 = lane & 15, l4 = lane >> 4;
     auto cq = [&](int j) { return j < JB ? IQ * JB + j : JQ * JB + j - JB; };
     auto rp = [&](int i) { return IP >= 0 ? (i < JB ? IP * JB + i : JP * JB + i - JB) : row0 + i; };
@@ -179,7 +180,7 @@ __device__ __forceinline__ jd4 tile_rotate(double* X, const double* __restrict__
         bq[g] = Rq[(4 * g + l4) * JS + 16 * wc + l15];
         ap[g] = two_sided ? Rp[(4 * g + l4) * JS + 16 * wr + l15] : 0.0;
     }
-    for (int e = tid; e < JS * JS; e += 256) {
+    for (int e = tid; e < JS * JS; e += SUB_THREADS) {
         const int i = e / JS, j = e % JS;
         X[i * JLD + j] = M[(int64_t)rp(i) * npad + cq(j)];
     }
@@ -208,7 +209,7 @@ __device__ __forceinline__ void jacobi_update_body(double* X, const MatDesc* __r
                                                    double* __restrict__ buf, const double* __restrict__ rbuf, int round, int flip)
 {
     const MatDesc m = mats[t.mat];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1, l15 = lane & 15, l4 = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave / JW, wc = wave % JW, l15 = lane & 15, l4 = lane >> 4;
     int IQ, JQ, IP = -1, JP = -1;
     pair_blocks(m.nb, round, t.q, IQ, JQ);
     if (t.kind == 0) pair_blocks(m.nb, round, t.p, IP, JP);
@@ -226,7 +227,7 @@ __device__ __forceinline__ void jacobi_update_body(double* X, const MatDesc* __r
 #pragma unroll
         for (int r = 0; r < 4; ++r) X[(16 * wr + l4 + 4 * r) * JLD + 16 * wc + l15] = acc[r];
         __syncthreads();
-        for (int e = tid; e < JS * JS; e += 256) {
+        for (int e = tid; e < JS * JS; e += SUB_THREADS) {
             const int i = e / JS, j = e % JS;                     // element (i, j) of the transposed block
             Mo[(int64_t)cq(i) * m.npad + rp(j)] = X[j * JLD + i];
         }
@@ -249,8 +250,9 @@ jacobi_round_kernel(const MatDesc* __restrict__ mats, const PairRef* __restrict_
                     const UpdTask* __restrict__ tasks, const int32_t* __restrict__ pair_start)
 {
     constexpr int BUFSZ = JS * JLD;
-    __shared__ double sh[3 * BUFSZ];                  // S, R and the staging tile of the off-diagonal block (25 KB: the registers cap the
-                                                      // kernel at 6 workgroups per CU anyway)
+    constexpr bool STAGE_IN_R = (JB > 16);            // JB = 32: 33 KB per buffer -- the staging tile shares R's (two workgroups per CU)
+    __shared__ double sh[(STAGE_IN_R ? 2 : 3) * BUFSZ];    // S, R and the staging tile of the off-diagonal block (JB = 16: 25 KB, the registers
+                                                      // cap the kernel at 6 workgroups per CU anyway)
     __shared__ double rot_c[JB], rot_s[JB];
     if ((int)blockIdx.x >= n_sub) { jacobi_update_body(sh, mats, pair_start, tasks[blockIdx.x - n_sub], buf, rbuf, round, flip); return; }
     double* S = sh;
@@ -261,7 +263,7 @@ jacobi_round_kernel(const MatDesc* __restrict__ mats, const PairRef* __restrict_
     pair_blocks(m.nb, round_next, pr.j, I, J);
     const int tid = threadIdx.x;
     const double* A = buf + (flip ? m.a2_off : m.a_off);
-    for (int e = tid; e < JS * JS; e += SUB_THREADS) R[(e / JS) * JLD + jacobi_seat_of(e % JS, cross)] = (e / JS == e % JS) ? 1.0 : 0.0;
+    if (!STAGE_IN_R) for (int e = tid; e < JS * JS; e += SUB_THREADS) R[(e / JS) * JLD + jacobi_seat_of(e % JS, cross)] = (e / JS == e % JS) ? 1.0 : 0.0;
     if (!has_prev) {
         for (int e = tid; e < JS * JS; e += SUB_THREADS) {
             const int i = e / JS, j = e % JS;
@@ -281,17 +283,22 @@ jacobi_round_kernel(const MatDesc* __restrict__ mats, const PairRef* __restrict_
 #pragma unroll
         for (int u = 0; u < 2 * JB * JB / SUB_THREADS; ++u)
             dv[u] = dbuf[(u == 0 ? g0 * 2 + hp0 : g1 * 2 + hp1) * (JB * JB) + tid];
-        const jd4 acc = tile_rotate(sh + 2 * BUFSZ, A, m.npad, PI0, PJ0, 0, PI1, PJ1, rbuf + g1 * JS * JS, rbuf + g0 * JS * JS, true);
+        const jd4 acc = tile_rotate(STAGE_IN_R ? R : sh + 2 * BUFSZ, A, m.npad, PI0, PJ0, 0, PI1, PJ1, rbuf + g1 * JS * JS, rbuf + g0 * JS * JS, true);
         const int lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
-        if ((wave >> 1) == hp0 && (wave & 1) == hp1) {
+        // the block (half hp0 of the rows, half hp1 of the columns) of the rotated tile is a JW/2 x JW/2 group of waves
+        if ((wave / JW) / (JW / 2) == hp0 && (wave % JW) / (JW / 2) == hp1) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int si = jacobi_seat_of(l4 + 4 * r, cross), sj = jacobi_seat_of(JB + l15, cross);
+                const int si = jacobi_seat_of(16 * ((wave / JW) % (JW / 2)) + l4 + 4 * r, cross), sj = jacobi_seat_of(JB + 16 * ((wave % JW) % (JW / 2)) + l15, cross);
                 S[si * JLD + sj] = acc[r]; S[sj * JLD + si] = acc[r];
             }
         }
 #pragma unroll
         for (int u = 0; u < 2 * JB * JB / SUB_THREADS; ++u) S[jacobi_seat_of(u * JB + tid / JB, cross) * JLD + jacobi_seat_of(u * JB + tid % JB, cross)] = dv[u];
+    }
+    if (STAGE_IN_R) {
+        __syncthreads();                                // the staging tile is read no more
+        for (int e = tid; e < JS * JS; e += SUB_THREADS) R[(e / JS) * JLD + jacobi_seat_of(e % JS, cross)] = (e / JS == e % JS) ? 1.0 : 0.0;
     }
     __syncthreads();
     {
