@@ -5,7 +5,7 @@ ARCH       ?= gfx950
 PKG        := dmrg.x_amd
 CSRC       := $(PKG)/csrc
 HIPFLAGS   := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Iinclude -I$(CSRC) -Wall -Wno-unused-function
-HIP_SRCS   := $(CSRC)/lib.hip $(CSRC)/pool.hip $(CSRC)/ggemm.hip $(CSRC)/kron_plan.hip $(CSRC)/eigs.hip $(CSRC)/rdm.hip $(CSRC)/hqr.hip $(CSRC)/rotate.hip $(CSRC)/comm.hip
+HIP_SRCS   := $(CSRC)/lib.hip $(CSRC)/pool.hip $(CSRC)/ggemm.hip $(CSRC)/kron_plan.hip $(CSRC)/eigs.hip $(CSRC)/rdm.hip $(CSRC)/hqr.hip $(CSRC)/symeig.hip $(CSRC)/rotate.hip $(CSRC)/comm.hip
 HIP_OBJS   := $(HIP_SRCS:.hip=.o)
 
 HOST       := $(PKG)/host
@@ -13,7 +13,7 @@ HOST_HDRS  := $(wildcard $(HOST)/*.hpp) include/dmrgx.h
 
 all: $(PKG)/libdmrgx_hip.so $(PKG)/dmrgx-square-lattice $(PKG)/dmrgx-host-tool oracle/liboracle_kron.so
 
-$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/ggemm.h $(CSRC)/hqr.h include/dmrgx.h
+$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/common.h $(CSRC)/ggemm.h $(CSRC)/hqr.h $(CSRC)/symeig.h include/dmrgx.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(PKG)/libdmrgx_hip.so: $(HIP_OBJS)

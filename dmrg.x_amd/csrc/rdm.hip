@@ -11,6 +11,7 @@
 // dmrgx_rdm_eigenvectors (== FillRotation_BlockDiag, :2006-2057).
 #include "ggemm.h"
 #include "hqr.h"
+#include "symeig.h"
 #include <chrono>
 #include <algorithm>
 #include <cmath>
@@ -508,6 +509,14 @@ static dmrgx_status rdm_create_impl(const dmrgx_sectors* left, const dmrgx_secto
         fprintf(stderr, "[rdm] stage %-10s %8.3f ms\n", name, std::chrono::duration<double, std::milli>(t - t_prev).count());
         t_prev = t;
     };
+    // ---- solver: tridiagonalisation + divide and conquer (symeig.hip, round 3) unless the environment asks for the block-Jacobi
+    //      iteration of rounds 1-2 (DMRGX_RDM_SOLVER=jacobi; kept for comparison and for orders above SYMEIG_MAX_N)
+    static const bool want_dc = !(getenv("DMRGX_RDM_SOLVER") && std::string(getenv("DMRGX_RDM_SOLVER")) == "jacobi");
+    bool use_dc = want_dc;                            // (a caller's warm-start bases are then only a hint, as with the QR preconditioner)
+    for (int32_t k = 0; k < nblocks && use_dc; ++k) {
+        if (block_il[k] < 0 || block_il[k] >= left->nsec || block_ir[k] < 0 || block_ir[k] >= right->nsec) break;       // reported below
+        if (std::max(left->size[block_il[k]], right->size[block_ir[k]]) > SYMEIG_MAX_N) use_dc = false;
+    }
     // ---- layout -------------------------------------------------------------------------------------------
     std::vector<int64_t> off(nblocks + 1, 0);
     int64_t total = 0;
@@ -524,7 +533,7 @@ static dmrgx_status rdm_create_impl(const dmrgx_sectors* left, const dmrgx_secto
             m.npad = ((m.n + JS - 1) / JS) * JS;
             m.nb = m.npad / JB;
             m.a_off = total; total += (int64_t)m.npad * m.npad;
-            m.a2_off = total; total += (int64_t)m.npad * m.npad;
+            m.a2_off = total; total += use_dc ? 0 : (int64_t)m.npad * m.npad;      // second buffer of A: block Jacobi only
             m.v_off = total; total += (int64_t)m.npad * m.npad;
             m.pad = 0;
             P->mats.push_back(m);
@@ -558,10 +567,12 @@ static dmrgx_status rdm_create_impl(const dmrgx_sectors* left, const dmrgx_secto
     const int64_t diag_base = total; total += dtot;
     const int64_t rq_base = total; total += dtot;            // Rayleigh quotients, same indexing as the diagonals
     const int64_t w_base = total; total += 2 * N;            // W = Psi^T V_L (n_R x n_L) and Psi V_R (n_L x n_R) per block
+    const int64_t ew_base = total; total += use_dc ? dtot : 0;   // eigenvalues as the direct solver returns them (ascending)
     // warm start: per matrix with a previous eigenbasis E (rows), W = E A and E^T (n x n each)
     // QR preconditioner (default on; DMRGX_RDM_QR=0 restores the plain / caller-warm-started solver for comparison): its
     // basis replaces the caller's v0_rows, which then only remain a hint
-    static const bool use_qr = !(getenv("DMRGX_RDM_QR") && atoi(getenv("DMRGX_RDM_QR")) == 0);
+    static const bool want_qr = !(getenv("DMRGX_RDM_QR") && atoi(getenv("DMRGX_RDM_QR")) == 0);
+    const bool use_qr = want_qr && !use_dc;
     std::vector<const double*> warm_src(nm, nullptr);
     std::vector<HqrMat> qmats(nm, HqrMat{0, 0, 0, 0, 0});
     std::vector<int64_t> qe_off(nm, 0), qperm_off(nm, 0);
@@ -577,7 +588,7 @@ static dmrgx_status rdm_create_impl(const dmrgx_sectors* left, const dmrgx_secto
             qe_off[mi] = total; total += n * n;
             qperm_off[mi] = qperm_tot; qperm_tot += n;
             any_qr = true;
-        } else if (!use_qr && v0_rows && v0_rows[mi]) warm_src[mi] = v0_rows[mi];
+        } else if (!use_qr && !use_dc && v0_rows && v0_rows[mi]) warm_src[mi] = v0_rows[mi];
     }
     std::vector<int64_t> warm_w(nm, -1), warm_et(nm, -1);
     for (int mi = 0; mi < nm; ++mi) if (warm_src[mi] || qmats[mi].n) { const int64_t nn = (int64_t)P->mats[mi].n * P->mats[mi].n; warm_w[mi] = total; total += nn; warm_et[mi] = total; total += nn; }
@@ -695,6 +706,15 @@ static dmrgx_status rdm_create_impl(const dmrgx_sectors* left, const dmrgx_secto
         DMRGX_HIP(hipGetLastError());
     }
     stage("qr");
+    if (use_dc) {
+        std::vector<SymEigMat> sm;
+        for (int mi = 0; mi < nm; ++mi) {
+            const MatDesc& m = P->mats[mi];
+            if (m.n > 0) sm.push_back(SymEigMat{m.n, m.npad, m.npad, 0, buf + m.a_off, buf + m.v_off, buf + ew_base + (diag_off[mi] - diag_base)});
+        }
+        DMRGX_CHK(symeig_batched(sm, st));
+        stage("symeig");
+    }
     bool any_warm = false;
     for (int mi = 0; mi < nm; ++mi) any_warm = any_warm || warm_src[mi];
     if (any_warm) {
@@ -746,7 +766,7 @@ static dmrgx_status rdm_create_impl(const dmrgx_sectors* left, const dmrgx_secto
     const int rounds = std::max(1, max_nb - 1);
     int sweep = 0, slot = 0, flip = 0;
     bool have_rot = false;                   // rbuf[slot] / dbuf[slot] hold the rotations of the round about to be applied
-    for (; sweep < 30; ++sweep) {
+    for (; sweep < 30 && !use_dc; ++sweep) {
         hipLaunchKernelGGL(offnorm_kernel, dim3(NORM_BLOCKS, nm), dim3(256), 0, st, dm, buf, buf + norm_off, flip);
         DMRGX_HIP(hipGetLastError());
         DMRGX_HIP(hipMemcpyAsync(norms.data(), buf + norm_off, norms.size() * sizeof(double), hipMemcpyDeviceToHost, st));

@@ -1,0 +1,28 @@
+// Batched symmetric eigensolver (f64) for the reduced density matrices: Householder tridiagonalisation, tridiagonal divide and
+// conquer, blocked back-transformation (symeig.hip).  Replaces the QR-preconditioned block-Jacobi iteration of rounds 1-2
+// (rdm.hip keeps it behind DMRGX_RDM_SOLVER=jacobi and for matrices above SYMEIG_MAX_N).
+//
+// Takes the place of the reference's EPSLAPACK call in EigRDM_BlockDiag (include/DMRGBlockContainer.hpp:1976-1982: all
+// eigenpairs of one dense symmetric block): same mathematical result (eigenvalues to c n eps ||A||, eigenvectors orthogonal to
+// round-off), computed for every block of a truncation step at once.
+#pragma once
+#include "common.h"
+
+namespace dmrgx {
+
+struct SymEigMat {
+    int32_t n;       // order (0 allowed: nothing is done)
+    int32_t lda;     // leading dimension of A (row-major)
+    int32_t ldx;     // leading dimension of X
+    int32_t pad;
+    double* A;       // in: symmetric n x n, BOTH triangles stored; overwritten
+    double* X;       // out: eigenvectors as COLUMNS of the row-major n x n array (column c belongs to w[c])
+    double* w;       // out (device): eigenvalues, ascending
+};
+
+constexpr int SYMEIG_MAX_N = 3072;     // the merge kernels keep O(n) vectors of one sub-problem in LDS
+
+// Enqueue the eigendecomposition of every matrix on `st` (asynchronous; workspace comes from the stream-ordered pool).
+dmrgx_status symeig_batched(const std::vector<SymEigMat>& mats, hipStream_t st);
+
+}  // namespace dmrgx

@@ -1,0 +1,853 @@
+// Batched symmetric eigensolver for the reduced density matrices -- see symeig.h.  Three phases, every one of them batched over
+// all matrices of a truncation step (the reference hands each block to LAPACK on rank 0, include/DMRGBlockContainer.hpp:1962-2003):
+//
+//  1. Householder tridiagonalisation  A = Q T Q^T,  ONE LAUNCH PER COLUMN (trid_step_kernel).  The eigenproblem of a DMRG step is a
+//     latency chain, not a flop count (sum n^3 ~ 3e9 at m = 2048): a column step needs two dependent reductions over the whole
+//     column, and the cheapest chip-wide barrier on this machine is a kernel boundary (~1.5 us; an in-kernel all-to-all exchange
+//     costs ~3 us).  The classical two phases of a column (y = A v; rank-2 update A -= v w^T + w v^T) are skewed so that one
+//     launch does both with one pass over the trailing matrix: every workgroup first finishes, redundantly, the O(n) vector work
+//     of the column (w_{j-1} from y_{j-1}; the updated row j -> d_j, e_j, v_j, tau_j), then applies the update of reflector j-1
+//     to its rows and multiplies the updated rows by v_j on the way (y_j).  n launches per matrix, all matrices in each launch.
+//  2. Tridiagonal divide and conquer (Cuppen; the method of LAPACK's dstedc), level-synchronous: uniform-depth tree, leaves <= 32
+//     solved by Jacobi in LDS, then per level: deflation (dc_deflate_kernel; the only sequential scan), secular roots by the
+//     "middle way" iteration in shifted coordinates (one wave per root), Loewner weights and eigenvector columns, and ONE grouped
+//     MFMA GEMM  Q_new = blockdiag(Q1, Q2) . U  in which deflated columns are unit columns of U (no gather / scatter kernels) and
+//     the deflation rotations are applied to the ROWS of U.  Density matrices of DMRG states deflate almost completely.
+//  3. Back-transformation  X = H_0 .. H_{n-3} Z  in blocks of 64 reflectors, compact-WY with T^-1 = striu(V^T V) + diag(1/tau):
+//     T V^T is formed for all blocks at once, then two grouped GEMMs per block step.
+//
+// tools/proto_trid_dc.py is the numpy statement of exactly this data flow.
+#include "symeig.h"
+#include "ggemm.h"
+#include <cfloat>
+#include <cmath>
+#include <numeric>
+
+namespace dmrgx {
+namespace {
+
+constexpr int TRID_THREADS = 256, TRID_ROWS = 8;      // rows of the trailing matrix per workgroup (two per wave)
+constexpr int DC_LEAF = 32;                           // largest leaf of the divide-and-conquer tree
+constexpr int WY_NB = 64;                             // reflectors per block of the back-transformation
+constexpr double DC_EPS = DBL_EPSILON;
+
+struct TridMat {
+    double *A, *VT, *y, *d, *e, *tau;                 // VT: row j = reflector v_j (zeros up to column j); y: 2 x n (double-buffered A v)
+    int32_t n, lda, ldv, pad;
+};
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// sum over the workgroup; `red` holds one slot per wave.  Two barriers: the first also publishes whatever the callers wrote to
+// LDS before the call, the second makes the partial sums visible.
+template <int NW>
+__device__ __forceinline__ double block_sum(double v, double* red, int tid)
+{
+    v = wave_sum(v);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) s += red[w];
+    return s;
+}
+template <int NW>
+__device__ __forceinline__ double block_max(double v, double* red, int tid)
+{
+    v = wave_max(v);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    double s = red[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) s = fmax(s, red[w]);
+    return s;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// 1. tridiagonalisation: launch j
+// ---------------------------------------------------------------------------------------------------------------------------
+// Stored state at the start of launch j: rows / columns >= j of A carry the updates of reflectors 0 .. j-2; y_{j-1} = A v_{j-1}
+// (un-scaled) and v_{j-1}, tau_{j-1} are in memory.  Row j is read by everybody and written by nobody (it retires here), rows
+// > j are each updated by exactly one wave, so the launch has no write-read race on A.
+__global__ void __launch_bounds__(TRID_THREADS)
+trid_step_kernel(const TridMat* __restrict__ mats, int nm, int j)
+{
+    extern __shared__ double sh[];                  // w | v_{j-1} | row j, then v_j   (indexed by the absolute column)
+    __shared__ double red[TRID_THREADS / 64];
+    int b = blockIdx.x, mi = 0;
+    for (; mi < nm; ++mi) {
+        const int n = mats[mi].n;
+        const int wgs = j < n ? max(1, (n - j - 1 + TRID_ROWS - 1) / TRID_ROWS) : 0;
+        if (b < wgs) break;
+        b -= wgs;
+    }
+    if (mi == nm) return;
+    const TridMat m = mats[mi];
+    const int n = m.n, tid = threadIdx.x, g = b;
+    double* sw = sh;
+    double* svp = sh + n;
+    double* svj = sh + 2 * n;
+    const double tau_p = j > 0 ? m.tau[j - 1] : 0.0;
+    const double* yp = m.y + (size_t)((j + 1) & 1) * n;
+    double* yc = m.y + (size_t)(j & 1) * n;
+    const double* vprow = m.VT + (int64_t)(j > 0 ? j - 1 : 0) * m.ldv;
+    const double* arow = m.A + (int64_t)j * m.lda;
+    double s = 0.0;
+    for (int k = j + tid; k < n; k += TRID_THREADS) {
+        const double vp = j > 0 ? vprow[k] : 0.0, y = j > 0 ? yp[k] : 0.0;
+        svp[k] = vp; sw[k] = y; svj[k] = arow[k];
+        s += y * vp;
+    }
+    s = block_sum<TRID_THREADS / 64>(s, red, tid);
+    const double coef = 0.5 * tau_p * tau_p * s;     // w = tau y - (tau^2 (y.v) / 2) v
+    for (int k = j + tid; k < n; k += TRID_THREADS) sw[k] = tau_p * sw[k] - coef * svp[k];
+    __syncthreads();
+    const double wj = sw[j], vpj = svp[j];
+    double sig = 0.0;
+    for (int k = j + tid; k < n; k += TRID_THREADS) {     // row j with the update of reflector j-1 applied
+        const double r = svj[k] - vpj * sw[k] - wj * svp[k];
+        svj[k] = r;
+        if (k >= j + 2) sig += r * r;
+    }
+    sig = block_sum<TRID_THREADS / 64>(sig, red, tid);
+    const double dj = svj[j];
+    const double alpha = (j + 1 < n) ? svj[j + 1] : 0.0;
+    double beta = alpha, tj = 0.0, scale = 0.0;          // dlarfg: H x = beta e_1, H = I - tau v v^T, v_1 = 1
+    if (sig > 0.0) {
+        const double nrm = sqrt(alpha * alpha + sig);
+        beta = alpha >= 0.0 ? -nrm : nrm;
+        tj = (beta - alpha) / beta;
+        scale = 1.0 / (alpha - beta);
+    }
+    __syncthreads();                                    // everyone holds d_j and alpha before row j turns into v_j
+    for (int k = j + tid; k < n; k += TRID_THREADS)     // a reflector with tau = 0 is stored as the zero vector (H = I)
+        svj[k] = (k <= j || tj == 0.0) ? 0.0 : (k == j + 1 ? 1.0 : svj[k] * scale);
+    __syncthreads();
+    if (g == 0) {
+        double* vt = m.VT + (int64_t)j * m.ldv;
+        for (int k = tid; k < n; k += TRID_THREADS) vt[k] = k > j ? svj[k] : 0.0;
+        if (tid == 0) { m.d[j] = dj; if (j + 1 < n) m.e[j] = beta; m.tau[j] = tj; }
+    }
+    // ---- rows j+1+8g .. : A[i,:] -= v_{j-1}[i] w^T + w[i] v_{j-1}^T, then y_j[i] = A[i,:] . v_j -- two rows per wave
+    const int lane = tid & 63, wave = tid >> 6;
+    const int i0 = j + 1 + TRID_ROWS * g + 2 * wave;
+    if (i0 >= n) return;
+    const bool two = i0 + 1 < n;
+    double* a0 = m.A + (int64_t)i0 * m.lda;
+    double* a1 = a0 + (two ? m.lda : 0);
+    const double vp0 = svp[i0], w0 = sw[i0], vp1 = two ? svp[i0 + 1] : 0.0, w1 = two ? sw[i0 + 1] : 0.0;
+    double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll 4
+    for (int k = j + 1 + lane; k < n; k += 64) {
+        const double wk = sw[k], vpk = svp[k], vjk = svj[k];
+        double x0 = a0[k], x1 = a1[k];
+        x0 -= vp0 * wk + w0 * vpk;
+        x1 -= vp1 * wk + w1 * vpk;
+        a0[k] = x0;
+        if (two) a1[k] = x1;
+        acc0 += x0 * vjk; acc1 += x1 * vjk;
+    }
+    acc0 = wave_sum(acc0); acc1 = wave_sum(acc1);
+    if (lane == 0) { yc[i0] = acc0; if (two) yc[i0 + 1] = acc1; }
+}
+
+// dst (n x n, ld) = src^T for every matrix (V from V^T)
+struct SqPair { const double* src; double* dst; int32_t n, lds, ldd, pad; };
+__global__ void __launch_bounds__(256) transpose_sq_kernel(const SqPair* __restrict__ prs)
+{
+    __shared__ double t[32][33];
+    const SqPair p = prs[blockIdx.z];
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    if (r0 >= p.n || c0 >= p.n) return;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) t[r][tx] = (r0 + r < p.n && c0 + tx < p.n) ? p.src[(int64_t)(r0 + r) * p.lds + c0 + tx] : 0.0;
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) if (c0 + r < p.n && r0 + tx < p.n) p.dst[(int64_t)(c0 + r) * p.ldd + r0 + tx] = t[tx][r];
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// 3. compact-WY factor of a block of reflectors:  Tneg = -(striu(G) + diag(1 / tau))^-1,  G = V_b^T V_b  (64 x 64, row-major)
+// ---------------------------------------------------------------------------------------------------------------------------
+struct WyBlock { const double* G; const double* tau; double* Tneg; int32_t kb, pad; };
+__global__ void __launch_bounds__(WY_NB) wy_tinv_kernel(const WyBlock* __restrict__ blocks)
+{
+    __shared__ double S[WY_NB][WY_NB + 1];            // upper triangle + diagonal: S; strictly lower triangle: T^T (T[r][c] at [c][r])
+    const WyBlock b = blocks[blockIdx.x];
+    const int c = threadIdx.x, kb = b.kb;
+    for (int r = 0; r < WY_NB; ++r) {
+        double v = 0.0;
+        if (r < kb && c < kb) {
+            if (c > r) v = b.G[r * WY_NB + c];
+            else if (c == r) { const double t = b.tau[r]; v = t != 0.0 ? 1.0 / t : 1.0; }
+        } else if (r == c) v = 1.0;
+        if (c >= r) S[r][c] = v;
+    }
+    __syncthreads();
+    // column c of S^-1 by back substitution (S upper triangular): t_c = 1 / S_cc;  t_r = -(sum_{l = r+1 .. c} S_rl t_l) / S_rr.
+    // Thread c writes row c of the lower triangle only and reads the upper triangle, which nobody writes: no barrier in the loop.
+    const double tcc = 1.0 / S[c][c];
+    for (int r = WY_NB - 2; r >= 0; --r) {
+        if (r < c) {
+            double acc = S[r][c] * tcc;
+            for (int l = r + 1; l < c; ++l) acc += S[r][l] * S[c][l];
+            S[c][r] = -acc / S[r][r];
+        }
+    }
+    for (int r = 0; r < WY_NB; ++r) {
+        double t = 0.0;
+        if (r < kb && c < kb) t = r < c ? S[c][r] : (r == c ? tcc : 0.0);
+        b.Tneg[r * WY_NB + c] = -t;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// 2. divide and conquer
+// ---------------------------------------------------------------------------------------------------------------------------
+struct DcMat {
+    double* Q[2];                  // eigenvector buffers (block diagonal while the tree is climbed); level l lives in Q[l & 1]
+    double* U;                     // the merge matrices of one level (block diagonal)
+    const double *d, *e;           // the tridiagonal matrix (unscaled)
+    double *dcur, *scale, *w;      // eigenvalues of the current nodes (scaled); the scale factor; output spectrum
+    double *dl, *zl, *tau, *lam, *zhat, *cnorm, *dval, *rc, *rs, *mrho;     // per position of the matrix, length n
+    int32_t *org, *pcol, *dcol, *rowpole, *colroot, *pcolmap, *rcp, *rcj, *mk, *mrot;
+    int32_t n, ldq[2], ldu;
+};
+struct DcLeaf { int32_t mat, lo, hi, buf; };
+struct DcMerge { int32_t mat, lo, mid, hi, src, pad; };
+
+__global__ void __launch_bounds__(256) dc_scale_kernel(const DcMat* __restrict__ mats)
+{
+    __shared__ double red[4];
+    const DcMat m = mats[blockIdx.x];
+    double v = 0.0;
+    for (int i = threadIdx.x; i < m.n; i += 256) { v = fmax(v, fabs(m.d[i])); if (i + 1 < m.n) v = fmax(v, fabs(m.e[i])); }
+    v = block_max<4>(v, red, threadIdx.x);
+    if (threadIdx.x == 0) m.scale[0] = v > 0.0 ? v : 1.0;
+}
+
+// Leaf: T[lo:hi] with the rank-one couplings to its neighbours taken off the end diagonals (T = diag(T1', T2') + |beta| u u^T,
+// u = e_last(1) + sign(beta) e_first(2)), diagonalised by cyclic Jacobi on the dense 32 x 32 array in LDS.
+__global__ void __launch_bounds__(256) dc_leaf_kernel(const DcMat* __restrict__ mats, const DcLeaf* __restrict__ leaves)
+{
+    constexpr int P = DC_LEAF, H = P / 2;
+    __shared__ double S[P][P + 1], R[P][P + 1];
+    __shared__ double rc[H], rs[H];
+    __shared__ double red[4];
+    __shared__ int rnk[P];
+    const DcLeaf lf = leaves[blockIdx.x];
+    const DcMat m = mats[lf.mat];
+    const int p = lf.hi - lf.lo, tid = threadIdx.x;
+    const double inv = 1.0 / m.scale[0];
+    for (int e = tid; e < P * P; e += 256) { const int i = e / P, c = e % P; S[i][c] = 0.0; R[i][c] = i == c ? 1.0 : 0.0; }
+    __syncthreads();
+    if (tid < p) {
+        const int gi = lf.lo + tid;
+        double dv = m.d[gi] * inv;
+        if (tid == 0 && lf.lo > 0) dv -= fabs(m.e[lf.lo - 1] * inv);
+        if (tid == p - 1 && lf.hi < m.n) dv -= fabs(m.e[lf.hi - 1] * inv);
+        S[tid][tid] = dv;
+        if (tid + 1 < p) { const double ev = m.e[gi] * inv; S[tid][tid + 1] = ev; S[tid + 1][tid] = ev; }
+    }
+    __syncthreads();
+    for (int sweep = 0; sweep < 20; ++sweep) {
+        double off = 0.0, dg = 0.0;
+        for (int e = tid; e < P * P; e += 256) { const int i = e / P, c = e % P; const double v = S[i][c]; if (i == c) dg += v * v; else off += v * v; }
+        off = block_sum<4>(off, red, tid);
+        dg = block_sum<4>(dg, red, tid);
+        if (off <= 1e-34 * dg || off == 0.0) break;          // uniform over the workgroup
+        for (int r = 0; r < P - 1; ++r) {
+            if (tid < H) {                                   // pair tid of round r (round-robin tournament of 32 indices)
+                int a, bq;
+                if (tid == 0) { a = P - 1; bq = r; } else { a = (r + tid) % (P - 1); bq = (r - tid + P - 1) % (P - 1); }
+                if (a > bq) { const int t = a; a = bq; bq = t; }
+                const double apq = S[a][bq], app = S[a][a], aqq = S[bq][bq];
+                double c = 1.0, s = 0.0;
+                if (apq != 0.0) {
+                    const double th = 0.5 * (aqq - app) / apq;
+                    const double t = (th >= 0.0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
+                    c = 1.0 / sqrt(t * t + 1.0); s = t * c;
+                }
+                rc[tid] = c; rs[tid] = s;
+            }
+            __syncthreads();
+            for (int e = tid; e < H * P; e += 256) {         // columns: S <- S J, R <- R J
+                const int t = e / P, i = e % P;
+                int a, bq;
+                if (t == 0) { a = P - 1; bq = r; } else { a = (r + t) % (P - 1); bq = (r - t + P - 1) % (P - 1); }
+                if (a > bq) { const int x = a; a = bq; bq = x; }
+                const double c = rc[t], s = rs[t];
+                const double sp = S[i][a], sq = S[i][bq];
+                S[i][a] = c * sp - s * sq; S[i][bq] = s * sp + c * sq;
+                const double rp = R[i][a], rq = R[i][bq];
+                R[i][a] = c * rp - s * rq; R[i][bq] = s * rp + c * rq;
+            }
+            __syncthreads();
+            for (int e = tid; e < H * P; e += 256) {         // rows: S <- J^T S
+                const int t = e / P, i = e % P;
+                int a, bq;
+                if (t == 0) { a = P - 1; bq = r; } else { a = (r + t) % (P - 1); bq = (r - t + P - 1) % (P - 1); }
+                if (a > bq) { const int x = a; a = bq; bq = x; }
+                const double c = rc[t], s = rs[t];
+                const double sp = S[a][i], sq = S[bq][i];
+                S[a][i] = c * sp - s * sq; S[bq][i] = s * sp + c * sq;
+            }
+            __syncthreads();
+        }
+    }
+    // ascending order; the padding indices >= p never mixed with the real ones (their rows and columns are exactly zero)
+    if (tid < p) {
+        const double v = S[tid][tid];
+        int r = 0;
+        for (int q = 0; q < p; ++q) { const double u = S[q][q]; r += (u < v) || (u == v && q < tid); }
+        rnk[tid] = r;
+        m.dcur[lf.lo + r] = v;
+    }
+    __syncthreads();
+    double* Q = m.Q[lf.buf];
+    const int ldq = m.ldq[lf.buf];
+    for (int e = tid; e < p * p; e += 256) { const int i = e / p, c = e % p; Q[(int64_t)(lf.lo + i) * ldq + lf.lo + rnk[c]] = R[i][c]; }
+}
+
+// Deflation of one merge (LAPACK dlaed2 in this solver's data flow): z from the children's boundary rows, poles ranked by brute-
+// force counting (no sortedness assumed), type-1 (rho |z_i| tiny) and type-2 (two close poles: one Givens rotation moves the
+// weight to one of them) deflation in one sequential scan by thread 0 -- the only serial part of the solver.
+__global__ void __launch_bounds__(1024) dc_deflate_kernel(const DcMat* __restrict__ mats, const DcMerge* __restrict__ merges, int nlmax)
+{
+    extern __shared__ double sh[];
+    double* D = sh;
+    double* z = sh + nlmax;
+    double* ds = sh + 2 * (size_t)nlmax;
+    double* zs = sh + 3 * (size_t)nlmax;
+    int* ord = (int*)(sh + 4 * (size_t)nlmax);
+    __shared__ double red[16];
+    const DcMerge mg = merges[blockIdx.x];
+    const DcMat m = mats[mg.mat];
+    const int lo = mg.lo, n1 = mg.mid - mg.lo, nl = mg.hi - mg.lo, tid = threadIdx.x;
+    const double beta = m.e[mg.mid - 1] / m.scale[0];
+    const double rho = 2.0 * fabs(beta), sgn = beta < 0.0 ? -1.0 : 1.0;
+    const double* Qs = m.Q[mg.src];
+    const int ldq = m.ldq[mg.src];
+    const double* row1 = Qs + (int64_t)(mg.mid - 1) * ldq + lo;      // last row of child 1 (columns lo .. mid-1)
+    const double* row2 = Qs + (int64_t)mg.mid * ldq + lo;            // first row of child 2 (columns mid .. hi-1)
+    double dmax = 0.0, zmax = 0.0;
+    for (int i = tid; i < nl; i += 1024) {
+        const double dv = m.dcur[lo + i];
+        const double zv = (i < n1 ? row1[i] : sgn * row2[i]) * 0.70710678118654752440;
+        D[i] = dv; z[i] = zv;
+        dmax = fmax(dmax, fabs(dv)); zmax = fmax(zmax, fabs(zv));
+        m.rowpole[lo + i] = -1;
+    }
+    dmax = block_max<16>(dmax, red, tid);
+    zmax = block_max<16>(zmax, red, tid);
+    for (int i = tid; i < nl; i += 1024) {
+        const double di = D[i];
+        int r = 0;
+        for (int q = 0; q < nl; ++q) { const double dq = D[q]; r += (dq < di) || (dq == di && q < i); }
+        ord[r] = i;
+    }
+    __syncthreads();
+    for (int s = tid; s < nl; s += 1024) { const int c = ord[s]; ds[s] = D[c]; zs[s] = z[c]; }
+    __syncthreads();
+    if (tid != 0) return;
+    const double tol = 8.0 * DC_EPS * fmax(dmax, zmax);
+    int k = 0, nd = 0, nrot = 0;
+    auto pole = [&](int s) { const int c = ord[s]; m.dl[lo + k] = ds[s]; m.zl[lo + k] = zs[s]; m.pcol[lo + k] = c; m.rowpole[lo + c] = k; ++k; };
+    auto defl = [&](int s) { m.dval[lo + nd] = ds[s]; m.dcol[lo + nd] = ord[s]; ++nd; };
+    if (rho * zmax <= tol) {
+        for (int s = 0; s < nl; ++s) defl(s);
+    } else {
+        int pj = -1;
+        for (int jj = 0; jj < nl; ++jj) {
+            if (rho * fabs(zs[jj]) <= tol) { defl(jj); continue; }
+            if (pj < 0) { pj = jj; continue; }
+            double s_ = zs[pj], c_ = zs[jj];
+            const double tau = hypot(c_, s_), t = ds[jj] - ds[pj];
+            c_ /= tau; s_ = -s_ / tau;
+            if (fabs(t * c_ * s_) <= tol) {
+                zs[jj] = tau; zs[pj] = 0.0;
+                m.rcp[lo + nrot] = ord[pj]; m.rcj[lo + nrot] = ord[jj]; m.rc[lo + nrot] = c_; m.rs[lo + nrot] = s_; ++nrot;
+                const double tt = ds[pj] * c_ * c_ + ds[jj] * s_ * s_;
+                ds[jj] = ds[pj] * s_ * s_ + ds[jj] * c_ * c_;
+                ds[pj] = tt;
+                defl(pj);
+                pj = jj;
+            } else { pole(pj); pj = jj; }
+        }
+        pole(pj);
+    }
+    m.mk[lo] = k; m.mrot[lo] = nrot; m.mrho[lo] = rho;
+}
+
+// Root j of  1 + rho sum_i z_i^2 / (d_i - lambda)  between d_j and d_{j+1} (the last one: right of d_{k-1}), one wave per root.
+// The unknown is tau = lambda - d_origin with the origin at the nearer pole; the iteration interpolates the poles left of the
+// root by s + a / (p - tau) and the ones right of it by r + b / (q - tau) with value and slope matched ("middle way"), and falls
+// back to bisection of the bracket whenever the model's root leaves it.
+__global__ void __launch_bounds__(256) dc_secular_kernel(const DcMat* __restrict__ mats, const DcMerge* __restrict__ merges, int nlmax)
+{
+    extern __shared__ double sh[];
+    double* dl = sh;
+    double* z2 = sh + nlmax;
+    const DcMerge mg = merges[blockIdx.y];
+    const DcMat m = mats[mg.mat];
+    const int lo = mg.lo, k = m.mk[lo], tid = threadIdx.x, lane = tid & 63;
+    if ((int)blockIdx.x * 4 >= k) return;
+    for (int i = tid; i < k; i += 256) { dl[i] = m.dl[lo + i]; const double zv = m.zl[lo + i]; z2[i] = zv * zv; }
+    __syncthreads();
+    const int j = blockIdx.x * 4 + (tid >> 6);
+    if (j >= k) return;
+    const double rho = m.mrho[lo];
+    int o = 0;
+    double tau;
+    if (k == 1) tau = rho * z2[0];
+    else {
+        const bool last = j == k - 1;
+        int p0, p1;
+        double lo_b, hi_b;
+        if (last) {
+            double s = 0.0;
+            for (int i = lane; i < k; i += 64) s += z2[i];
+            const double width = rho * wave_sum(s), mid = 0.5 * width;
+            o = j; p0 = j - 1; p1 = j;
+            const double dorg = dl[o];
+            double g = 0.0;
+            for (int i = lane; i < k; i += 64) g += z2[i] / ((dl[i] - dorg) - mid);
+            g = 1.0 + rho * wave_sum(g);
+            if (g <= 0.0) { lo_b = mid; hi_b = width; } else { lo_b = 0.0; hi_b = mid; }
+        } else {
+            const double width = dl[j + 1] - dl[j], mid = 0.5 * width;
+            p0 = j; p1 = j + 1;
+            const double dj = dl[j];
+            double g = 0.0;
+            for (int i = lane; i < k; i += 64) g += z2[i] / ((dl[i] - dj) - mid);
+            g = 1.0 + rho * wave_sum(g);
+            if (g >= 0.0) { o = j; lo_b = 0.0; hi_b = mid; } else { o = j + 1; lo_b = -mid; hi_b = 0.0; }
+        }
+        const double dorg = dl[o];
+        const double p = dl[p0] - dorg, q = dl[p1] - dorg;
+        const int nlft = p0 + 1;
+        tau = 0.5 * (lo_b + hi_b);
+        for (int it = 0; it < 100; ++it) {
+            double sg = 0.0, sa = 0.0, psi = 0.0, dpsi = 0.0, phi = 0.0, dphi = 0.0;
+            for (int i = lane; i < k; i += 64) {
+                const double den = (dl[i] - dorg) - tau;
+                const double t = rho * z2[i] / den, dt = t / den;
+                sg += t; sa += fabs(t);
+                if (i < nlft) { psi += t; dpsi += dt; } else { phi += t; dphi += dt; }
+            }
+            sg = wave_sum(sg); sa = wave_sum(sa); psi = wave_sum(psi); dpsi = wave_sum(dpsi); phi = wave_sum(phi); dphi = wave_sum(dphi);
+            const double g = 1.0 + sg;
+            if (fabs(g) <= DC_EPS * (8.0 * sa + 1.0)) break;
+            if (g > 0.0) hi_b = tau; else lo_b = tau;
+            if (hi_b - lo_b <= 2.0 * DC_EPS * fmax(fabs(lo_b), fabs(hi_b))) break;
+            const double a = dpsi * (p - tau) * (p - tau), sc = psi - dpsi * (p - tau);
+            const double b = dphi * (q - tau) * (q - tau), rcst = phi - dphi * (q - tau);
+            const double c = 1.0 + sc + rcst;
+            const double A2 = c, B2 = -(c * (p + q) + a + b), C2 = c * p * q + a * q + b * p;      // c (p-t)(q-t) + a (q-t) + b (p-t) = 0
+            double t1 = 0.5 * (lo_b + hi_b), t2 = t1;
+            bool h1 = false, h2 = false;
+            if (A2 == 0.0) { if (B2 != 0.0) { t1 = -C2 / B2; h1 = true; } }
+            else {
+                const double disc = B2 * B2 - 4.0 * A2 * C2;
+                if (disc >= 0.0) {
+                    const double sq = sqrt(disc), qq = -0.5 * (B2 + (B2 >= 0.0 ? sq : -sq));
+                    if (qq != 0.0) { t1 = C2 / qq; h1 = true; }
+                    t2 = qq / A2; h2 = true;
+                }
+            }
+            if (h1 && t1 > lo_b && t1 < hi_b) tau = t1;
+            else if (h2 && t2 > lo_b && t2 < hi_b) tau = t2;
+            else tau = 0.5 * (lo_b + hi_b);
+        }
+    }
+    if (lane == 0) { m.org[lo + j] = o; m.tau[lo + j] = tau; m.lam[lo + j] = dl[o] + tau; }
+}
+
+// Loewner weights (Gu / Eisenstat: the z for which the computed roots are the exact eigenvalues -- this is what makes the
+// eigenvector columns orthogonal to round-off), column norms, and the final order of the node's eigenvalues.
+__global__ void __launch_bounds__(1024) dc_weights_kernel(const DcMat* __restrict__ mats, const DcMerge* __restrict__ merges, int nlmax)
+{
+    extern __shared__ double sh[];
+    double* dl = sh;
+    double* od = sh + nlmax;                  // d_origin(j)
+    double* tau = sh + 2 * (size_t)nlmax;
+    double* zh = sh + 3 * (size_t)nlmax;
+    double* val = sh;                         // reuses dl | od once the weights are done
+    const DcMerge mg = merges[blockIdx.x];
+    const DcMat m = mats[mg.mat];
+    const int lo = mg.lo, nl = mg.hi - mg.lo, k = m.mk[lo], tid = threadIdx.x;
+    for (int j = tid; j < k; j += 1024) { dl[j] = m.dl[lo + j]; tau[j] = m.tau[lo + j]; }
+    __syncthreads();
+    for (int j = tid; j < k; j += 1024) od[j] = dl[m.org[lo + j]];
+    __syncthreads();
+    for (int i = tid; i < k; i += 1024) {
+        const double di = dl[i];
+        double w = (di - od[i]) - tau[i];
+        for (int j = 0; j < k; ++j) if (j != i) w *= ((di - od[j]) - tau[j]) / (di - dl[j]);
+        const double zv = copysign(sqrt(fabs(w)), m.zl[lo + i]);
+        zh[i] = zv; m.zhat[lo + i] = zv;
+    }
+    __syncthreads();
+    for (int j = tid; j < k; j += 1024) {
+        const double oj = od[j], tj = tau[j];
+        double s = 0.0;
+        for (int i = 0; i < k; ++i) { const double t = zh[i] / ((dl[i] - oj) - tj); s += t * t; }
+        m.cnorm[lo + j] = 1.0 / sqrt(s);
+    }
+    __syncthreads();
+    for (int x = tid; x < nl; x += 1024) val[x] = x < k ? m.lam[lo + x] : m.dval[lo + x - k];
+    __syncthreads();
+    for (int x = tid; x < nl; x += 1024) {
+        const double v = val[x];
+        int r = 0;
+        for (int q = 0; q < nl; ++q) { const double u = val[q]; r += (u < v) || (u == v && q < x); }
+        m.dcur[lo + r] = v;
+        m.colroot[lo + r] = x < k ? x : -(x - k) - 1;
+        if (x >= k) m.pcolmap[lo + m.dcol[lo + x - k]] = r;
+    }
+}
+
+// U (node block): column of root j = zhat_i / (d_i - lambda_j), normalised, in the rows of the non-deflated poles; column of a
+// deflated pole = the unit vector of its old column.  64 x 64 elements per workgroup.
+__global__ void __launch_bounds__(256) dc_fill_u_kernel(const DcMat* __restrict__ mats, const DcMerge* __restrict__ merges)
+{
+    __shared__ int rp[64];
+    __shared__ double rz[64], rd[64];
+    const DcMerge mg = merges[blockIdx.z];
+    const DcMat m = mats[mg.mat];
+    const int lo = mg.lo, nl = mg.hi - mg.lo, tid = threadIdx.x;
+    const int c = blockIdx.x * 64 + (tid & 63), rbase = blockIdx.y * 64;
+    if ((int)blockIdx.x * 64 >= nl || rbase >= nl) return;
+    if (tid < 64) {
+        const int r = rbase + tid;
+        int i = -1;
+        if (r < nl) i = m.rowpole[lo + r];
+        rp[tid] = i;
+        if (i >= 0) { rz[tid] = m.zhat[lo + i]; rd[tid] = m.dl[lo + i]; }
+    }
+    __syncthreads();
+    if (c >= nl) return;
+    const int cr = m.colroot[lo + c];
+    double od = 0.0, tj = 0.0, cn = 0.0;
+    int dcolv = -1;
+    if (cr >= 0) { od = m.dl[lo + m.org[lo + cr]]; tj = m.tau[lo + cr]; cn = m.cnorm[lo + cr]; }
+    else dcolv = m.dcol[lo - cr - 1];
+    for (int rr = tid >> 6; rr < 64; rr += 4) {
+        const int r = rbase + rr;
+        if (r >= nl) break;
+        double v;
+        if (cr >= 0) v = rp[rr] >= 0 ? rz[rr] / ((rd[rr] - od) - tj) * cn : 0.0;
+        else v = dcolv == r ? 1.0 : 0.0;
+        m.U[(int64_t)(lo + r) * m.ldu + lo + c] = v;
+    }
+}
+
+// The type-2 deflation rotations act on columns of blockdiag(Q1, Q2); Q G U' = Q (G U'), so they are applied to the ROWS of U
+// instead, in reverse order, one thread per column of U.  A chain pj_1 -> jj_1 = pj_2 -> jj_2 .. is a register recurrence: the
+// row of a deflated pole is still the unit row of its final column when its rotation is reached, so nothing but the survivor's
+// row is ever loaded.
+__global__ void __launch_bounds__(256) dc_rot_kernel(const DcMat* __restrict__ mats, const DcMerge* __restrict__ merges, int nlmax)
+{
+    extern __shared__ double sh[];
+    double* rc = sh;
+    double* rs = sh + nlmax;
+    int* rcp = (int*)(sh + 2 * (size_t)nlmax);
+    int* rcj = rcp + nlmax;
+    int* pmap = rcj + nlmax;
+    const DcMerge mg = merges[blockIdx.y];
+    const DcMat m = mats[mg.mat];
+    const int lo = mg.lo, nl = mg.hi - mg.lo, nrot = m.mrot[lo], tid = threadIdx.x;
+    if (nrot == 0 || (int)blockIdx.x * 256 >= nl) return;
+    for (int t = tid; t < nrot; t += 256) { rc[t] = m.rc[lo + t]; rs[t] = m.rs[lo + t]; const int cp = m.rcp[lo + t]; rcp[t] = cp; rcj[t] = m.rcj[lo + t]; pmap[t] = m.pcolmap[lo + cp]; }
+    __syncthreads();
+    const int p = blockIdx.x * 256 + tid;
+    if (p >= nl) return;
+    double* Ucol = m.U + (int64_t)lo * m.ldu + lo + p;
+    int t = nrot - 1;
+    while (t >= 0) {
+        double R = Ucol[(int64_t)rcj[t] * m.ldu];
+        bool cont;
+        do {
+            const double e = pmap[t] == p ? 1.0 : 0.0, c = rc[t], s = rs[t];
+            Ucol[(int64_t)rcj[t] * m.ldu] = s * e + c * R;
+            R = c * e - s * R;
+            cont = t > 0 && rcj[t - 1] == rcp[t];
+            if (!cont) Ucol[(int64_t)rcp[t] * m.ldu] = R;
+            --t;
+        } while (cont);
+    }
+}
+
+__global__ void __launch_bounds__(256) dc_out_kernel(const DcMat* __restrict__ mats)
+{
+    const DcMat m = mats[blockIdx.y];
+    const double sc = m.scale[0];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < m.n; i += gridDim.x * 256) m.w[i] = m.dcur[i] * sc;
+}
+
+// boundaries of the tree's nodes at a depth: repeated halving of [0, n)
+std::vector<int> tree_bounds(int n, int level)
+{
+    std::vector<int> b{0, n};
+    for (int l = 0; l < level; ++l) {
+        std::vector<int> nb;
+        for (size_t i = 0; i + 1 < b.size(); ++i) { nb.push_back(b[i]); nb.push_back((b[i] + b[i + 1]) / 2); }
+        nb.push_back(n);
+        b.swap(nb);
+    }
+    return b;
+}
+
+struct GemmSet {                                   // the tile lists of one dependent GEMM step
+    size_t big_off = 0, small_off = 0;
+    int32_t nbig = 0, nsmall = 0;
+};
+
+template <class K> dmrgx_status set_dyn_lds(K kernel, size_t bytes)
+{
+    if (bytes > 64 * 1024) DMRGX_HIP(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return DMRGX_OK;
+}
+
+}  // namespace
+
+dmrgx_status symeig_batched(const std::vector<SymEigMat>& mats_in, hipStream_t st)
+{
+    std::vector<SymEigMat> M;
+    for (const SymEigMat& s : mats_in) {
+        if (s.n < 0 || s.n > SYMEIG_MAX_N) DMRGX_FAIL(DMRGX_ERR_ARG, "symeig: matrix of order %d (supported: 0..%d)", s.n, SYMEIG_MAX_N);
+        if (s.n > 0 && (!s.A || !s.X || !s.w || s.lda < s.n || s.ldx < s.n)) DMRGX_FAIL(DMRGX_ERR_ARG, "symeig: bad matrix descriptor");
+        if (s.n > 0) M.push_back(s);
+    }
+    const int nm = (int)M.size();
+    if (nm == 0) return DMRGX_OK;
+    int nmax = 0;
+    for (const SymEigMat& s : M) nmax = std::max(nmax, s.n);
+
+    // ---- workspace -----------------------------------------------------------------------------------------------------
+    struct Ws { int64_t VT, Vc, TV, Q1, U, y, d, e, tau, dcur, scale, vecs, G, Tn, W; int64_t ints; int nblk; };
+    std::vector<Ws> ws(nm);
+    int64_t dtot = 0, itot = 0;
+    constexpr int NVEC = 10, NINT = 10;              // per-position double / int arrays of DcMat
+    for (int i = 0; i < nm; ++i) {
+        const int64_t n = M[i].n, nn = n * n;
+        Ws& w = ws[i];
+        w.nblk = (int)((std::max<int64_t>(n - 2, 0) + WY_NB - 1) / WY_NB);
+        w.VT = dtot; dtot += nn;
+        w.Vc = dtot; dtot += nn;
+        w.TV = dtot; dtot += nn;
+        w.Q1 = dtot; dtot += nn;
+        w.U = dtot; dtot += nn;
+        w.y = dtot; dtot += 2 * n;
+        w.d = dtot; dtot += n; w.e = dtot; dtot += n; w.tau = dtot; dtot += n; w.dcur = dtot; dtot += n;
+        w.scale = dtot; dtot += 8;
+        w.vecs = dtot; dtot += NVEC * n;
+        w.G = dtot; dtot += (int64_t)w.nblk * WY_NB * WY_NB;
+        w.Tn = dtot; dtot += (int64_t)w.nblk * WY_NB * WY_NB;
+        w.W = dtot; dtot += (int64_t)WY_NB * n;
+        w.ints = itot; itot += NINT * n;
+    }
+    DevBuf dbuf, ibuf;
+    DMRGX_CHK(dbuf.alloc((size_t)dtot * sizeof(double)));
+    DMRGX_CHK(ibuf.alloc((size_t)itot * sizeof(int32_t)));
+    double* B = dbuf.as<double>();
+    int32_t* I = ibuf.as<int32_t>();
+
+    // ---- 1. tridiagonalisation -------------------------------------------------------------------------------------------
+    {
+        std::vector<TridMat> tm(nm);
+        for (int i = 0; i < nm; ++i) tm[i] = TridMat{M[i].A, B + ws[i].VT, B + ws[i].y, B + ws[i].d, B + ws[i].e, B + ws[i].tau, M[i].n, M[i].lda, M[i].n, 0};
+        DevBuf d_tm;
+        DMRGX_CHK(upload(d_tm, tm, st));
+        const size_t lds = (size_t)3 * nmax * sizeof(double);
+        DMRGX_CHK(set_dyn_lds(trid_step_kernel, lds));
+        for (int j = 0; j < nmax; ++j) {
+            unsigned grid = 0;
+            for (int i = 0; i < nm; ++i) if (j < M[i].n) grid += (unsigned)std::max(1, (M[i].n - j - 1 + TRID_ROWS - 1) / TRID_ROWS);
+            hipLaunchKernelGGL(trid_step_kernel, dim3(grid), dim3(TRID_THREADS), lds, st, d_tm.as<TridMat>(), nm, j);
+        }
+        DMRGX_HIP(hipGetLastError());
+    }
+
+    // ---- 3a. (independent of the eigenvectors) V = (V^T)^T, the Gram blocks, T factors and T V^T ---------------------------------
+    std::vector<GProd> prods;
+    std::vector<GGroup> groups;
+    std::vector<GTile> tiles;                         // all tile lists, one after the other
+    auto add_set = [&](std::vector<GTile>& big, std::vector<GTile>& small) {
+        GemmSet s;
+        ggemm_schedule(big, 2); ggemm_schedule(small);
+        s.big_off = tiles.size(); s.nbig = (int32_t)big.size(); tiles.insert(tiles.end(), big.begin(), big.end());
+        s.small_off = tiles.size(); s.nsmall = (int32_t)small.size(); tiles.insert(tiles.end(), small.begin(), small.end());
+        return s;
+    };
+    auto add_gemm = [&](std::vector<GTile>& big, std::vector<GTile>& small, double* C, int ldc, int Mr, int Nc, const double* A, int lda, const double* Bm, int ldb, int K, int accumulate) {
+        if (Mr <= 0 || Nc <= 0 || K <= 0) return;
+        prods.push_back(GProd{A, Bm, lda, ldb, K, GPROD_GEMM, 1.0});
+        groups.push_back(GGroup{C, ldc, Mr, Nc, (int32_t)prods.size() - 1, (int32_t)prods.size(), 0, accumulate});
+        ggemm_append_tiles_mixed(big, small, (int32_t)groups.size() - 1, Mr, Nc, (K + GG_BK - 1) / GG_BK);
+    };
+    std::vector<SqPair> tp(nm);
+    std::vector<WyBlock> wyb;
+    GemmSet set_gram, set_tv;
+    int max_nblk = 0;
+    {
+        std::vector<GTile> gb, gs, tb, tsm;
+        for (int i = 0; i < nm; ++i) {
+            const int n = M[i].n;
+            const Ws& w = ws[i];
+            max_nblk = std::max(max_nblk, w.nblk);
+            tp[i] = SqPair{B + w.VT, B + w.Vc, n, n, n, 0};
+            for (int b = 0; b < w.nblk; ++b) {
+                const int b0 = b * WY_NB, kb = std::min(WY_NB, n - 2 - b0), r0 = b0 + 1;      // reflectors b0 .. b0+kb-1 live in rows >= b0+1
+                double* G = B + w.G + (int64_t)b * WY_NB * WY_NB;
+                double* Tn = B + w.Tn + (int64_t)b * WY_NB * WY_NB;
+                add_gemm(gb, gs, G, WY_NB, kb, kb, B + w.VT + (int64_t)b0 * n + r0, n, B + w.Vc + (int64_t)r0 * n + b0, n, n - r0, 0);
+                wyb.push_back(WyBlock{G, B + w.tau + b0, Tn, kb, 0});
+                add_gemm(tb, tsm, B + w.TV + (int64_t)b0 * n, n, kb, n, Tn, WY_NB, B + w.VT + (int64_t)b0 * n, n, kb, 0);     // (T V^T)_b = Tneg_b . V_b^T
+            }
+        }
+        set_gram = add_set(gb, gs);
+        set_tv = add_set(tb, tsm);
+    }
+
+    // ---- 2. divide-and-conquer tables --------------------------------------------------------------------------------------
+    std::vector<DcMat> dm(nm);
+    std::vector<DcLeaf> leaves;
+    std::vector<int> depth(nm, 0);
+    int dmax = 0;
+    for (int i = 0; i < nm; ++i) {
+        const int n = M[i].n;
+        const Ws& w = ws[i];
+        int D = 0;
+        while ((n + (1 << D) - 1) / (1 << D) > DC_LEAF) ++D;
+        depth[i] = D; dmax = std::max(dmax, D);
+        DcMat& q = dm[i];
+        q.Q[0] = M[i].X; q.ldq[0] = M[i].ldx;
+        q.Q[1] = B + w.Q1; q.ldq[1] = n;
+        q.U = B + w.U; q.ldu = n;
+        q.d = B + w.d; q.e = B + w.e; q.dcur = B + w.dcur; q.scale = B + w.scale; q.w = M[i].w;
+        double* v = B + w.vecs;
+        q.dl = v; q.zl = v + n; q.tau = v + 2 * (int64_t)n; q.lam = v + 3 * (int64_t)n; q.zhat = v + 4 * (int64_t)n; q.cnorm = v + 5 * (int64_t)n;
+        q.dval = v + 6 * (int64_t)n; q.rc = v + 7 * (int64_t)n; q.rs = v + 8 * (int64_t)n; q.mrho = v + 9 * (int64_t)n;
+        int32_t* iv = I + w.ints;
+        q.org = iv; q.pcol = iv + n; q.dcol = iv + 2 * (int64_t)n; q.rowpole = iv + 3 * (int64_t)n; q.colroot = iv + 4 * (int64_t)n; q.pcolmap = iv + 5 * (int64_t)n;
+        q.rcp = iv + 6 * (int64_t)n; q.rcj = iv + 7 * (int64_t)n; q.mk = iv + 8 * (int64_t)n; q.mrot = iv + 9 * (int64_t)n;
+        q.n = n;
+        const std::vector<int> b = tree_bounds(n, D);
+        for (size_t t = 0; t + 1 < b.size(); ++t) leaves.push_back(DcLeaf{i, b[t], b[t + 1], D & 1});
+    }
+    struct Step { size_t merge_off = 0; int nmerge = 0, nlmax = 0; GemmSet gemm; };
+    std::vector<Step> steps((size_t)dmax);
+    std::vector<DcMerge> merges;
+    for (int t = 1; t <= dmax; ++t) {
+        Step& s = steps[(size_t)t - 1];
+        s.merge_off = merges.size();
+        std::vector<GTile> gb, gs;
+        for (int i = 0; i < nm; ++i) {
+            if (depth[i] < t) continue;
+            const int lev = depth[i] - t, n = M[i].n;           // the level being produced; its children live at lev + 1
+            const std::vector<int> pb = tree_bounds(n, lev), cb = tree_bounds(n, lev + 1);
+            const int src = (lev + 1) & 1, dst = lev & 1;
+            for (size_t u = 0; u + 1 < pb.size(); ++u) {
+                const int lo = pb[u], mid = cb[2 * u + 1], hi = pb[u + 1];
+                merges.push_back(DcMerge{i, lo, mid, hi, src, 0});
+                s.nlmax = std::max(s.nlmax, hi - lo);
+                double* Qd = dm[i].Q[dst]; const int ldd = dm[i].ldq[dst];
+                const double* Qs = dm[i].Q[src]; const int lds_ = dm[i].ldq[src];
+                const double* U = dm[i].U; const int ldu = dm[i].ldu;
+                add_gemm(gb, gs, Qd + (int64_t)lo * ldd + lo, ldd, mid - lo, hi - lo, Qs + (int64_t)lo * lds_ + lo, lds_, U + (int64_t)lo * ldu + lo, ldu, mid - lo, 0);
+                add_gemm(gb, gs, Qd + (int64_t)mid * ldd + lo, ldd, hi - mid, hi - lo, Qs + (int64_t)mid * lds_ + mid, lds_, U + (int64_t)mid * ldu + lo, ldu, hi - mid, 0);
+            }
+        }
+        s.nmerge = (int)(merges.size() - s.merge_off);
+        s.gemm = add_set(gb, gs);
+    }
+
+    // ---- 3b. back-transformation steps (last block first), aligned at the end of every matrix's block list ------------------------
+    std::vector<GemmSet> bt_w((size_t)max_nblk), bt_x((size_t)max_nblk);
+    for (int s = 0; s < max_nblk; ++s) {
+        std::vector<GTile> wb, wsm, xb, xs;
+        for (int i = 0; i < nm; ++i) {
+            const Ws& w = ws[i];
+            const int b = w.nblk - 1 - s, n = M[i].n;
+            if (b < 0) continue;
+            const int b0 = b * WY_NB, kb = std::min(WY_NB, n - 2 - b0), r0 = b0 + 1;
+            double* X = M[i].X; const int ldx = M[i].ldx;
+            add_gemm(wb, wsm, B + w.W, n, kb, n, B + w.TV + (int64_t)b0 * n + r0, n, X + (int64_t)r0 * ldx, ldx, n - r0, 0);          // W = -(T V^T) X
+            add_gemm(xb, xs, X + (int64_t)r0 * ldx, ldx, n - r0, n, B + w.Vc + (int64_t)r0 * n + b0, n, B + w.W, n, kb, 1);             // X += V W
+        }
+        bt_w[(size_t)s] = add_set(wb, wsm);
+        bt_x[(size_t)s] = add_set(xb, xs);
+    }
+
+    // ---- uploads ---------------------------------------------------------------------------------------------------------------
+    if (prods.empty()) prods.push_back(GProd{nullptr, nullptr, 0, 0, 0, GPROD_GEMM, 0.0});
+    if (groups.empty()) groups.push_back(GGroup{nullptr, 0, 0, 0, 0, 0, 0, 0});
+    if (tiles.empty()) tiles.push_back(GTile{-1, 0, 0, 0});
+    if (merges.empty()) merges.push_back(DcMerge{0, 0, 0, 0, 0, 0});
+    if (wyb.empty()) wyb.push_back(WyBlock{nullptr, nullptr, nullptr, 0, 0});
+    DevBuf d_prods, d_groups, d_tiles, d_tp, d_wyb, d_dm, d_leaves, d_merges;
+    DMRGX_CHK(upload(d_prods, prods, st)); DMRGX_CHK(upload(d_groups, groups, st)); DMRGX_CHK(upload(d_tiles, tiles, st));
+    DMRGX_CHK(upload(d_tp, tp, st)); DMRGX_CHK(upload(d_wyb, wyb, st)); DMRGX_CHK(upload(d_dm, dm, st));
+    DMRGX_CHK(upload(d_leaves, leaves, st)); DMRGX_CHK(upload(d_merges, merges, st));
+    auto run_set = [&](const GemmSet& s) -> dmrgx_status {
+        DMRGX_CHK(ggemm_launch(d_tiles.as<GTile>() + s.big_off, d_groups.as<GGroup>(), d_prods.as<GProd>(), s.nbig, st, 1));
+        DMRGX_CHK(ggemm_launch(d_tiles.as<GTile>() + s.small_off, d_groups.as<GGroup>(), d_prods.as<GProd>(), s.nsmall, st, 0));
+        return DMRGX_OK;
+    };
+
+    // ---- 3a: launches ----------------------------------------------------------------------------------------------------------
+    const bool any_blk = max_nblk > 0;
+    if (any_blk) {
+        const unsigned t32 = (unsigned)((nmax + 31) / 32);
+        hipLaunchKernelGGL(transpose_sq_kernel, dim3(t32, t32, (unsigned)nm), dim3(256), 0, st, d_tp.as<SqPair>());
+        DMRGX_HIP(hipGetLastError());
+        DMRGX_CHK(run_set(set_gram));
+        hipLaunchKernelGGL(wy_tinv_kernel, dim3((unsigned)wyb.size()), dim3(WY_NB), 0, st, d_wyb.as<WyBlock>());
+        DMRGX_HIP(hipGetLastError());
+        DMRGX_CHK(run_set(set_tv));
+    }
+
+    // ---- 2: launches -------------------------------------------------------------------------------------------------------------
+    const DcMat* ddm = d_dm.as<DcMat>();
+    hipLaunchKernelGGL(dc_scale_kernel, dim3((unsigned)nm), dim3(256), 0, st, ddm);
+    hipLaunchKernelGGL(dc_leaf_kernel, dim3((unsigned)leaves.size()), dim3(256), 0, st, ddm, d_leaves.as<DcLeaf>());
+    DMRGX_HIP(hipGetLastError());
+    for (const Step& s : steps) {
+        if (s.nmerge == 0) continue;
+        const DcMerge* mp = d_merges.as<DcMerge>() + s.merge_off;
+        const int nl = s.nlmax;
+        const size_t lds_defl = (size_t)nl * (4 * sizeof(double) + sizeof(int)) + 16;
+        const size_t lds_sec = (size_t)nl * 2 * sizeof(double);
+        const size_t lds_wgt = (size_t)nl * 4 * sizeof(double);
+        const size_t lds_rot = (size_t)nl * (2 * sizeof(double) + 3 * sizeof(int)) + 16;
+        DMRGX_CHK(set_dyn_lds(dc_deflate_kernel, lds_defl)); DMRGX_CHK(set_dyn_lds(dc_secular_kernel, lds_sec));
+        DMRGX_CHK(set_dyn_lds(dc_weights_kernel, lds_wgt)); DMRGX_CHK(set_dyn_lds(dc_rot_kernel, lds_rot));
+        hipLaunchKernelGGL(dc_deflate_kernel, dim3((unsigned)s.nmerge), dim3(1024), lds_defl, st, ddm, mp, nl);
+        hipLaunchKernelGGL(dc_secular_kernel, dim3((unsigned)((nl + 3) / 4), (unsigned)s.nmerge), dim3(256), lds_sec, st, ddm, mp, nl);
+        hipLaunchKernelGGL(dc_weights_kernel, dim3((unsigned)s.nmerge), dim3(1024), lds_wgt, st, ddm, mp, nl);
+        hipLaunchKernelGGL(dc_fill_u_kernel, dim3((unsigned)((nl + 63) / 64), (unsigned)((nl + 63) / 64), (unsigned)s.nmerge), dim3(256), 0, st, ddm, mp);
+        hipLaunchKernelGGL(dc_rot_kernel, dim3((unsigned)((nl + 255) / 256), (unsigned)s.nmerge), dim3(256), lds_rot, st, ddm, mp, nl);
+        DMRGX_HIP(hipGetLastError());
+        DMRGX_CHK(run_set(s.gemm));
+    }
+    hipLaunchKernelGGL(dc_out_kernel, dim3((unsigned)((nmax + 255) / 256), (unsigned)nm), dim3(256), 0, st, ddm);
+    DMRGX_HIP(hipGetLastError());
+
+    // ---- 3b: launches ------------------------------------------------------------------------------------------------------------
+    for (int s = 0; s < max_nblk; ++s) { DMRGX_CHK(run_set(bt_w[(size_t)s])); DMRGX_CHK(run_set(bt_x[(size_t)s])); }
+    return DMRGX_OK;
+}
+
+}  // namespace dmrgx

@@ -1168,6 +1168,8 @@ public:
         }
         if (use_rdm_warm && W == 1) for (int side = 0; side < 2; ++side) {      /* remember this visit's eigenbases (all eigenvectors, as rows) */
             if (keys[side] < 0 || (side == 1 && keyR == keyL)) continue;
+            /* a side whose spectrum was borrowed (dead block of a pruned sweep) has no eigenvectors: drop what an earlier visit stored */
+            if (!need_vec[side]) { rdm_basis.erase({keys[side], side}); continue; }
             WarmBasis& wb = rdm_basis[{keys[side], side}];
             wb.sizes = side == 0 ? ls : rs;
             wb.E.clear();

@@ -283,11 +283,3 @@ def apply_factored_numpy(sb, x):
             Y += a * (A @ X[ks] @ Bm.T)
         y[off[k]:off[k + 1]] = Y.ravel()
     return y
-
-
-def alg_counts(sb):
-    """(F_alg, B_alg) per apply with the formulas of SURVEY 8d, computed from the actual cells."""
-    terms = sb.terms
-    right_used = sorted({(OpSp if t[3] != OpSz else OpSz, t[4], t[3]) for t in terms})
-    left_used = sorted({(OpSp if t[1] != OpSz else OpSz, t[2], t[1]) for t in terms})
-    return dict(n_left=len(left_used), n_right=len(right_used))

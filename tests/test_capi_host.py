@@ -25,6 +25,19 @@ def test_library_exports_every_declared_symbol(pkg):
     assert lib.dmrgx_abi_version() == 2
 
 
+def test_integration_document_prints_the_header_signatures(pkg):
+    """Every call form `dmrgx_x(a, b, ...)` printed in INTEGRATION.md has the argument count of the ABI (a maintainer
+    copying the document must get code that compiles)."""
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    seen = 0
+    for name, args in re.findall(r"\b(dmrgx_[a-z0-9_]+)\(([^()]*)\)", doc):
+        assert name in pkg._capi.SIGNATURES, f"INTEGRATION.md names {name}, which include/dmrgx.h does not declare"
+        n = 0 if not args.strip() else args.count(",") + 1
+        assert n == len(pkg._capi.SIGNATURES[name][1]), f"INTEGRATION.md prints {name}({args}) but the ABI takes {len(pkg._capi.SIGNATURES[name][1])} arguments"
+        seen += 1
+    assert seen >= 15
+
+
 def test_product_does_not_import_oracle():
     """The product package must never route through the CPU oracle."""
     for fn in os.listdir(os.path.join(ROOT, "dmrg.x_amd")):
