@@ -809,7 +809,7 @@ static dmrgx_status rdm_create_impl(const dmrgx_sectors* left, const dmrgx_secto
     P->sweeps = sweep;
     if (sweep >= 30) DMRGX_FAIL(DMRGX_ERR_NOTCONV, "rdm_create: block Jacobi did not converge in 30 sweeps");
 
-    {
+    if (!use_dc) {           // (the direct solver's eigenvectors are products of Householder and GEMM factors: no drift to remove)
         int max_npad = JS;
         for (auto& m : P->mats) max_npad = std::max(max_npad, m.npad);
         hipLaunchKernelGGL(normalize_columns_kernel, dim3((max_npad + 63) / 64, nm), dim3(256), 0, st, dm, buf);

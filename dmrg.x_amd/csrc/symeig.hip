@@ -27,6 +27,7 @@ namespace dmrgx {
 namespace {
 
 constexpr int TRID_THREADS = 256, TRID_ROWS = 8;      // rows of the trailing matrix per workgroup (two per wave)
+constexpr int TRID_PF = 8;                            // chunks of 64 columns requested per row before they are used
 constexpr int DC_LEAF = 32;                           // largest leaf of the divide-and-conquer tree
 constexpr int WY_NB = 64;                             // reflectors per block of the back-transformation
 constexpr double DC_EPS = DBL_EPSILON;
@@ -81,21 +82,21 @@ __device__ __forceinline__ double block_max(double v, double* red, int tid)
 // Stored state at the start of launch j: rows / columns >= j of A carry the updates of reflectors 0 .. j-2; y_{j-1} = A v_{j-1}
 // (un-scaled) and v_{j-1}, tau_{j-1} are in memory.  Row j is read by everybody and written by nobody (it retires here), rows
 // > j are each updated by exactly one wave, so the launch has no write-read race on A.
+constexpr int TRID_MAXM = 32;                         // matrices per launch: their descriptors travel in the kernel argument segment
+struct TridArgs { TridMat m[TRID_MAXM]; };            // (a descriptor table in memory costs every workgroup two dependent cold loads
+                                                      //  before it can ask for its vectors: ~1.5 us of a ~5 us launch)
 __global__ void __launch_bounds__(TRID_THREADS)
-trid_step_kernel(const TridMat* __restrict__ mats, int nm, int j)
+trid_step_kernel(const TridArgs args, int j)
 {
     extern __shared__ double sh[];                  // w | v_{j-1} | row j, then v_j   (indexed by the absolute column)
     __shared__ double red[TRID_THREADS / 64];
-    int b = blockIdx.x, mi = 0;
-    for (; mi < nm; ++mi) {
-        const int n = mats[mi].n;
-        const int wgs = j < n ? max(1, (n - j - 1 + TRID_ROWS - 1) / TRID_ROWS) : 0;
-        if (b < wgs) break;
-        b -= wgs;
-    }
-    if (mi == nm) return;
-    const TridMat m = mats[mi];
-    const int n = m.n, tid = threadIdx.x, g = b;
+    const TridMat& m = args.m[blockIdx.y];
+    const int n = m.n, tid = threadIdx.x, g = blockIdx.x;
+    // Workgroup g owns rows [8 g, 8 g + 8) of its matrix in EVERY launch (the grid does not shrink with j: workgroups whose rows have
+    // all retired leave at once), so a row is always handled by the same position of the grid.  The last row block also does the
+    // bookkeeping of the column (it is never retired before the matrix is done).
+    const int glast = (n - 1) / TRID_ROWS;
+    if (j >= n || g > glast || (TRID_ROWS * g + TRID_ROWS - 1 <= j && g != glast)) return;
     double* sw = sh;
     double* svp = sh + n;
     double* svj = sh + 2 * n;
@@ -104,6 +105,21 @@ trid_step_kernel(const TridMat* __restrict__ mats, int nm, int j)
     double* yc = m.y + (size_t)(j & 1) * n;
     const double* vprow = m.VT + (int64_t)(j > 0 ? j - 1 : 0) * m.ldv;
     const double* arow = m.A + (int64_t)j * m.lda;
+    // the rows this wave will update.  Their first TRID_PF chunks of 64 columns are requested now, ahead of the column's vector work
+    // (the loads depend on nothing but addresses; the update is latency-bound otherwise)
+    const int lane = tid & 63, wave = tid >> 6;
+    const int i0 = TRID_ROWS * g + 2 * wave;            // rows i0, i0+1, where they still belong to the trailing matrix (> j)
+    const bool r0 = i0 > j && i0 < n, r1 = i0 + 1 > j && i0 + 1 < n;
+    double* a0 = m.A + (int64_t)(r0 ? i0 : j) * m.lda;
+    double* a1 = m.A + (int64_t)(r1 ? i0 + 1 : j) * m.lda;
+    const int kb = j + 1 + lane;
+    double pa0[TRID_PF], pa1[TRID_PF];
+#pragma unroll
+    for (int c = 0; c < TRID_PF; ++c) {
+        const int k = kb + 64 * c;
+        pa0[c] = (r0 && k < n) ? a0[k] : 0.0;
+        pa1[c] = (r1 && k < n) ? a1[k] : 0.0;
+    }
     double s = 0.0;
     for (int k = j + tid; k < n; k += TRID_THREADS) {
         const double vp = j > 0 ? vprow[k] : 0.0, y = j > 0 ? yp[k] : 0.0;
@@ -135,32 +151,217 @@ trid_step_kernel(const TridMat* __restrict__ mats, int nm, int j)
     for (int k = j + tid; k < n; k += TRID_THREADS)     // a reflector with tau = 0 is stored as the zero vector (H = I)
         svj[k] = (k <= j || tj == 0.0) ? 0.0 : (k == j + 1 ? 1.0 : svj[k] * scale);
     __syncthreads();
-    if (g == 0) {
+    if (g == glast) {
         double* vt = m.VT + (int64_t)j * m.ldv;
         for (int k = tid; k < n; k += TRID_THREADS) vt[k] = k > j ? svj[k] : 0.0;
         if (tid == 0) { m.d[j] = dj; if (j + 1 < n) m.e[j] = beta; m.tau[j] = tj; }
     }
-    // ---- rows j+1+8g .. : A[i,:] -= v_{j-1}[i] w^T + w[i] v_{j-1}^T, then y_j[i] = A[i,:] . v_j -- two rows per wave
-    const int lane = tid & 63, wave = tid >> 6;
-    const int i0 = j + 1 + TRID_ROWS * g + 2 * wave;
-    if (i0 >= n) return;
-    const bool two = i0 + 1 < n;
-    double* a0 = m.A + (int64_t)i0 * m.lda;
-    double* a1 = a0 + (two ? m.lda : 0);
-    const double vp0 = svp[i0], w0 = sw[i0], vp1 = two ? svp[i0 + 1] : 0.0, w1 = two ? sw[i0 + 1] : 0.0;
+    // ---- own rows: A[i,:] -= v_{j-1}[i] w^T + w[i] v_{j-1}^T, then y_j[i] = A[i,:] . v_j -- two rows per wave
+    if (!r0 && !r1) return;
+    const double vp0 = r0 ? svp[i0] : 0.0, w0 = r0 ? sw[i0] : 0.0, vp1 = r1 ? svp[i0 + 1] : 0.0, w1 = r1 ? sw[i0 + 1] : 0.0;
     double acc0 = 0.0, acc1 = 0.0;
-#pragma unroll 4
-    for (int k = j + 1 + lane; k < n; k += 64) {
-        const double wk = sw[k], vpk = svp[k], vjk = svj[k];
-        double x0 = a0[k], x1 = a1[k];
-        x0 -= vp0 * wk + w0 * vpk;
-        x1 -= vp1 * wk + w1 * vpk;
-        a0[k] = x0;
-        if (two) a1[k] = x1;
-        acc0 += x0 * vjk; acc1 += x1 * vjk;
+#pragma unroll
+    for (int c = 0; c < TRID_PF; ++c) {
+        const int k = kb + 64 * c;
+        if (k < n) {
+            const double wk = sw[k], vpk = svp[k], vjk = svj[k];
+            const double x0 = pa0[c] - (vp0 * wk + w0 * vpk), x1 = pa1[c] - (vp1 * wk + w1 * vpk);
+            if (r0) a0[k] = x0;
+            if (r1) a1[k] = x1;
+            acc0 += x0 * vjk; acc1 += x1 * vjk;
+        }
+    }
+    for (int kc = kb + 64 * TRID_PF; kc < n + lane; kc += 64 * TRID_PF) {     // (kc - lane < n: wave-uniform trip count)
+#pragma unroll
+        for (int c = 0; c < TRID_PF; ++c) {
+            const int k = kc + 64 * c;
+            pa0[c] = (r0 && k < n) ? a0[k] : 0.0;
+            pa1[c] = (r1 && k < n) ? a1[k] : 0.0;
+        }
+#pragma unroll
+        for (int c = 0; c < TRID_PF; ++c) {
+            const int k = kc + 64 * c;
+            if (k < n) {
+                const double wk = sw[k], vpk = svp[k], vjk = svj[k];
+                const double x0 = pa0[c] - (vp0 * wk + w0 * vpk), x1 = pa1[c] - (vp1 * wk + w1 * vpk);
+                if (r0) a0[k] = x0;
+                if (r1) a1[k] = x1;
+                acc0 += x0 * vjk; acc1 += x1 * vjk;
+            }
+        }
     }
     acc0 = wave_sum(acc0); acc1 = wave_sum(acc1);
-    if (lane == 0) { yc[i0] = acc0; if (two) yc[i0 + 1] = acc1; }
+    if (lane == 0) { if (r0) yc[i0] = acc0; if (r1) yc[i0 + 1] = acc1; }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// 1b. tridiagonalisation with the matrices RESIDENT IN LDS: one persistent launch
+// ---------------------------------------------------------------------------------------------------------------------------
+// The launch-per-column kernel above pays, per column, a kernel boundary plus a chain of cold loads (~4 us) and streams the whole
+// trailing matrix through the fabric twice (read + write-back: ~5 us on average at m = 2048).  Here the rows of a matrix are dealt
+// cyclically over G workgroups (one per CU, up to 160 KB of LDS each: 16 rows of a 1037 x 1037 matrix) and never leave the chip;
+// per column the workgroups exchange only what the vector work needs -- y_j = A v_j (each publishes the entries of its rows) and
+// the next pivot row (published by its owner while it updates it) -- as 8-byte {epoch, half of a double} granules written with
+// agent-scope atomic stores and polled with agent-scope atomic loads: the data is the flag, no fence, no ordering assumption
+// (cdna_hip_programming.md section 6, Guideline 16, form R2).  Buffers are double-buffered by column parity: a workgroup can be at
+// most one column ahead of the slowest one, because publishing column j+1 needs everybody's column j.  Every spin is bounded: a
+// workgroup that is not served in time (its partners are not resident -- e.g. another process holds CUs with a persistent kernel of
+// its own) sets the status word and leaves; the host then repeats the step with the launch-per-column kernel (A is only read here).
+typedef unsigned long long u64;
+typedef u64 __attribute__((address_space(1))) gu64;
+#define DMRGX_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+constexpr int TC_THREADS = 512, TC_WAVES = TC_THREADS / 64;
+constexpr int TC_SPIN_LIMIT = 1 << 19;               // polls of one batch of granules before giving up (~0.5 s)
+constexpr int TC_KB = 4;                             // columns per thread whose granules are in flight together
+
+struct TcMat {
+    const double* A; double *VT, *d, *e, *tau;
+    u64 *ybuf, *rowbuf;                               // 2 (parity) x n x 2 granules each
+    int32_t n, lda, ldv, G, wg0, pad;
+};
+struct TcArgs { TcMat m[TRID_MAXM]; int32_t* status; int32_t nm, pad; };
+
+__device__ __forceinline__ void put_f64(u64* g, unsigned epoch, double v)
+{
+    const u64 b = (u64)__double_as_longlong(v), e = (u64)epoch << 32;
+    __hip_atomic_store((gu64*)g, e | (b & 0xffffffffull), DMRGX_RLX_AGENT);
+    __hip_atomic_store((gu64*)(g + 1), e | (b >> 32), DMRGX_RLX_AGENT);
+}
+__device__ __forceinline__ bool wait_f64(const u64* g, unsigned epoch, double& v)
+{
+    for (int spins = 0; spins < TC_SPIN_LIMIT; ++spins) {
+        const u64 x0 = __hip_atomic_load((gu64*)g, DMRGX_RLX_AGENT), x1 = __hip_atomic_load((gu64*)(g + 1), DMRGX_RLX_AGENT);
+        if ((unsigned)(x0 >> 32) == epoch && (unsigned)(x1 >> 32) == epoch) { v = __longlong_as_double((long long)((x0 & 0xffffffffull) | (x1 << 32))); return true; }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    v = 0.0;
+    return false;
+}
+
+__global__ void __launch_bounds__(TC_THREADS)
+trid_coop_kernel(const TcArgs args)
+{
+    extern __shared__ __attribute__((aligned(16))) double shc[];      // w | v (two buffers, swapped per column) | the rows of this workgroup
+    __shared__ double red[TC_WAVES];
+    __shared__ int sfail;
+    const int b = blockIdx.x;
+    int mi = 0;
+    for (; mi < args.nm; ++mi) if (b >= args.m[mi].wg0 && b < args.m[mi].wg0 + args.m[mi].G) break;
+    if (mi == args.nm) return;
+    const TcMat& m = args.m[mi];
+    const int n = m.n, G = m.G, g = b - m.wg0, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double* sw = shc;
+    double* svp = shc + n;
+    double* svj = shc + 2 * (size_t)n;
+    double* rows = shc + 3 * (size_t)n;                 // row t of this workgroup = row g + G t of the matrix
+    const int cnt = g < n ? (n - g + G - 1) / G : 0;
+    for (int t = 0; t < cnt; ++t) {
+        const double* src = m.A + (int64_t)(g + G * t) * m.lda;
+        for (int k = tid; k < n; k += TC_THREADS) rows[(size_t)t * n + k] = src[k];
+    }
+    for (int k = tid; k < n; k += TC_THREADS) { svj[k] = 0.0; svp[k] = 0.0; sw[k] = 0.0; }
+    if (g == 0) for (int k = tid; k < n; k += TC_THREADS) put_f64(m.rowbuf + 2 * (size_t)k, 1u, m.A[k]);     // row 0, epoch 1
+    if (tid == 0) sfail = 0;
+    __syncthreads();
+    double tau_p = 0.0;
+    for (int j = 0; j < n; ++j) {
+        { double* t = svp; svp = svj; svj = t; }                      // svp = v_{j-1}
+        const u64* rb = m.rowbuf + (size_t)(j & 1) * 2 * n;              // row j, epoch j+1
+        const u64* yb = m.ybuf + (size_t)((j + 1) & 1) * 2 * n;          // y_{j-1}, epoch j
+        double s = 0.0;
+        bool ok = true;
+        // every granule this thread needs is requested before the first tag is looked at (TC_KB columns x 4 loads in flight), and only
+        // the columns that were not there yet are asked for again
+        for (int k0 = j + tid; k0 < n; k0 += TC_THREADS * TC_KB) {
+            unsigned pending = 0;
+#pragma unroll
+            for (int c = 0; c < TC_KB; ++c) if (k0 + c * TC_THREADS < n) pending |= 1u << c;
+            for (int spins = 0; pending; ++spins) {
+                u64 x[TC_KB][4];
+#pragma unroll
+                for (int c = 0; c < TC_KB; ++c) {
+                    if (!(pending >> c & 1)) continue;
+                    const size_t k = (size_t)(k0 + c * TC_THREADS);
+                    x[c][0] = __hip_atomic_load((gu64*)(rb + 2 * k), DMRGX_RLX_AGENT);
+                    x[c][1] = __hip_atomic_load((gu64*)(rb + 2 * k + 1), DMRGX_RLX_AGENT);
+                    if (j > 0) { x[c][2] = __hip_atomic_load((gu64*)(yb + 2 * k), DMRGX_RLX_AGENT); x[c][3] = __hip_atomic_load((gu64*)(yb + 2 * k + 1), DMRGX_RLX_AGENT); }
+                }
+#pragma unroll
+                for (int c = 0; c < TC_KB; ++c) {
+                    if (!(pending >> c & 1)) continue;
+                    const unsigned er = (unsigned)(j + 1), ey = (unsigned)j;
+                    bool ready = (unsigned)(x[c][0] >> 32) == er && (unsigned)(x[c][1] >> 32) == er;
+                    if (j > 0) ready = ready && (unsigned)(x[c][2] >> 32) == ey && (unsigned)(x[c][3] >> 32) == ey;
+                    if (!ready) continue;
+                    const int k = k0 + c * TC_THREADS;
+                    const double a = __longlong_as_double((long long)((x[c][0] & 0xffffffffull) | (x[c][1] << 32)));
+                    const double y = j > 0 ? __longlong_as_double((long long)((x[c][2] & 0xffffffffull) | (x[c][3] << 32))) : 0.0;
+                    sw[k] = y; svj[k] = a;
+                    pending &= ~(1u << c);
+                }
+                if (pending) {
+                    if (spins > TC_SPIN_LIMIT) { ok = false; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+        }
+        // INVARIANT: the vector arithmetic of a column is done redundantly by every workgroup of the matrix and must be BIT-IDENTICAL in
+        // all of them (same thread -> column map, same summation order): they never exchange v_j or w, so a one-ulp disagreement is
+        // never repaired and the recurrence amplifies it (found the hard way: adding y.v in granule-arrival order broke Tr T = Tr A).
+        for (int k = j + tid; k < n; k += TC_THREADS) s += sw[k] * svp[k];
+        if (!ok) sfail = 1;
+        s = block_sum<TC_WAVES>(s, red, tid);
+        if (sfail) { if (tid == 0) __hip_atomic_store(args.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+        const double coef = 0.5 * tau_p * tau_p * s;
+        for (int k = j + tid; k < n; k += TC_THREADS) sw[k] = tau_p * sw[k] - coef * svp[k];
+        __syncthreads();
+        const double wj = sw[j], vpj = svp[j];
+        double sig = 0.0;
+        for (int k = j + tid; k < n; k += TC_THREADS) {
+            const double r = svj[k] - vpj * sw[k] - wj * svp[k];
+            svj[k] = r;
+            if (k >= j + 2) sig += r * r;
+        }
+        sig = block_sum<TC_WAVES>(sig, red, tid);
+        const double dj = svj[j];
+        const double alpha = (j + 1 < n) ? svj[j + 1] : 0.0;
+        double beta = alpha, tj = 0.0, scale = 0.0;
+        if (sig > 0.0) {
+            const double nrm = sqrt(alpha * alpha + sig);
+            beta = alpha >= 0.0 ? -nrm : nrm;
+            tj = (beta - alpha) / beta;
+            scale = 1.0 / (alpha - beta);
+        }
+        __syncthreads();
+        for (int k = j + tid; k < n; k += TC_THREADS) svj[k] = (k <= j || tj == 0.0) ? 0.0 : (k == j + 1 ? 1.0 : svj[k] * scale);
+        __syncthreads();
+        if (g == 0) {
+            double* vt = m.VT + (int64_t)j * m.ldv;
+            for (int k = tid; k < n; k += TC_THREADS) vt[k] = k > j ? svj[k] : 0.0;
+            if (tid == 0) { m.d[j] = dj; if (j + 1 < n) m.e[j] = beta; m.tau[j] = tj; }
+        }
+        tau_p = tj;
+        // ---- own rows (in LDS): update with reflector j-1, multiply by v_j; the owner of row j+1 publishes it while it is in hand
+        u64* rbn = m.rowbuf + (size_t)((j + 1) & 1) * 2 * n;
+        u64* ybn = m.ybuf + (size_t)(j & 1) * 2 * n;
+        for (int t = wave; t < cnt; t += TC_WAVES) {
+            const int i = g + G * t;
+            if (i <= j) continue;
+            double* row = rows + (size_t)t * n;
+            const double vpi = svp[i], wi = sw[i];
+            const bool pub = i == j + 1;
+            double acc = 0.0;
+            for (int k = j + 1 + lane; k < n; k += 64) {
+                const double x = row[k] - (vpi * sw[k] + wi * svp[k]);
+                row[k] = x;
+                acc += x * svj[k];
+                if (pub) put_f64(rbn + 2 * (size_t)k, (unsigned)(j + 2), x);
+            }
+            acc = wave_sum(acc);
+            if (lane == 0) put_f64(ybn + 2 * (size_t)i, (unsigned)(j + 1), acc);
+        }
+        __syncthreads();
+    }
 }
 
 // dst (n x n, ld) = src^T for every matrix (V from V^T)
@@ -266,7 +467,7 @@ __global__ void __launch_bounds__(256) dc_leaf_kernel(const DcMat* __restrict__ 
         for (int e = tid; e < P * P; e += 256) { const int i = e / P, c = e % P; const double v = S[i][c]; if (i == c) dg += v * v; else off += v * v; }
         off = block_sum<4>(off, red, tid);
         dg = block_sum<4>(dg, red, tid);
-        if (off <= 1e-34 * dg || off == 0.0) break;          // uniform over the workgroup
+        if (off <= 2e-31 * dg || off == 0.0) break;          // off-diagonal norm <= 2 eps |T|; uniform over the workgroup
         for (int r = 0; r < P - 1; ++r) {
             if (tid < H) {                                   // pair tid of round r (round-robin tournament of 32 indices)
                 int a, bq;
@@ -609,6 +810,8 @@ std::vector<int> tree_bounds(int n, int level)
     return b;
 }
 
+bool g_coop_disabled = false;                       // set once a persistent round has timed out (process-wide)
+
 struct GemmSet {                                   // the tile lists of one dependent GEMM step
     size_t big_off = 0, small_off = 0;
     int32_t nbig = 0, nsmall = 0;
@@ -665,20 +868,80 @@ dmrgx_status symeig_batched(const std::vector<SymEigMat>& mats_in, hipStream_t s
     int32_t* I = ibuf.as<int32_t>();
 
     // ---- 1. tridiagonalisation -------------------------------------------------------------------------------------------
-    {
-        std::vector<TridMat> tm(nm);
-        for (int i = 0; i < nm; ++i) tm[i] = TridMat{M[i].A, B + ws[i].VT, B + ws[i].y, B + ws[i].d, B + ws[i].e, B + ws[i].tau, M[i].n, M[i].lda, M[i].n, 0};
-        DevBuf d_tm;
-        DMRGX_CHK(upload(d_tm, tm, st));
-        const size_t lds = (size_t)3 * nmax * sizeof(double);
-        DMRGX_CHK(set_dyn_lds(trid_step_kernel, lds));
-        for (int j = 0; j < nmax; ++j) {
-            unsigned grid = 0;
-            for (int i = 0; i < nm; ++i) if (j < M[i].n) grid += (unsigned)std::max(1, (M[i].n - j - 1 + TRID_ROWS - 1) / TRID_ROWS);
-            hipLaunchKernelGGL(trid_step_kernel, dim3(grid), dim3(TRID_THREADS), lds, st, d_tm.as<TridMat>(), nm, j);
+    // Matrices whose rows fit the LDS of at most all CUs go through the persistent kernel (in rounds of <= #CUs workgroups and
+    // <= 32 matrices); larger ones, and every one of them if a round reports a bounded-spin timeout, through one launch per column.
+    auto trid_by_launches = [&](const std::vector<int>& set) -> dmrgx_status {
+        for (size_t c0 = 0; c0 < set.size(); c0 += TRID_MAXM) {
+            const int cn = (int)std::min<size_t>(TRID_MAXM, set.size() - c0);
+            TridArgs ta;
+            int gmax = 0;
+            for (int i = 0; i < TRID_MAXM; ++i) {
+                if (i < cn) { const int q = set[c0 + i]; ta.m[i] = TridMat{M[q].A, B + ws[q].VT, B + ws[q].y, B + ws[q].d, B + ws[q].e, B + ws[q].tau, M[q].n, M[q].lda, M[q].n, 0}; gmax = std::max(gmax, M[q].n); }
+                else ta.m[i] = TridMat{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0};
+            }
+            const size_t lds = (size_t)3 * gmax * sizeof(double);
+            DMRGX_CHK(set_dyn_lds(trid_step_kernel, lds));
+            const unsigned gx = (unsigned)((gmax + TRID_ROWS - 1) / TRID_ROWS);
+            for (int j = 0; j < gmax; ++j) hipLaunchKernelGGL(trid_step_kernel, dim3(gx, (unsigned)cn), dim3(TRID_THREADS), lds, st, ta, j);
         }
         DMRGX_HIP(hipGetLastError());
-    }
+        return DMRGX_OK;
+    };
+    static const bool coop_wanted = !(getenv("DMRGX_TRID") && std::string(getenv("DMRGX_TRID")) == "launch");     // developer aid / A-B
+    std::vector<int> launch_set, coop_set;
+    DevBuf gran;                                       // status word (first 16 bytes) + granule buffers of the persistent rounds
+    int32_t coop_status = 0;
+    bool coop_ran = false;
+    if (coop_wanted && !g_coop_disabled) {
+        int dev = 0, ncu = 0, max_lds = 0;
+        DMRGX_HIP(hipGetDevice(&dev));
+        DMRGX_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+        DMRGX_HIP(hipDeviceGetAttribute(&max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev));
+        const int64_t dyn_max = std::min<int64_t>(max_lds, 160 * 1024) - 256;       // (static LDS of the kernel: a few words)
+        std::vector<int> order(nm);
+        std::iota(order.begin(), order.end(), 0);
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return M[a].n > M[b].n; });
+        struct Round { std::vector<int> mats, G; int wgs = 0; };
+        std::vector<Round> rounds;
+        for (int q : order) {
+            const int64_t n = M[q].n, cap = (dyn_max / 8 - 3 * n) / n;               // rows of this matrix one workgroup can hold
+            const int G = cap >= 1 ? (int)((n + cap - 1) / cap) : ncu + 1;
+            if (G > ncu) { launch_set.push_back(q); continue; }
+            Round* r = nullptr;
+            for (Round& c : rounds) if (c.wgs + G <= ncu && (int)c.mats.size() < TRID_MAXM) { r = &c; break; }
+            if (!r) { rounds.emplace_back(); r = &rounds.back(); }
+            r->mats.push_back(q); r->G.push_back(G); r->wgs += G;
+            coop_set.push_back(q);
+        }
+        if (!rounds.empty()) {
+            int64_t gtot = 2;                                                        // in u64 words; the status word owns the first 16 bytes
+            std::vector<int64_t> goff(nm, 0);
+            for (int q : coop_set) { goff[q] = gtot; gtot += 8 * (int64_t)M[q].n; }   // ybuf, rowbuf: 2 parities x n x 2 granules each
+            gtot = (gtot + 1) & ~(int64_t)1;
+            DMRGX_CHK(gran.alloc((size_t)gtot * sizeof(u64)));
+            DMRGX_HIP(hipMemsetAsync(gran.p, 0, (size_t)gtot * sizeof(u64), st));     // epochs start at 1: a zeroed granule is "not yet"
+            u64* GB = gran.as<u64>();
+            DMRGX_HIP(hipFuncSetAttribute((const void*)trid_coop_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_max));
+            for (const Round& r : rounds) {
+                TcArgs ta;
+                ta.status = reinterpret_cast<int32_t*>(GB); ta.nm = (int32_t)r.mats.size(); ta.pad = 0;
+                size_t lds = 0;
+                int wg0 = 0;
+                for (int i = 0; i < TRID_MAXM; ++i) {
+                    if (i < (int)r.mats.size()) {
+                        const int q = r.mats[(size_t)i], n = M[q].n, G = r.G[(size_t)i], rows = (n + G - 1) / G;
+                        ta.m[i] = TcMat{M[q].A, B + ws[q].VT, B + ws[q].d, B + ws[q].e, B + ws[q].tau, GB + goff[q], GB + goff[q] + 4 * (int64_t)n, n, M[q].lda, n, G, wg0, 0};
+                        wg0 += G;
+                        lds = std::max(lds, (size_t)(3 + rows) * n * sizeof(double));
+                    } else ta.m[i] = TcMat{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 1 << 30, 0};
+                }
+                hipLaunchKernelGGL(trid_coop_kernel, dim3((unsigned)wg0), dim3(TC_THREADS), lds, st, ta);
+                DMRGX_HIP(hipGetLastError());
+            }
+            coop_ran = true;
+        }
+    } else for (int q = 0; q < nm; ++q) launch_set.push_back(q);
+    if (!launch_set.empty()) DMRGX_CHK(trid_by_launches(launch_set));
 
     // ---- 3a. (independent of the eigenvectors) V = (V^T)^T, the Gram blocks, T factors and T V^T ---------------------------------
     std::vector<GProd> prods;
@@ -801,6 +1064,65 @@ dmrgx_status symeig_batched(const std::vector<SymEigMat>& mats_in, hipStream_t s
     DMRGX_CHK(upload(d_prods, prods, st)); DMRGX_CHK(upload(d_groups, groups, st)); DMRGX_CHK(upload(d_tiles, tiles, st));
     DMRGX_CHK(upload(d_tp, tp, st)); DMRGX_CHK(upload(d_wyb, wyb, st)); DMRGX_CHK(upload(d_dm, dm, st));
     DMRGX_CHK(upload(d_leaves, leaves, st)); DMRGX_CHK(upload(d_merges, merges, st));
+    // ---- the persistent rounds have had the host's table building and the table uploads to run in: did every workgroup get its partners? ---------------
+    if (coop_ran) {
+        DMRGX_HIP(hipMemcpyAsync(&coop_status, gran.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));      // (a pageable copy: it may block, so it is issued here)
+        DMRGX_HIP(hipStreamSynchronize(st));
+        if (coop_status != 0) {
+            if (!g_coop_disabled) fprintf(stderr, "[dmrgx] persistent tridiagonalisation timed out waiting for a partner workgroup (GPU shared with another "
+                                                  "persistent kernel?): using one launch per column from now on\n");
+            g_coop_disabled = true;
+            DMRGX_CHK(trid_by_launches(coop_set));     // A was only read by the persistent kernel
+        }
+        if (const char* dir = getenv("DMRGX_TRID_DUMP")) {      // developer aid: A, d, e of the largest matrix of the second call, for offline checks
+            static int call = 0;
+            if (call++ == 1 && !coop_set.empty()) {
+                const int q = coop_set[0];
+                const int64_t n = M[q].n;
+                std::vector<double> hA((size_t)n * M[q].lda), hd((size_t)2 * n);
+                DMRGX_HIP(hipMemcpy(hA.data(), M[q].A, hA.size() * 8, hipMemcpyDeviceToHost));
+                DMRGX_HIP(hipMemcpy(hd.data(), B + ws[q].d, (size_t)n * 8, hipMemcpyDeviceToHost));
+                DMRGX_HIP(hipMemcpy(hd.data() + n, B + ws[q].e, (size_t)n * 8, hipMemcpyDeviceToHost));
+                const std::string fn = std::string(dir) + "/trid_dump.bin";
+                if (FILE* f = fopen(fn.c_str(), "wb")) {
+                    const int64_t hdr[2] = {n, M[q].lda};
+                    fwrite(hdr, 8, 2, f); fwrite(hA.data(), 8, hA.size(), f); fwrite(hd.data(), 8, hd.size(), f);
+                    fclose(f);
+                }
+            }
+        }
+        if (getenv("DMRGX_TRID_CHECK")) {             // developer aid: the same matrices through the launch-per-column kernel, d / e / tau compared
+            for (int q : coop_set) {
+                const int64_t n = M[q].n;
+                DevBuf a2, w2;
+                DMRGX_CHK(a2.alloc((size_t)n * M[q].lda * sizeof(double)));
+                DMRGX_CHK(w2.alloc((size_t)(n * n + 6 * n) * sizeof(double)));
+                DMRGX_HIP(hipMemcpyAsync(a2.p, M[q].A, (size_t)n * M[q].lda * sizeof(double), hipMemcpyDeviceToDevice, st));
+                double* W2 = w2.as<double>();
+                TridArgs ta;
+                for (int i = 0; i < TRID_MAXM; ++i) ta.m[i] = TridMat{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0};
+                ta.m[0] = TridMat{a2.as<double>(), W2, W2 + n * n, W2 + n * n + 2 * n, W2 + n * n + 3 * n, W2 + n * n + 4 * n, (int32_t)n, M[q].lda, (int32_t)n, 0};
+                const size_t lds = (size_t)3 * n * sizeof(double);
+                DMRGX_CHK(set_dyn_lds(trid_step_kernel, lds));
+                for (int j = 0; j < n; ++j) hipLaunchKernelGGL(trid_step_kernel, dim3((unsigned)((n + TRID_ROWS - 1) / TRID_ROWS), 1), dim3(TRID_THREADS), lds, st, ta, j);
+                std::vector<double> h1((size_t)3 * n), h2((size_t)3 * n);
+                DMRGX_HIP(hipMemcpy(h1.data(), B + ws[q].d, (size_t)n * 8, hipMemcpyDeviceToHost));
+                DMRGX_HIP(hipMemcpy(h1.data() + n, B + ws[q].e, (size_t)n * 8, hipMemcpyDeviceToHost));
+                DMRGX_HIP(hipMemcpy(h1.data() + 2 * n, B + ws[q].tau, (size_t)n * 8, hipMemcpyDeviceToHost));
+                DMRGX_HIP(hipMemcpy(h2.data(), W2 + n * n + 2 * n, (size_t)3 * n * 8, hipMemcpyDeviceToHost));
+                double worst = 0.0; int first = -1;
+                for (int64_t i = 0; i < 3 * n; ++i) {
+                    if (i % n == n - 1 && i / n == 1) continue;      // e[n-1] does not exist
+                    const double df = fabs(h1[(size_t)i] - h2[(size_t)i]);
+                    if (df > worst) worst = df;
+                    if (first < 0 && df > 1e-9) first = (int)i;
+                }
+                fprintf(stderr, "[trid-check] n=%lld max |d,e,tau (persistent) - (launches)| = %.3e%s", (long long)n, worst, first < 0 ? "\n" : "");
+                if (first >= 0) fprintf(stderr, "  first mismatch: %s[%d] %.15g vs %.15g\n", first / n == 0 ? "d" : first / n == 1 ? "e" : "tau", (int)(first % n), h1[(size_t)first], h2[(size_t)first]);
+            }
+        }
+    }
+
     auto run_set = [&](const GemmSet& s) -> dmrgx_status {
         DMRGX_CHK(ggemm_launch(d_tiles.as<GTile>() + s.big_off, d_groups.as<GGroup>(), d_prods.as<GProd>(), s.nbig, st, 1));
         DMRGX_CHK(ggemm_launch(d_tiles.as<GTile>() + s.small_off, d_groups.as<GGroup>(), d_prods.as<GProd>(), s.nsmall, st, 0));
