@@ -90,16 +90,37 @@ def cpu_baseline_factored(sb, reps=5):
                       f"{f.flops / 1e9:.1f} GF of SURVEY 8d's F_alg: terms merged per right operator, structural zeros of O(x)1 skipped)"}
 
 
-def engine_run(opts, timeout=300):
-    """Run the drop-in sweep engine (dmrg.x_amd/dmrgx-square-lattice, the host C++ driver over the same C ABI) in a child
-    process and return its DMRGRun.json.  Child process: it owns its own HIP context, nothing is exec'd from this one."""
+def engine_run(opts, timeout=300, ranks=1, rehearsal=False):
+    """Run the drop-in sweep engine (dmrg.x_amd/dmrgx-square-lattice, the host C++ driver over the same C ABI) in child
+    processes and return its DMRGRun.json.  Child processes: they own their HIP contexts, nothing is exec'd from this one.
+    ranks > 1: one engine process per GPU with the environment its communicator start-up reads (RANK / WORLD_SIZE / LOCAL_RANK,
+    petsc_compat.hpp::CommBootstrap: RCCL id through a rendezvous file); rehearsal: all ranks on GPU 0, host-staged back-end."""
     import subprocess
     import tempfile
     exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dmrg.x_amd", "dmrgx-square-lattice")
     with tempfile.TemporaryDirectory(prefix="dmrgx_bench_") as d:
-        r = subprocess.run([exe, *[str(o) for o in opts], "-data_dir", d + "/"], capture_output=True, text=True, timeout=timeout)
-        if r.returncode != 0:
-            raise RuntimeError("sweep engine failed: " + (r.stdout + r.stderr)[-1000:])
+        cmd = [exe, *[str(o) for o in opts], "-data_dir", d + "/"]
+        if ranks == 1:
+            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}     # a one-rank engine, whatever launched us
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+            if r.returncode != 0:
+                raise RuntimeError("sweep engine failed: " + (r.stdout + r.stderr)[-1000:])
+        else:
+            base = dict(os.environ, WORLD_SIZE=str(ranks), HSA_ENABLE_IPC_MODE_LEGACY="0", DMRGX_RDZV_FILE=os.path.join(d, "rdzv"),
+                        DMRGX_SHM_NAME="dmrgx_bench_eng_%d" % os.getpid(), DMRGX_COMM="shm" if rehearsal else "rccl")
+            procs = [subprocess.Popen(cmd, env=dict(base, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(ranks)]
+            t_end = time.time() + timeout
+            outs, rc = [], 0
+            for p in procs:
+                try:
+                    o, _ = p.communicate(timeout=max(1.0, t_end - time.time()))
+                except subprocess.TimeoutExpired:
+                    for q in procs:
+                        q.kill()                                   # the exact processes started above
+                    raise RuntimeError("sweep engine on %d ranks timed out after %d s" % (ranks, timeout))
+                outs.append(o); rc = rc or p.returncode
+            if rc != 0:
+                raise RuntimeError("sweep engine on %d ranks failed: %s" % (ranks, "".join(outs)[-1500:]))
         run = json.load(open(os.path.join(d, "DMRGRun.json")))
         # per-sweep totals from the reference-format step tables (DMRGSteps.json: LoopType/LoopIdx, Timings.json: Total, MatMults)
         steps = json.load(open(os.path.join(d, "DMRGSteps.json")))["table"]
@@ -183,6 +204,58 @@ def sweep_legs():
     return out
 
 
+def sweep_legs_multi(ranks, rehearsal):
+    """N > 1: the configs[3] engine leg on N ranks (same binary, one process per GPU, striped plans, RDMs dealt over the ranks), and
+    for N = 2 BASELINE configs[2] as specified (Heisenberg 16x6 cylinder, m = 1024, Sz sectors sharded over 2 GPUs).  The rehearsal
+    (tests, one GPU) runs the same control flow on small lattices."""
+    def leg(run, config):
+        return {"sites_per_s": run["LastSweepSteps"] / run["LastSweepSeconds"], "config": config, "ranks": run.get("Ranks"),
+                "sweep_steps": run["LastSweepSteps"], "sweep_seconds": run["LastSweepSeconds"], "sweep_matmults": run["LastSweepMatMults"],
+                "matmults_per_s_in_sweep": run["LastSweepMatMults"] / run["LastSweepSeconds"], "gs_energy": run["GSEnergy"], "max_trunc_err": run["MaxTruncErr"]}
+    j1j2 = ["-J1", 1, "-Jz1", 1, "-J2", 0.5, "-Jz2", 0.5]
+    if rehearsal:
+        big = ["-Lx", 6, "-Ly", 4, "-mwarmup", 48, *j1j2, "-nsweeps", 1]
+        heis = ["-Lx", 6, "-Ly", 2, "-heisenberg", 1, "-mwarmup", 32, "-nsweeps", 1]
+        big_name, heis_name = "rehearsal: J1-J2 6x4, m=48", "rehearsal: Heisenberg 6x2, m=32"
+    else:
+        big = ["-Lx", 20, "-Ly", 8, "-mwarmup", 2048, *j1j2, "-nsweeps", 2, "-H_eps_type", "gd"]
+        heis = ["-Lx", 16, "-Ly", 6, "-heisenberg", 1, "-mwarmup", 1024, "-nsweeps", 2, "-H_eps_type", "gd"]
+        big_name = "configs[3] on %d GPUs: J1-J2 20x8 cylinder, J2=0.5, m=2048, warm-up + two sweeps (-H_eps_type gd); sites_per_s is the second sweep" % ranks
+        heis_name = "configs[2]: Heisenberg 16x6 cylinder, m=1024, on 2 GPUs, warm-up + two sweeps (-H_eps_type gd)"
+    out = {}
+    try:
+        out = leg(engine_run(big, timeout=1200, ranks=ranks, rehearsal=rehearsal), big_name)
+    except Exception as e:                                        # noqa: BLE001 -- reported in the JSON line, the MatMult line stands
+        out = {"error": str(e)[-600:]}
+    if ranks == 2:
+        try:
+            out["configs_2"] = leg(engine_run(heis, timeout=900, ranks=2, rehearsal=rehearsal), heis_name)
+        except Exception as e:                                    # noqa: BLE001
+            out["configs_2"] = {"error": str(e)[-600:]}
+    return out
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` as a plain command: start the N rank processes ourselves (what torch.distributed.run would
+    do: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT), relay rank 0's JSON line, exit with the worst return code.
+    Called before anything in this process has touched the GPU; the children are ordinary child processes (no exec of this one)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    base = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=dict(base, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL) for r in range(n)]
+    out0, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        rc = p.wait() or rc
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    sys.exit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -199,8 +272,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args.gpus)                  # plain `python bench.py --gpus N`: become the launcher (never returns)
     if args.gpus > 1 and world != args.gpus:
-        sys.exit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+        sys.exit(f"--gpus {args.gpus} but the launcher started {world} ranks (WORLD_SIZE)")
     # Rehearsal mode (tests only): DMRGX_BENCH_REHEARSAL=1 runs the N > 1 control flow with all ranks on cuda:0 and the
     # collectives staged through gloo on the host -- RCCL needs one GPU per rank, the one-GPU test box has one.
     rehearsal = os.environ.get("DMRGX_BENCH_REHEARSAL") == "1"
@@ -279,7 +354,7 @@ def main():
 
     out = {
         "metric": "superblock MatMults/sec inside the ground-state eigensolve (Lanczos step = 1 MatMult + reorthogonalisation)",
-        "value": args.steps / elapsed, "unit": "MatMults/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "value": args.steps / elapsed, "unit": "MatMults/s", "n_gpus": comm.info()[1] if comm is not None else 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"{args.workload}: {CONFIGS[args.workload]['desc']}" + ("" if args.workload == "cfg4real" else "; mid-sweep column cut, sector profile sigma=1.8 (SURVEY 8d)"),
@@ -313,18 +388,21 @@ def main():
         out["cpu_baseline"]["reference_row_loop"] = cpu_baseline(sb)
     elif rank == 0:
         out["cpu_baseline"] = None
+    if comm is not None:
+        out["communicator"] = dict(zip(("rank", "world", "backend"), comm.info()), backend_names={"0": "rccl", "1": "host-staged (rehearsal)"})
     plan.destroy()
-    plan = None
-    if rank == 0 and world == 1 and not args.no_sweep:
-        out["sweep"] = sweep_legs()
-    if rank == 0:
-        print(json.dumps(out))
-    if plan is not None:
-        plan.destroy()
     if comm is not None:
         comm.destroy()
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
+    torch.cuda.empty_cache()                     # the engine legs below run in child processes on the same GPU(s)
+    if rank == 0 and not args.no_sweep:
+        # sites/sec per sweep on the real engine: one rank -> the full set of legs; N ranks -> the configs[3] engine leg on N ranks
+        # (and configs[2] for N = 2).  The other bench ranks have finished by now and released their GPUs.
+        out["sweep"] = sweep_legs() if world == 1 else sweep_legs_multi(world, rehearsal)
+    if rank == 0:
+        print(json.dumps(out))
 
 
 if __name__ == "__main__":

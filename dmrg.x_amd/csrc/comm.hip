@@ -13,6 +13,7 @@
 //   host-staged -- several ranks sharing ONE GPU exchange through a POSIX shared-memory segment (RCCL refuses two ranks on one
 //                  device).  Rehearsal of the N > 1 control flow on a one-GPU box (tests); never used for measurements.
 #include "common.h"
+#include "symeig.h"
 #include <rccl/rccl.h>
 #include <dlfcn.h>
 #include <fcntl.h>
@@ -147,6 +148,7 @@ extern "C" dmrgx_status dmrgx_comm_init_host_staged(int32_t rank, int32_t world,
     std::unique_ptr<dmrgx_comm> C(new (std::nothrow) dmrgx_comm());
     if (!C) DMRGX_FAIL(DMRGX_ERR_MEM, "out of host memory");
     C->rank = rank; C->world = world; C->backend = DMRGX_COMM_HOST_STAGED;
+    if (world > 1) symeig_set_persistent(false);      // several ranks share ONE GPU here: persistent kernels that each want most CUs would wait on each other
     C->shm_name = shm_name[0] == '/' ? shm_name : std::string("/") + shm_name;
     const size_t total_mb = getenv("DMRGX_SHM_MB") ? (size_t)atol(getenv("DMRGX_SHM_MB")) : 256;
     const size_t hdr_bytes = 4096;

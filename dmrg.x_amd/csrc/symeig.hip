@@ -29,6 +29,7 @@ namespace {
 constexpr int TRID_THREADS = 256, TRID_ROWS = 8;      // rows of the trailing matrix per workgroup (two per wave)
 constexpr int TRID_PF = 8;                            // chunks of 64 columns requested per row before they are used
 constexpr int DC_LEAF = 32;                           // largest leaf of the divide-and-conquer tree
+constexpr int DC_LEAF_THREADS = 256;                  // (one wave per leaf measured 2x slower: the sweep is bound by its LDS work, not by its barriers)
 constexpr int WY_NB = 64;                             // reflectors per block of the back-transformation
 constexpr double DC_EPS = DBL_EPSILON;
 
@@ -42,6 +43,41 @@ __device__ __forceinline__ double wave_sum(double v)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
+}
+// The same sum in every lane without the LDS crossbar (ds_bpermute costs ~100 cycles per step on the latency path of every column):
+// lane bits 0, 1 by quad permutes, bits 2, 3 by row rotations (a rotation all-reduce: after +ror4 and +ror8 every lane of a row
+// holds the row's sum), bits 4, 5 by the gfx950 row / half swaps.
+#define DMRGX_DPP_ADD(a, CTRL)                                                                                                   \
+    {                                                                                                                            \
+        const int lo_ = __double2loint(a), hi_ = __double2hiint(a);                                                              \
+        a += __hiloint2double(__builtin_amdgcn_update_dpp(0, hi_, CTRL, 0xf, 0xf, false), __builtin_amdgcn_update_dpp(0, lo_, CTRL, 0xf, 0xf, false)); \
+    }
+__device__ __forceinline__ double wave_sum_fast(double a)
+{
+    DMRGX_DPP_ADD(a, 0xb1);      // quad_perm [1,0,3,2]
+    DMRGX_DPP_ADD(a, 0x4e);      // quad_perm [2,3,0,1]
+    DMRGX_DPP_ADD(a, 0x124);     // row_ror:4
+    DMRGX_DPP_ADD(a, 0x128);     // row_ror:8
+    int lo = __double2loint(a), hi = __double2hiint(a);
+    auto l16 = __builtin_amdgcn_permlane16_swap((unsigned)lo, (unsigned)lo, false, false);
+    auto h16 = __builtin_amdgcn_permlane16_swap((unsigned)hi, (unsigned)hi, false, false);
+    a = __hiloint2double((int)h16[0], (int)l16[0]) + __hiloint2double((int)h16[1], (int)l16[1]);
+    lo = __double2loint(a); hi = __double2hiint(a);
+    auto l32 = __builtin_amdgcn_permlane32_swap((unsigned)lo, (unsigned)lo, false, false);
+    auto h32 = __builtin_amdgcn_permlane32_swap((unsigned)hi, (unsigned)hi, false, false);
+    return __hiloint2double((int)h32[0], (int)l32[0]) + __hiloint2double((int)h32[1], (int)l32[1]);
+}
+// one-barrier block sum: `red` must not be in use by waves that have not passed a barrier since they last read it
+template <int NW>
+__device__ __forceinline__ double block_sum1(double v, double* red, int tid)
+{
+    v = wave_sum_fast(v);
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) s += red[w];
+    return s;
 }
 __device__ __forceinline__ double wave_max(double v)
 {
@@ -213,13 +249,15 @@ typedef u64 __attribute__((address_space(1))) gu64;
 constexpr int TC_THREADS = 512, TC_WAVES = TC_THREADS / 64;
 constexpr int TC_SPIN_LIMIT = 1 << 19;               // polls of one batch of granules before giving up (~0.5 s)
 constexpr int TC_KB = 4;                             // columns per thread whose granules are in flight together
+constexpr int TC_MB = 4;                             // chunks of 64 columns of the row pass whose LDS reads are in flight together
+constexpr int TC_VECS = 4;                           // O(n) vectors every workgroup keeps beside its rows
 
 struct TcMat {
     const double* A; double *VT, *d, *e, *tau;
     u64 *ybuf, *rowbuf;                               // 2 (parity) x n x 2 granules each
     int32_t n, lda, ldv, G, wg0, pad;
 };
-struct TcArgs { TcMat m[TRID_MAXM]; int32_t* status; int32_t nm, pad; };
+struct TcArgs { TcMat m[TRID_MAXM]; int32_t* status; long long* prof; int32_t nm, pad; };      // prof: developer aid (phase clocks of one workgroup), else null
 
 __device__ __forceinline__ void put_f64(u64* g, unsigned epoch, double v)
 {
@@ -238,11 +276,14 @@ __device__ __forceinline__ bool wait_f64(const u64* g, unsigned epoch, double& v
     return false;
 }
 
+// (Measured and dropped: the rows in REGISTERS instead of LDS -- 256-thread workgroups, one wave per SIMD, 6 rows x 17 chunks per
+// lane.  The f64 update of a lane's ~100 elements is then one dependent-issue stream per SIMD: 2.5 us per column against ~1 us for
+// eight waves over LDS-resident rows, and the whole column 9.9 us against 4.9.)
 __global__ void __launch_bounds__(TC_THREADS)
 trid_coop_kernel(const TcArgs args)
 {
-    extern __shared__ __attribute__((aligned(16))) double shc[];      // w | v (two buffers, swapped per column) | the rows of this workgroup
-    __shared__ double red[TC_WAVES];
+    extern __shared__ __attribute__((aligned(16))) double shc[];      // y / w (two buffers) | v (two buffers) | the rows of this workgroup
+    __shared__ double red_s[TC_WAVES], red_g[TC_WAVES], piv[2];
     __shared__ int sfail;
     const int b = blockIdx.x;
     int mi = 0;
@@ -251,20 +292,24 @@ trid_coop_kernel(const TcArgs args)
     const TcMat& m = args.m[mi];
     const int n = m.n, G = m.G, g = b - m.wg0, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double* sw = shc;
-    double* svp = shc + n;
-    double* svj = shc + 2 * (size_t)n;
-    double* rows = shc + 3 * (size_t)n;                 // row t of this workgroup = row g + G t of the matrix
+    double* sw_next = shc + n;
+    double* svp = shc + 2 * (size_t)n;
+    double* svj = shc + 3 * (size_t)n;
+    double* rows = shc + TC_VECS * (size_t)n;           // row t of this workgroup = row g + G t of the matrix
     const int cnt = g < n ? (n - g + G - 1) / G : 0;
     for (int t = 0; t < cnt; ++t) {
         const double* src = m.A + (int64_t)(g + G * t) * m.lda;
         for (int k = tid; k < n; k += TC_THREADS) rows[(size_t)t * n + k] = src[k];
     }
-    for (int k = tid; k < n; k += TC_THREADS) { svj[k] = 0.0; svp[k] = 0.0; sw[k] = 0.0; }
+    for (int k = tid; k < n; k += TC_THREADS) { svj[k] = 0.0; svp[k] = 0.0; sw[k] = 0.0; sw_next[k] = 0.0; }
     if (g == 0) for (int k = tid; k < n; k += TC_THREADS) put_f64(m.rowbuf + 2 * (size_t)k, 1u, m.A[k]);     // row 0, epoch 1
     if (tid == 0) sfail = 0;
     __syncthreads();
     double tau_p = 0.0;
+    const bool prof = args.prof && mi == 0 && g == (G > 1 ? 1 : 0) && tid == 0;
+    long long pt[4] = {0, 0, 0, 0}, pc = 0;
     for (int j = 0; j < n; ++j) {
+        if (prof) pc = wall_clock64();
         { double* t = svp; svp = svj; svj = t; }                      // svp = v_{j-1}
         const u64* rb = m.rowbuf + (size_t)(j & 1) * 2 * n;              // row j, epoch j+1
         const u64* yb = m.ybuf + (size_t)((j + 1) & 1) * 2 * n;          // y_{j-1}, epoch j
@@ -309,22 +354,25 @@ trid_coop_kernel(const TcArgs args)
         // all of them (same thread -> column map, same summation order): they never exchange v_j or w, so a one-ulp disagreement is
         // never repaired and the recurrence amplifies it (found the hard way: adding y.v in granule-arrival order broke Tr T = Tr A).
         for (int k = j + tid; k < n; k += TC_THREADS) s += sw[k] * svp[k];
+        if (prof) { const long long c = wall_clock64(); pt[0] += c - pc; pc = c; }
         if (!ok) sfail = 1;
-        s = block_sum<TC_WAVES>(s, red, tid);
+        s = block_sum1<TC_WAVES>(s, red_s, tid);          // (its barrier also publishes the y and the pivot row the other threads just stored)
         if (sfail) { if (tid == 0) __hip_atomic_store(args.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
         const double coef = 0.5 * tau_p * tau_p * s;
-        for (int k = j + tid; k < n; k += TC_THREADS) sw[k] = tau_p * sw[k] - coef * svp[k];
-        __syncthreads();
-        const double wj = sw[j], vpj = svp[j];
+        const double vpj = svp[j], wj = tau_p * sw[j] - coef * vpj;     // w_{j-1}[j], straight from y[j]: no barrier between w and the row update
         double sig = 0.0;
         for (int k = j + tid; k < n; k += TC_THREADS) {
-            const double r = svj[k] - vpj * sw[k] - wj * svp[k];
+            const double vpk = svp[k], wk = tau_p * sw[k] - coef * vpk;
+            const double r = svj[k] - vpj * wk - wj * vpk;          // row j with the update of reflector j-1 applied
+            sw_next[k] = wk;
             svj[k] = r;
             if (k >= j + 2) sig += r * r;
+            if (k == j) piv[0] = r;
+            if (k == j + 1) piv[1] = r;
         }
-        sig = block_sum<TC_WAVES>(sig, red, tid);
-        const double dj = svj[j];
-        const double alpha = (j + 1 < n) ? svj[j + 1] : 0.0;
+        if (j + 1 >= n && tid == 0) piv[1] = 0.0;
+        sig = block_sum1<TC_WAVES>(sig, red_g, tid);
+        const double dj = piv[0], alpha = piv[1];
         double beta = alpha, tj = 0.0, scale = 0.0;
         if (sig > 0.0) {
             const double nrm = sqrt(alpha * alpha + sig);
@@ -332,36 +380,57 @@ trid_coop_kernel(const TcArgs args)
             tj = (beta - alpha) / beta;
             scale = 1.0 / (alpha - beta);
         }
+        for (int k = j + tid; k < n; k += TC_THREADS) svj[k] = (k <= j || tj == 0.0) ? 0.0 : (k == j + 1 ? 1.0 : svj[k] * scale);     // own columns only
         __syncthreads();
-        for (int k = j + tid; k < n; k += TC_THREADS) svj[k] = (k <= j || tj == 0.0) ? 0.0 : (k == j + 1 ? 1.0 : svj[k] * scale);
-        __syncthreads();
+        { double* t = sw; sw = sw_next; sw_next = t; }          // sw = w_{j-1} (the y buffer of this column is the w buffer of the next)
         if (g == 0) {
             double* vt = m.VT + (int64_t)j * m.ldv;
             for (int k = tid; k < n; k += TC_THREADS) vt[k] = k > j ? svj[k] : 0.0;
             if (tid == 0) { m.d[j] = dj; if (j + 1 < n) m.e[j] = beta; m.tau[j] = tj; }
         }
         tau_p = tj;
-        // ---- own rows (in LDS): update with reflector j-1, multiply by v_j; the owner of row j+1 publishes it while it is in hand
+        if (prof) { const long long c = wall_clock64(); pt[1] += c - pc; pc = c; }
+        // ---- own rows (in LDS): update with reflector j-1, multiply by v_j; the owner of row j+1 publishes it while it is in hand.
+        //      The rows still alive (t >= tmin) are dealt over the waves afresh every column -- wave w takes rows tmin + w and
+        //      tmin + w + 8 -- so that retired rows do not leave waves idle; the two rows of a wave share the reads of w, v_{j-1}, v_j.
         u64* rbn = m.rowbuf + (size_t)((j + 1) & 1) * 2 * n;
         u64* ybn = m.ybuf + (size_t)(j & 1) * 2 * n;
-        for (int t = wave; t < cnt; t += TC_WAVES) {
-            const int i = g + G * t;
-            if (i <= j) continue;
-            double* row = rows + (size_t)t * n;
-            const double vpi = svp[i], wi = sw[i];
-            const bool pub = i == j + 1;
-            double acc = 0.0;
-            for (int k = j + 1 + lane; k < n; k += 64) {
-                const double x = row[k] - (vpi * sw[k] + wi * svp[k]);
-                row[k] = x;
-                acc += x * svj[k];
-                if (pub) put_f64(rbn + 2 * (size_t)k, (unsigned)(j + 2), x);
+        const int tmin = j >= g ? (j - g) / G + 1 : 0;                 // first row of this workgroup below the pivot (row j+1, if it is ours, is this one)
+        for (int t0 = tmin + wave; t0 < cnt; t0 += 2 * TC_WAVES) {
+            const int t1 = t0 + TC_WAVES;
+            const int i0 = g + G * t0, i1 = g + G * t1;
+            const bool a1 = t1 < cnt;
+            double* row0 = rows + (size_t)t0 * n;
+            double* row1 = rows + (size_t)(a1 ? t1 : t0) * n;
+            const double vp0 = svp[i0], w0 = sw[i0], vp1 = a1 ? svp[i1] : 0.0, w1 = a1 ? sw[i1] : 0.0;
+            const bool pub0 = i0 == j + 1;
+            double acc0 = 0.0, acc1 = 0.0;
+            for (int kc = j + 1 + lane; kc < n + lane; kc += 64 * TC_MB) {
+                double wk[TC_MB], vpk[TC_MB], vjk[TC_MB], x0[TC_MB], x1[TC_MB];
+#pragma unroll
+                for (int c = 0; c < TC_MB; ++c) {
+                    const int k = min(kc + 64 * c, n - 1);
+                    wk[c] = sw[k]; vpk[c] = svp[k]; vjk[c] = svj[k]; x0[c] = row0[k]; x1[c] = row1[k];
+                }
+#pragma unroll
+                for (int c = 0; c < TC_MB; ++c) {
+                    const int k = kc + 64 * c;
+                    if (k < n) {
+                        const double y0 = x0[c] - (vp0 * wk[c] + w0 * vpk[c]), y1 = x1[c] - (vp1 * wk[c] + w1 * vpk[c]);
+                        row0[k] = y0; acc0 += y0 * vjk[c];
+                        if (pub0) put_f64(rbn + 2 * (size_t)k, (unsigned)(j + 2), y0);
+                        if (a1) { row1[k] = y1; acc1 += y1 * vjk[c]; }
+                    }
+                }
             }
-            acc = wave_sum(acc);
-            if (lane == 0) put_f64(ybn + 2 * (size_t)i, (unsigned)(j + 1), acc);
+            acc0 = wave_sum_fast(acc0); acc1 = wave_sum_fast(acc1);
+            if (lane == 0) { put_f64(ybn + 2 * (size_t)i0, (unsigned)(j + 1), acc0); if (a1) put_f64(ybn + 2 * (size_t)i1, (unsigned)(j + 1), acc1); }
         }
+        if (prof) { const long long c = wall_clock64(); pt[2] += c - pc; pc = c; }
         __syncthreads();
+        if (prof) { const long long c = wall_clock64(); pt[3] += c - pc; pc = c; }
     }
+    if (prof) for (int q = 0; q < 4; ++q) args.prof[q] = pt[q];
 }
 
 // dst (n x n, ld) = src^T for every matrix (V from V^T)
@@ -440,7 +509,7 @@ __global__ void __launch_bounds__(256) dc_scale_kernel(const DcMat* __restrict__
 
 // Leaf: T[lo:hi] with the rank-one couplings to its neighbours taken off the end diagonals (T = diag(T1', T2') + |beta| u u^T,
 // u = e_last(1) + sign(beta) e_first(2)), diagonalised by cyclic Jacobi on the dense 32 x 32 array in LDS.
-__global__ void __launch_bounds__(256) dc_leaf_kernel(const DcMat* __restrict__ mats, const DcLeaf* __restrict__ leaves)
+__global__ void __launch_bounds__(DC_LEAF_THREADS) dc_leaf_kernel(const DcMat* __restrict__ mats, const DcLeaf* __restrict__ leaves)
 {
     constexpr int P = DC_LEAF, H = P / 2;
     __shared__ double S[P][P + 1], R[P][P + 1];
@@ -451,7 +520,7 @@ __global__ void __launch_bounds__(256) dc_leaf_kernel(const DcMat* __restrict__ 
     const DcMat m = mats[lf.mat];
     const int p = lf.hi - lf.lo, tid = threadIdx.x;
     const double inv = 1.0 / m.scale[0];
-    for (int e = tid; e < P * P; e += 256) { const int i = e / P, c = e % P; S[i][c] = 0.0; R[i][c] = i == c ? 1.0 : 0.0; }
+    for (int e = tid; e < P * P; e += DC_LEAF_THREADS) { const int i = e / P, c = e % P; S[i][c] = 0.0; R[i][c] = i == c ? 1.0 : 0.0; }
     __syncthreads();
     if (tid < p) {
         const int gi = lf.lo + tid;
@@ -464,9 +533,9 @@ __global__ void __launch_bounds__(256) dc_leaf_kernel(const DcMat* __restrict__ 
     __syncthreads();
     for (int sweep = 0; sweep < 20; ++sweep) {
         double off = 0.0, dg = 0.0;
-        for (int e = tid; e < P * P; e += 256) { const int i = e / P, c = e % P; const double v = S[i][c]; if (i == c) dg += v * v; else off += v * v; }
-        off = block_sum<4>(off, red, tid);
-        dg = block_sum<4>(dg, red, tid);
+        for (int e = tid; e < P * P; e += DC_LEAF_THREADS) { const int i = e / P, c = e % P; const double v = S[i][c]; if (i == c) dg += v * v; else off += v * v; }
+        off = block_sum<DC_LEAF_THREADS / 64>(off, red, tid);
+        dg = block_sum<DC_LEAF_THREADS / 64>(dg, red, tid);
         if (off <= 2e-31 * dg || off == 0.0) break;          // off-diagonal norm <= 2 eps |T|; uniform over the workgroup
         for (int r = 0; r < P - 1; ++r) {
             if (tid < H) {                                   // pair tid of round r (round-robin tournament of 32 indices)
@@ -483,7 +552,7 @@ __global__ void __launch_bounds__(256) dc_leaf_kernel(const DcMat* __restrict__ 
                 rc[tid] = c; rs[tid] = s;
             }
             __syncthreads();
-            for (int e = tid; e < H * P; e += 256) {         // columns: S <- S J, R <- R J
+            for (int e = tid; e < H * P; e += DC_LEAF_THREADS) {         // columns: S <- S J, R <- R J
                 const int t = e / P, i = e % P;
                 int a, bq;
                 if (t == 0) { a = P - 1; bq = r; } else { a = (r + t) % (P - 1); bq = (r - t + P - 1) % (P - 1); }
@@ -495,7 +564,7 @@ __global__ void __launch_bounds__(256) dc_leaf_kernel(const DcMat* __restrict__ 
                 R[i][a] = c * rp - s * rq; R[i][bq] = s * rp + c * rq;
             }
             __syncthreads();
-            for (int e = tid; e < H * P; e += 256) {         // rows: S <- J^T S
+            for (int e = tid; e < H * P; e += DC_LEAF_THREADS) {         // rows: S <- J^T S
                 const int t = e / P, i = e % P;
                 int a, bq;
                 if (t == 0) { a = P - 1; bq = r; } else { a = (r + t) % (P - 1); bq = (r - t + P - 1) % (P - 1); }
@@ -518,7 +587,7 @@ __global__ void __launch_bounds__(256) dc_leaf_kernel(const DcMat* __restrict__ 
     __syncthreads();
     double* Q = m.Q[lf.buf];
     const int ldq = m.ldq[lf.buf];
-    for (int e = tid; e < p * p; e += 256) { const int i = e / p, c = e % p; Q[(int64_t)(lf.lo + i) * ldq + lf.lo + rnk[c]] = R[i][c]; }
+    for (int e = tid; e < p * p; e += DC_LEAF_THREADS) { const int i = e / p, c = e % p; Q[(int64_t)(lf.lo + i) * ldq + lf.lo + rnk[c]] = R[i][c]; }
 }
 
 // Deflation of one merge (LAPACK dlaed2 in this solver's data flow): z from the children's boundary rows, poles ranked by brute-
@@ -561,34 +630,94 @@ __global__ void __launch_bounds__(1024) dc_deflate_kernel(const DcMat* __restric
     __syncthreads();
     for (int s = tid; s < nl; s += 1024) { const int c = ord[s]; ds[s] = D[c]; zs[s] = z[c]; }
     __syncthreads();
-    if (tid != 0) return;
     const double tol = 8.0 * DC_EPS * fmax(dmax, zmax);
-    int k = 0, nd = 0, nrot = 0;
-    auto pole = [&](int s) { const int c = ord[s]; m.dl[lo + k] = ds[s]; m.zl[lo + k] = zs[s]; m.pcol[lo + k] = c; m.rowpole[lo + c] = k; ++k; };
-    auto defl = [&](int s) { m.dval[lo + nd] = ds[s]; m.dcol[lo + nd] = ord[s]; ++nd; };
-    if (rho * zmax <= tol) {
-        for (int s = 0; s < nl; ++s) defl(s);
-    } else {
-        int pj = -1;
-        for (int jj = 0; jj < nl; ++jj) {
-            if (rho * fabs(zs[jj]) <= tol) { defl(jj); continue; }
-            if (pj < 0) { pj = jj; continue; }
-            double s_ = zs[pj], c_ = zs[jj];
-            const double tau = hypot(c_, s_), t = ds[jj] - ds[pj];
-            c_ /= tau; s_ = -s_ / tau;
-            if (fabs(t * c_ * s_) <= tol) {
-                zs[jj] = tau; zs[pj] = 0.0;
-                m.rcp[lo + nrot] = ord[pj]; m.rcj[lo + nrot] = ord[jj]; m.rc[lo + nrot] = c_; m.rs[lo + nrot] = s_; ++nrot;
-                const double tt = ds[pj] * c_ * c_ + ds[jj] * s_ * s_;
-                ds[jj] = ds[pj] * s_ * s_ + ds[jj] * c_ * c_;
-                ds[pj] = tt;
-                defl(pj);
-                pj = jj;
-            } else { pole(pj); pj = jj; }
+    // ---- fast path: no pair of neighbouring poles needs a type-2 rotation (the usual case without exact degeneracies), so the
+    //      deflation scan has no sequential dependence: type-1 flags, a prefix count, and every pole / deflated entry written by
+    //      its own thread.  One neighbour pair that would rotate sends the whole merge through the sequential scan below.
+    int* pre = ord + nlmax;                               // exclusive count of non-deflated entries in front of sorted position s
+    int* nf = pre + nlmax;                                // sorted positions of the non-deflated entries, in order
+    __shared__ int wtot[16], s_any2, s_k;
+    const bool all_defl = rho * zmax <= tol;
+    {
+        const int per = (nl + 1023) / 1024, s0 = tid * per;
+        int c = 0;
+        for (int u = 0; u < per; ++u) { const int sp = s0 + u; if (sp < nl && !(all_defl || rho * fabs(zs[sp]) <= tol)) ++c; }
+        int inc = c;
+        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o, 64); if ((tid & 63) >= o) inc += v; }
+        if ((tid & 63) == 63) wtot[tid >> 6] = inc;
+        if (tid == 0) s_any2 = 0;
+        __syncthreads();
+        int base = 0;
+        for (int w = 0; w < (tid >> 6); ++w) base += wtot[w];
+        int run = base + inc - c;
+        for (int u = 0; u < per; ++u) {
+            const int sp = s0 + u;
+            if (sp >= nl) break;
+            pre[sp] = run;
+            if (!(all_defl || rho * fabs(zs[sp]) <= tol)) { nf[run] = sp; ++run; }
         }
-        pole(pj);
+        if (tid == 1023) s_k = run;
+        __syncthreads();
     }
-    m.mk[lo] = k; m.mrot[lo] = nrot; m.mrho[lo] = rho;
+    const int kfast = s_k;
+    for (int p = 1 + tid; p < kfast; p += 1024) {         // would the scan rotate the pair (nf[p-1], nf[p])?
+        const int a = nf[p - 1], b = nf[p];
+        double s_ = zs[a], c_ = zs[b];
+        const double tau = hypot(c_, s_), t = ds[b] - ds[a];
+        c_ /= tau; s_ = -s_ / tau;
+        if (fabs(t * c_ * s_) <= tol) s_any2 = 1;
+    }
+    __syncthreads();
+    if (!s_any2) {
+        for (int sp = tid; sp < nl; sp += 1024) {
+            const bool d1 = all_defl || rho * fabs(zs[sp]) <= tol;
+            const int c = ord[sp];
+            if (d1) { const int t = sp - pre[sp]; m.dval[lo + t] = ds[sp]; m.dcol[lo + t] = c; }
+            else { const int kk = pre[sp]; m.dl[lo + kk] = ds[sp]; m.zl[lo + kk] = zs[sp]; m.pcol[lo + kk] = c; m.rowpole[lo + c] = kk; }
+        }
+        if (tid == 0) { m.mk[lo] = kfast; m.mrot[lo] = 0; m.mrho[lo] = rho; }
+        return;
+    }
+    // ---- sequential scan (thread 0), everything it touches in LDS and the pole it carries in registers: the test
+    //      |t c s| <= tol with c = z_jj / tau, s = z_pj / tau is done as |t z_jj z_pj| <= tol tau^2 (no square root, no division
+    //      unless the pair really rotates); the lists go to memory in parallel afterwards.
+    int* polepos = pre;                                  // (the fast path's arrays are free again)
+    int* deflpos = nf;
+    int* rcp_s = nf + nlmax;
+    int* rcj_s = rcp_s + nlmax;
+    double* rc_s = D;                                     // D and z were consumed when ds / zs were built
+    double* rs_s = z;
+    __shared__ int s_nd, s_nrot;
+    if (tid == 0) {
+        int k = 0, nd = 0, nrot = 0, pj = -1;
+        double zpj = 0.0, dpj = 0.0;
+        double zn = zs[0], dn = ds[0];
+        for (int jj = 0; jj < nl; ++jj) {
+            const double zj = zn, dj = dn;
+            if (jj + 1 < nl) { zn = zs[jj + 1]; dn = ds[jj + 1]; }          // (requested one element ahead of its use)
+            if (rho * fabs(zj) <= tol) { deflpos[nd++] = jj; continue; }
+            if (pj < 0) { pj = jj; zpj = zj; dpj = dj; continue; }
+            const double tau2 = zj * zj + zpj * zpj, t = dj - dpj;
+            if (fabs(t * zj * zpj) <= tol * tau2) {
+                const double tau = sqrt(tau2), c_ = zj / tau, s_ = -zpj / tau;
+                rcp_s[nrot] = ord[pj]; rcj_s[nrot] = ord[jj]; rc_s[nrot] = c_; rs_s[nrot] = s_; ++nrot;
+                const double tt = dpj * c_ * c_ + dj * s_ * s_;
+                const double dnew = dpj * s_ * s_ + dj * c_ * c_;
+                ds[pj] = tt; zs[pj] = 0.0;
+                deflpos[nd++] = pj;
+                pj = jj; zpj = tau; dpj = dnew;
+                ds[jj] = dnew; zs[jj] = tau;
+            } else { polepos[k++] = pj; pj = jj; zpj = zj; dpj = dj; }
+        }
+        polepos[k++] = pj;
+        s_k = k; s_nd = nd; s_nrot = nrot;
+    }
+    __syncthreads();
+    const int k = s_k, nd = s_nd, nrot = s_nrot;
+    for (int p = tid; p < k; p += 1024) { const int sp = polepos[p], c = ord[sp]; m.dl[lo + p] = ds[sp]; m.zl[lo + p] = zs[sp]; m.pcol[lo + p] = c; m.rowpole[lo + c] = p; }
+    for (int t = tid; t < nd; t += 1024) { const int sp = deflpos[t]; m.dval[lo + t] = ds[sp]; m.dcol[lo + t] = ord[sp]; }
+    for (int t = tid; t < nrot; t += 1024) { m.rcp[lo + t] = rcp_s[t]; m.rcj[lo + t] = rcj_s[t]; m.rc[lo + t] = rc_s[t]; m.rs[lo + t] = rs_s[t]; }
+    if (tid == 0) { m.mk[lo] = k; m.mrot[lo] = nrot; m.mrho[lo] = rho; }
 }
 
 // Root j of  1 + rho sum_i z_i^2 / (d_i - lambda)  between d_j and d_{j+1} (the last one: right of d_{k-1}), one wave per root.
@@ -676,46 +805,80 @@ __global__ void __launch_bounds__(256) dc_secular_kernel(const DcMat* __restrict
 }
 
 // Loewner weights (Gu / Eisenstat: the z for which the computed roots are the exact eigenvalues -- this is what makes the
-// eigenvector columns orthogonal to round-off), column norms, and the final order of the node's eigenvalues.
-__global__ void __launch_bounds__(1024) dc_weights_kernel(const DcMat* __restrict__ mats, const DcMerge* __restrict__ merges, int nlmax)
+// eigenvector columns orthogonal to round-off).  k^2 work per merge: DC_SPLIT workgroups per merge, 16 lanes per pole.
+constexpr int DC_SPLIT = 8;
+__device__ __forceinline__ double prod16(double v)          // product over the 16 lanes of a row, in every lane
+{
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v *= __shfl_xor(v, o, 16);
+    return v;
+}
+__device__ __forceinline__ double sum16(double v)
+{
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 16);
+    return v;
+}
+__global__ void __launch_bounds__(1024) dc_zhat_kernel(const DcMat* __restrict__ mats, const DcMerge* __restrict__ merges, int nlmax)
 {
     extern __shared__ double sh[];
     double* dl = sh;
     double* od = sh + nlmax;                  // d_origin(j)
     double* tau = sh + 2 * (size_t)nlmax;
-    double* zh = sh + 3 * (size_t)nlmax;
-    double* val = sh;                         // reuses dl | od once the weights are done
-    const DcMerge mg = merges[blockIdx.x];
+    const DcMerge mg = merges[blockIdx.y];
     const DcMat m = mats[mg.mat];
-    const int lo = mg.lo, nl = mg.hi - mg.lo, k = m.mk[lo], tid = threadIdx.x;
+    const int lo = mg.lo, k = m.mk[lo], tid = threadIdx.x;
+    if ((int)blockIdx.x * 64 >= k) return;
     for (int j = tid; j < k; j += 1024) { dl[j] = m.dl[lo + j]; tau[j] = m.tau[lo + j]; }
     __syncthreads();
     for (int j = tid; j < k; j += 1024) od[j] = dl[m.org[lo + j]];
     __syncthreads();
-    for (int i = tid; i < k; i += 1024) {
+    const int ps = tid >> 4, q = tid & 15;
+    for (int i0 = blockIdx.x * 64; i0 < k; i0 += DC_SPLIT * 64) {     // (uniform trip count: the shuffles below need all 16 lanes of a pole)
+        const int i = min(i0 + ps, k - 1);
         const double di = dl[i];
-        double w = (di - od[i]) - tau[i];
-        for (int j = 0; j < k; ++j) if (j != i) w *= ((di - od[j]) - tau[j]) / (di - dl[j]);
-        const double zv = copysign(sqrt(fabs(w)), m.zl[lo + i]);
-        zh[i] = zv; m.zhat[lo + i] = zv;
+        double w = q == 0 ? (di - od[i]) - tau[i] : 1.0;
+        for (int j = q; j < k; j += 16) if (j != i) w *= ((di - od[j]) - tau[j]) / (di - dl[j]);
+        w = prod16(w);
+        if (q == 0 && i0 + ps < k) m.zhat[lo + i] = copysign(sqrt(fabs(w)), m.zl[lo + i]);
     }
-    __syncthreads();
-    for (int j = tid; j < k; j += 1024) {
-        const double oj = od[j], tj = tau[j];
-        double s = 0.0;
-        for (int i = 0; i < k; ++i) { const double t = zh[i] / ((dl[i] - oj) - tj); s += t * t; }
-        m.cnorm[lo + j] = 1.0 / sqrt(s);
-    }
-    __syncthreads();
+}
+
+// column norms of the merge's eigenvector block, and the final order of the node's eigenvalues
+__global__ void __launch_bounds__(1024) dc_norm_rank_kernel(const DcMat* __restrict__ mats, const DcMerge* __restrict__ merges, int nlmax)
+{
+    extern __shared__ double sh[];
+    double* dl = sh;
+    double* zh = sh + nlmax;
+    double* val = sh + 2 * (size_t)nlmax;
+    const DcMerge mg = merges[blockIdx.y];
+    const DcMat m = mats[mg.mat];
+    const int lo = mg.lo, nl = mg.hi - mg.lo, k = m.mk[lo], tid = threadIdx.x;
+    if ((int)blockIdx.x * 64 >= nl) return;
+    for (int j = tid; j < k; j += 1024) { dl[j] = m.dl[lo + j]; zh[j] = m.zhat[lo + j]; }
     for (int x = tid; x < nl; x += 1024) val[x] = x < k ? m.lam[lo + x] : m.dval[lo + x - k];
     __syncthreads();
-    for (int x = tid; x < nl; x += 1024) {
+    const int ps = tid >> 4, q = tid & 15;
+    for (int j0 = blockIdx.x * 64; j0 < k; j0 += DC_SPLIT * 64) {
+        const int j = min(j0 + ps, k - 1);
+        const double oj = dl[m.org[lo + j]], tj = m.tau[lo + j];
+        double s = 0.0;
+        for (int i = q; i < k; i += 16) { const double t = zh[i] / ((dl[i] - oj) - tj); s += t * t; }
+        s = sum16(s);
+        if (q == 0 && j0 + ps < k) m.cnorm[lo + j] = 1.0 / sqrt(s);
+    }
+    for (int x0 = blockIdx.x * 64; x0 < nl; x0 += DC_SPLIT * 64) {
+        const int x = min(x0 + ps, nl - 1);
         const double v = val[x];
         int r = 0;
-        for (int q = 0; q < nl; ++q) { const double u = val[q]; r += (u < v) || (u == v && q < x); }
-        m.dcur[lo + r] = v;
-        m.colroot[lo + r] = x < k ? x : -(x - k) - 1;
-        if (x >= k) m.pcolmap[lo + m.dcol[lo + x - k]] = r;
+        for (int p = q; p < nl; p += 16) { const double u = val[p]; r += (u < v) || (u == v && p < x); }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) r += __shfl_xor(r, o, 16);
+        if (q == 0 && x0 + ps < nl) {
+            m.dcur[lo + r] = v;
+            m.colroot[lo + r] = x < k ? x : -(x - k) - 1;
+            if (x >= k) m.pcolmap[lo + m.dcol[lo + x - k]] = r;
+        }
     }
 }
 
@@ -825,6 +988,8 @@ template <class K> dmrgx_status set_dyn_lds(K kernel, size_t bytes)
 
 }  // namespace
 
+void symeig_set_persistent(bool on) { g_coop_disabled = !on; }
+
 dmrgx_status symeig_batched(const std::vector<SymEigMat>& mats_in, hipStream_t st)
 {
     std::vector<SymEigMat> M;
@@ -893,9 +1058,10 @@ dmrgx_status symeig_batched(const std::vector<SymEigMat>& mats_in, hipStream_t s
     int32_t coop_status = 0;
     bool coop_ran = false;
     if (coop_wanted && !g_coop_disabled) {
-        int dev = 0, ncu = 0, max_lds = 0;
+        int dev = 0, ncu = 0;
         DMRGX_HIP(hipGetDevice(&dev));
         DMRGX_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+        int max_lds = 0;
         DMRGX_HIP(hipDeviceGetAttribute(&max_lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev));
         const int64_t dyn_max = std::min<int64_t>(max_lds, 160 * 1024) - 256;       // (static LDS of the kernel: a few words)
         std::vector<int> order(nm);
@@ -904,7 +1070,7 @@ dmrgx_status symeig_batched(const std::vector<SymEigMat>& mats_in, hipStream_t s
         struct Round { std::vector<int> mats, G; int wgs = 0; };
         std::vector<Round> rounds;
         for (int q : order) {
-            const int64_t n = M[q].n, cap = (dyn_max / 8 - 3 * n) / n;               // rows of this matrix one workgroup can hold
+            const int64_t n = M[q].n, cap = (dyn_max / 8 - TC_VECS * n) / n;         // rows of this matrix one workgroup can hold
             const int G = cap >= 1 ? (int)((n + cap - 1) / cap) : ncu + 1;
             if (G > ncu) { launch_set.push_back(q); continue; }
             Round* r = nullptr;
@@ -925,14 +1091,15 @@ dmrgx_status symeig_batched(const std::vector<SymEigMat>& mats_in, hipStream_t s
             for (const Round& r : rounds) {
                 TcArgs ta;
                 ta.status = reinterpret_cast<int32_t*>(GB); ta.nm = (int32_t)r.mats.size(); ta.pad = 0;
+                ta.prof = getenv("DMRGX_TRID_PROF") ? reinterpret_cast<long long*>(B + ws[r.mats[0]].y) : nullptr;      // (the y scratch of the launch path is idle here)
                 size_t lds = 0;
                 int wg0 = 0;
                 for (int i = 0; i < TRID_MAXM; ++i) {
                     if (i < (int)r.mats.size()) {
-                        const int q = r.mats[(size_t)i], n = M[q].n, G = r.G[(size_t)i], rows = (n + G - 1) / G;
+                        const int q = r.mats[(size_t)i], n = M[q].n, G = r.G[(size_t)i];
                         ta.m[i] = TcMat{M[q].A, B + ws[q].VT, B + ws[q].d, B + ws[q].e, B + ws[q].tau, GB + goff[q], GB + goff[q] + 4 * (int64_t)n, n, M[q].lda, n, G, wg0, 0};
                         wg0 += G;
-                        lds = std::max(lds, (size_t)(3 + rows) * n * sizeof(double));
+                        lds = std::max(lds, (size_t)(TC_VECS + (n + G - 1) / G) * n * sizeof(double));
                     } else ta.m[i] = TcMat{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 1 << 30, 0};
                 }
                 hipLaunchKernelGGL(trid_coop_kernel, dim3((unsigned)wg0), dim3(TC_THREADS), lds, st, ta);
@@ -1065,6 +1232,11 @@ dmrgx_status symeig_batched(const std::vector<SymEigMat>& mats_in, hipStream_t s
     DMRGX_CHK(upload(d_tp, tp, st)); DMRGX_CHK(upload(d_wyb, wyb, st)); DMRGX_CHK(upload(d_dm, dm, st));
     DMRGX_CHK(upload(d_leaves, leaves, st)); DMRGX_CHK(upload(d_merges, merges, st));
     // ---- the persistent rounds have had the host's table building and the table uploads to run in: did every workgroup get its partners? ---------------
+    if (coop_ran && getenv("DMRGX_TRID_PROF")) {
+        long long pr[4];
+        DMRGX_HIP(hipMemcpy(pr, B + ws[coop_set[0]].y, sizeof(pr), hipMemcpyDeviceToHost));
+        fprintf(stderr, "[trid-prof] n=%d: wave 0 of workgroup 1, 100 MHz ticks -> us: consume %.1f  vector work %.1f  own rows %.1f  end barrier %.1f\n", M[coop_set[0]].n, pr[0] / 100.0, pr[1] / 100.0, pr[2] / 100.0, pr[3] / 100.0);
+    }
     if (coop_ran) {
         DMRGX_HIP(hipMemcpyAsync(&coop_status, gran.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));      // (a pageable copy: it may block, so it is issued here)
         DMRGX_HIP(hipStreamSynchronize(st));
@@ -1144,21 +1316,22 @@ dmrgx_status symeig_batched(const std::vector<SymEigMat>& mats_in, hipStream_t s
     // ---- 2: launches -------------------------------------------------------------------------------------------------------------
     const DcMat* ddm = d_dm.as<DcMat>();
     hipLaunchKernelGGL(dc_scale_kernel, dim3((unsigned)nm), dim3(256), 0, st, ddm);
-    hipLaunchKernelGGL(dc_leaf_kernel, dim3((unsigned)leaves.size()), dim3(256), 0, st, ddm, d_leaves.as<DcLeaf>());
+    hipLaunchKernelGGL(dc_leaf_kernel, dim3((unsigned)leaves.size()), dim3(DC_LEAF_THREADS), 0, st, ddm, d_leaves.as<DcLeaf>());
     DMRGX_HIP(hipGetLastError());
     for (const Step& s : steps) {
         if (s.nmerge == 0) continue;
         const DcMerge* mp = d_merges.as<DcMerge>() + s.merge_off;
         const int nl = s.nlmax;
-        const size_t lds_defl = (size_t)nl * (4 * sizeof(double) + sizeof(int)) + 16;
+        const size_t lds_defl = (size_t)nl * (4 * sizeof(double) + 5 * sizeof(int)) + 16;
         const size_t lds_sec = (size_t)nl * 2 * sizeof(double);
-        const size_t lds_wgt = (size_t)nl * 4 * sizeof(double);
+        const size_t lds_wgt = (size_t)nl * 3 * sizeof(double);
         const size_t lds_rot = (size_t)nl * (2 * sizeof(double) + 3 * sizeof(int)) + 16;
         DMRGX_CHK(set_dyn_lds(dc_deflate_kernel, lds_defl)); DMRGX_CHK(set_dyn_lds(dc_secular_kernel, lds_sec));
-        DMRGX_CHK(set_dyn_lds(dc_weights_kernel, lds_wgt)); DMRGX_CHK(set_dyn_lds(dc_rot_kernel, lds_rot));
+        DMRGX_CHK(set_dyn_lds(dc_zhat_kernel, lds_wgt)); DMRGX_CHK(set_dyn_lds(dc_norm_rank_kernel, lds_wgt)); DMRGX_CHK(set_dyn_lds(dc_rot_kernel, lds_rot));
         hipLaunchKernelGGL(dc_deflate_kernel, dim3((unsigned)s.nmerge), dim3(1024), lds_defl, st, ddm, mp, nl);
         hipLaunchKernelGGL(dc_secular_kernel, dim3((unsigned)((nl + 3) / 4), (unsigned)s.nmerge), dim3(256), lds_sec, st, ddm, mp, nl);
-        hipLaunchKernelGGL(dc_weights_kernel, dim3((unsigned)s.nmerge), dim3(1024), lds_wgt, st, ddm, mp, nl);
+        hipLaunchKernelGGL(dc_zhat_kernel, dim3(DC_SPLIT, (unsigned)s.nmerge), dim3(1024), lds_wgt, st, ddm, mp, nl);
+        hipLaunchKernelGGL(dc_norm_rank_kernel, dim3(DC_SPLIT, (unsigned)s.nmerge), dim3(1024), lds_wgt, st, ddm, mp, nl);
         hipLaunchKernelGGL(dc_fill_u_kernel, dim3((unsigned)((nl + 63) / 64), (unsigned)((nl + 63) / 64), (unsigned)s.nmerge), dim3(256), 0, st, ddm, mp);
         hipLaunchKernelGGL(dc_rot_kernel, dim3((unsigned)((nl + 255) / 256), (unsigned)s.nmerge), dim3(256), lds_rot, st, ddm, mp, nl);
         DMRGX_HIP(hipGetLastError());

@@ -272,6 +272,12 @@ class Communicator:
     def barrier(self, stream=None):
         _capi.check(_capi.lib().dmrgx_comm_barrier(self.handle, self._st(stream)))
 
+    def info(self):
+        """(rank, world, backend) as the library's communicator reports them (backend 0 = RCCL, 1 = host-staged)."""
+        r, w, b = C.c_int32(), C.c_int32(), C.c_int32()
+        _capi.check(_capi.lib().dmrgx_comm_info(self.handle, C.byref(r), C.byref(w), C.byref(b)))
+        return r.value, w.value, b.value
+
     def destroy(self):
         if self.handle:
             _capi.check(_capi.lib().dmrgx_comm_destroy(self.handle))

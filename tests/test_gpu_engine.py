@@ -461,13 +461,14 @@ def test_rccl_hooks_single_rank():
 
 
 def test_bench_multi_rank_control_flow_rehearsal():
-    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one process per rank), rehearsed with two ranks
-    on the one GPU and the host-staged back-end of the native communicator: striped plans, the solver's own collectives, barrier +
-    max-over-ranks timing, one JSON line from rank 0 with whole-job throughput."""
+    """`python bench.py --gpus 2` as a PLAIN command (the driver's form: bench.py starts its own rank processes), rehearsed with two
+    ranks on the one GPU and the host-staged back-end of the native communicator: striped plans, the solver's own collectives,
+    barrier + max-over-ranks timing, one JSON line from rank 0 with whole-job throughput, n_gpus read back from the library's
+    communicator, and the engine legs on two ranks (configs[3]'s and configs[2]'s control flow on small lattices)."""
     import sys
-    env = dict(os.environ, DMRGX_BENCH_REHEARSAL="1", PYTHONPATH=ROOT)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29651",
-           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "24", "--warmup", "8", "--workload", "cfg2"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(DMRGX_BENCH_REHEARSAL="1", PYTHONPATH=ROOT)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "24", "--warmup", "8", "--workload", "cfg2"]
     p = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert p.returncode == 0, p.stderr.decode()[-3000:]
     lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
@@ -475,5 +476,8 @@ def test_bench_multi_rank_control_flow_rehearsal():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 24 and d["warmup"] == 8 and d["scaling"] == "strong" and d["unit"] == "MatMults/s"
     assert d["value"] > 0 and abs(d["value"] * d["ms_per_step"] / 1e3 - 1.0) < 1e-9
-    assert d["cpu_baseline"] is None and "sweep" not in d and d["roofline"]["achieved"] > 0
-    assert "2 GPU" in d["config"]["parallelism"]
+    assert d["cpu_baseline"] is None and d["roofline"]["achieved"] > 0
+    assert "2 GPU" in d["config"]["parallelism"] and d["communicator"]["world"] == 2
+    sw = d["sweep"]
+    assert "error" not in sw and sw["ranks"] == 2 and sw["sites_per_s"] > 0, sw
+    assert "error" not in sw["configs_2"] and sw["configs_2"]["ranks"] == 2 and sw["configs_2"]["sites_per_s"] > 0, sw["configs_2"]
