@@ -35,20 +35,21 @@ void set_error(const char* fmt, ...);
     } while (0)
 
 // Stripe rule of the multi-GPU layout: rank w owns columns [stripe_cut(n,W,w), stripe_cut(n,W,w+1)) of a KronBlock.
-// Cuts sit on multiples of the GEMM tile width (64 columns) when every rank still gets at least one tile, else on multiples of
-// the MFMA block width (16), else on the even split: a stripe of 128.5 columns would otherwise cost every rank a third,
-// almost empty tile per KronBlock and operator (the ragged remainder of n stays with the last rank, as on one GPU).
+// Cuts sit at the even split rounded to a multiple of the MFMA block width (16 columns) -- every stripe is within 16 columns of
+// n / W, so no rank carries the whole remainder (a cut on whole 64-column GEMM tiles with the remainder on the last rank gave
+// 64,128,..,168 for n = 1000, W = 8: the slowest rank 34 % above the even share) -- and snap to a multiple of the GEMM tile
+// width (64) when that is no further from the even split than 16 columns, which keeps a rank from paying for an almost empty tile
+// column per operator where it costs no balance; below 48 W columns the plain even split is used.
 inline int32_t stripe_cut(int32_t n, int32_t W, int32_t w)
 {
     if (w <= 0) return 0;
     if (w >= W) return n;
     const int64_t even = ((int64_t)n * w) / W;
-    for (int32_t g : {64, 16}) {
-        if ((int64_t)n < (int64_t)g * W) continue;
-        const int64_t units = n / g;                       // whole g-column units, dealt evenly; the remainder goes to the last rank
-        return (int32_t)(((units * w) / W) * g);
-    }
-    return (int32_t)even;
+    if ((int64_t)n < (int64_t)48 * W) return (int32_t)even;      // (every cut moves by at most 16 columns: stripes of >= 48 keep >= 16)
+    const int64_t c16 = ((even + 8) / 16) * 16, c64 = ((even + 32) / 64) * 64;
+    const int64_t d64 = c64 > even ? c64 - even : even - c64;
+    const int64_t cut = (d64 <= 16 && c64 > 0 && c64 < n) ? c64 : c16;
+    return (int32_t)std::min<int64_t>(std::max<int64_t>(cut, 0), n);
 }
 
 // Pooled device memory and a fill kernel (pool.hip): pool_free never synchronises, recycling is stream-ordered.

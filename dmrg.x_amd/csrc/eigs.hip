@@ -330,9 +330,11 @@ extern "C" dmrgx_status dmrgx_eigs_lowest(dmrgx_kron_plan* plan, const dmrgx_eig
     // the diagonally preconditioned iteration pays off from a start vector close to the answer (the engine's transformed ground
     // state: 16-19 MatMults where Lanczos needs 21-27); from a random vector it is twice as slow as Lanczos (measured 140 vs 72),
     // so without a supplied start vector the request falls through to the Lanczos path
-    if (opts->method == 1 && opts->use_initial && opts->max_matvec <= 0) return eigs_davidson(plan, opts, e0, psi_full, stats, st);
     dmrgx_kron_info I;
     DMRGX_CHK(dmrgx_kron_plan_info(plan, &I));
+    // (a search space of fewer than two vectors -- a one-state superblock sector, ncv = 1 -- has nothing to precondition: Lanczos path)
+    const bool gd_space = std::min<int64_t>(opts->ncv > 0 ? opts->ncv : 16, I.n_states) >= 2;
+    if (opts->method == 1 && opts->use_initial && opts->max_matvec <= 0 && gd_space) return eigs_davidson(plan, opts, e0, psi_full, stats, st);
     const bool dist = I.vec_len != I.n_states;
     const bool hooks = opts->allgather && opts->allreduce_sum;
     if (dist && !hooks && !opts->comm) DMRGX_FAIL(DMRGX_ERR_ARG, "eigs_lowest: a striped plan needs a communicator (opts->comm) or the allgather/allreduce hooks");
@@ -661,8 +663,9 @@ static dmrgx_status eigs_davidson(dmrgx_kron_plan* plan, const dmrgx_eigs_opts* 
     int mp = 0;
     // the residual norm comes back through pinned memory behind an event, so that the orthogonalisation of the next direction is
     // already queued when the host waits for it
-    static double* h_r2 = nullptr;
-    static hipEvent_t ev_r2 = nullptr;
+    // pinned scalar + event for the residual look: one pair per host thread (callers on different threads / devices do not share it)
+    static thread_local double* h_r2 = nullptr;
+    static thread_local hipEvent_t ev_r2 = nullptr;
     if (!h_r2) { DMRGX_HIP(hipHostMalloc((void**)&h_r2, 64, hipHostMallocDefault)); DMRGX_HIP(hipEventCreateWithFlags(&ev_r2, hipEventDisableTiming)); }
     bool ritz_is_v0 = false;                    // a restart has just made the Ritz vector the first basis vector
     while (true) {
@@ -713,7 +716,7 @@ static dmrgx_status eigs_davidson(dmrgx_kron_plan* plan, const dmrgx_eigs_opts* 
             if (mm == m) {
                 // thick restart: the kk lowest Ritz vectors span the new basis (V <- V Y, W <- W Y, G <- diag(theta))
                 static const int kk_env = getenv("DMRGX_GD_KEEP") ? atoi(getenv("DMRGX_GD_KEEP")) : 0;
-                const int kk = std::max(1, std::min(kk_env > 0 ? kk_env : m / 2, m - 1));      // as many as the Lanczos path keeps: a slowly converging solve loses too much with fewer
+                const int kk = std::max(1, std::min({kk_env > 0 ? kk_env : m / 2, m - 1, m / 2 + 2}));      // (dTmp holds m / 2 + 2 vectors)      // as many as the Lanczos path keeps: a slowly converging solve loses too much with fewer
                 std::vector<double> Q((size_t)m * kk);
                 for (int i = 0; i < m; ++i) for (int b2 = 0; b2 < kk; ++b2) Q[(size_t)i * kk + b2] = Y[(size_t)i * m + b2];
                 DMRGX_HIP(h2d_async(dY.p, Q.data(), Q.size() * sizeof(double), st));

@@ -746,6 +746,7 @@ extern "C" dmrgx_status dmrgx_kron_plan_create(const dmrgx_kron_desc* d, void* s
                 // block (q -> q): the diagonal crosses the cell where r0 + i == c0 + j (transposed storage swaps the roles, same set)
                 const int32_t lo = std::max(c.r0, c.c0), hi = std::min(c.r0 + c.nr, c.c0 + c.nc);
                 if (lo >= hi) continue;
+                if (c.kind != DMRGX_CELL_DENSE && c.r0 != c.c0) continue;      // an identity cell maps row r0 + i to column c0 + i: on the diagonal only when r0 == c0
                 DiagSrc d;
                 d.n = hi - lo; d.scale = c.scale; d.ld = c.nc;
                 d.off = c.kind == DMRGX_CELL_DENSE ? c.off + (int64_t)(lo - c.r0) * c.nc + (lo - c.c0) : -1;

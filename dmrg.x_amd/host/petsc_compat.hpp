@@ -115,7 +115,11 @@ inline int CommBootstrap()
     const int rank = getenv("RANK") ? atoi(getenv("RANK")) : 0;
     const int local = getenv("LOCAL_RANK") ? atoi(getenv("LOCAL_RANK")) : rank;
     const std::string mode = getenv("DMRGX_COMM") ? getenv("DMRGX_COMM") : "rccl";
-    const std::string tag = std::to_string((long)getppid()) + "_" + (getenv("MASTER_PORT") ? getenv("MASTER_PORT") : "0");
+    /* per-launch tag of the rendezvous names: launcher pid + port + the launcher's run id / restart count where it exports one
+       (torch.distributed.run does), so that a restarted worker group never reads the id of the previous attempt */
+    const std::string tag = std::to_string((long)getppid()) + "_" + (getenv("MASTER_PORT") ? getenv("MASTER_PORT") : "0") +
+                            (getenv("TORCHELASTIC_RUN_ID") ? std::string("_") + getenv("TORCHELASTIC_RUN_ID") : std::string()) +
+                            (getenv("TORCHELASTIC_RESTART_COUNT") ? std::string("_") + getenv("TORCHELASTIC_RESTART_COUNT") : std::string());
     dmrgx_comm* comm = nullptr;
     if (mode == "shm") {
         if (dmrgx_set_device(0)) { fprintf(stderr, "[dmrgx] %s\n", dmrgx_last_error()); return 1; }
@@ -125,9 +129,13 @@ inline int CommBootstrap()
         if (dmrgx_set_device(local)) { fprintf(stderr, "[dmrgx] %s\n", dmrgx_last_error()); return 1; }
         const std::string path = getenv("DMRGX_RDZV_FILE") ? getenv("DMRGX_RDZV_FILE") : "/tmp/dmrgx_rdzv_" + tag;
         uint8_t id[DMRGX_COMM_ID_BYTES];
+        int ndev = 0;
+        if (dmrgx_device_count(&ndev) == 0 && world > ndev && !getenv("DMRGX_MULTI_NODE")) {
+            fprintf(stderr, "[dmrgx] WORLD_SIZE %d exceeds the %d GPU(s) of this node (the rendezvous file is node-local)\n", world, ndev); return 1; }
         if (rank == 0) {
             if (dmrgx_comm_unique_id(id)) { fprintf(stderr, "[dmrgx] %s\n", dmrgx_last_error()); return 1; }
             const std::string tmp = path + ".tmp";
+            unlink(path.c_str());                                  /* a file left behind by a run that died before its barrier */
             FILE* f = fopen(tmp.c_str(), "wb");
             if (!f || fwrite(id, 1, sizeof(id), f) != sizeof(id)) { fprintf(stderr, "[dmrgx] cannot write %s\n", tmp.c_str()); return 1; }
             fclose(f);

@@ -191,8 +191,16 @@ def column_cut_terms(Ly, J1, Jz1, J2, Jz2):
     return terms
 
 
-def synthetic_superblock(name="cfg2", m=None, Ly=None, seed=None, sigma=1.8, **couplings):
-    """Mid-chain, column-aligned superblock of BASELINE config `name` (or custom m/Ly/couplings)."""
+def scaled_real_profile(name, factor):
+    """The kept-sector tables of a real sweep step (REAL_PROFILES), every sector divided by `factor` (at least one state): the
+    L != R structure of the bench workload at a size the CPU oracle's row loop can check."""
+    p = REAL_PROFILES[name]
+    return ({q: max(1, int(round(n / factor))) for q, n in p["left"].items()}, {q: max(1, int(round(n / factor))) for q, n in p["right"].items()})
+
+
+def synthetic_superblock(name="cfg2", m=None, Ly=None, seed=None, sigma=1.8, kept=None, **couplings):
+    """Mid-chain, column-aligned superblock of BASELINE config `name` (or custom m/Ly/couplings).
+    kept = (left, right): explicit kept-sector tables {Sz: states} of the two blocks (overrides m / the real profile)."""
     cfg = dict(CONFIGS.get(name, CONFIGS["cfg2"]))
     if m is not None:
         cfg["m"] = m
@@ -202,7 +210,9 @@ def synthetic_superblock(name="cfg2", m=None, Ly=None, seed=None, sigma=1.8, **c
         cfg["seed"] = seed
     cfg.update(couplings)
     rng = np.random.default_rng(cfg["seed"])
-    if name in REAL_PROFILES and m is None:
+    if kept is not None:
+        kept_l, kept_r = kept
+    elif name in REAL_PROFILES and m is None:
         kept_l, kept_r = REAL_PROFILES[name]["left"], REAL_PROFILES[name]["right"]
     else:
         kept_l = kept_r = kept_profile(cfg["m"], sigma)

@@ -87,12 +87,20 @@ def test_stripe_bounds_partition(pkg):
                 cuts.append((a.value, b.value))
             assert cuts[0][0] == 0 and cuts[-1][1] == n
             assert all(cuts[i][1] == cuts[i + 1][0] for i in range(W - 1))
-            # cuts sit on whole GEMM tiles (64 columns) when every rank gets one, else on MFMA blocks (16), else the even split;
-            # the ragged remainder of n stays with the last rank
-            g = 64 if n >= 64 * W else 16 if n >= 16 * W else 1
+            # cuts sit at the even split rounded to MFMA blocks (16 columns; the plain even split below 48 W columns), snapped to a
+            # whole GEMM tile (64) where that costs no balance: every stripe is within 16 columns of its even share, the remainder of
+            # n is spread instead of piling on the last rank (n = 1000, W = 8 used to give 64,128,..,168)
+            g = 16 if n >= 48 * W else 1
             assert all(a % g == 0 for a, _ in cuts)
             widths = [b - a for a, b in cuts]
-            assert max(widths[:-1] + [widths[-1] - n % g]) - min(widths[:-1] + [widths[-1] - n % g]) <= g
+            assert all(abs(a - n * r // W) <= 16 for r, (a, _) in enumerate(cuts))
+            assert all(abs(wd - n / W) <= 33 for wd in widths) and (n < W or min(widths) > 0), (n, W, widths)
+    cuts = []
+    for r in range(8):
+        a, b = C.c_int32(), C.c_int32()
+        assert lib.dmrgx_stripe_bounds(1000, 8, r, C.byref(a), C.byref(b)) == 0
+        cuts.append(b.value - a.value)
+    assert max(cuts) <= 125 + 19 and min(cuts) >= 125 - 19, cuts
     a, b = C.c_int32(), C.c_int32()
     assert lib.dmrgx_stripe_bounds(10, 2, 2, C.byref(a), C.byref(b)) == pkg._capi.DMRGX_ERR_ARG
     # per KronBlock the stripes are dealt round the ranks: rank r owns stripe (r + block) mod W, every stripe exactly once

@@ -142,7 +142,10 @@ def test_engine_single_site_and_kronblocks_order():
 
 
 @pytest.mark.parametrize("opts", [dict(Lx=16, Ly=1, heisenberg=1.0), dict(Lx=4, Ly=2, heisenberg=1.0), dict(Lx=4, Ly=4, J1=1, Jz1=1, J2=0.5, Jz2=0.5),
-                                  dict(Lx=4, Ly=4), dict(Lx=6, Ly=3, J1=1, Jz1=0.3, J2=0.5, Jz2=0.2, BCperiodic=True), dict(Lx=5, Ly=4, J1=1, Jz1=1, J2=1, Jz2=1, BCopen=True)])
+                                  dict(Lx=4, Ly=4), dict(Lx=6, Ly=3, J1=1, Jz1=0.3, J2=0.5, Jz2=0.2, BCperiodic=True), dict(Lx=5, Ly=4, J1=1, Jz1=1, J2=1, Jz2=1, BCopen=True),
+                                  # the headline geometries of BASELINE configs[3], [2], [4]: width-8 and width-6 cylinders, and the XY point where
+                                  # the reference drops the J2 bonds together with Jz2 = 0 (src/Hamiltonians.cpp:101)
+                                  dict(Lx=20, Ly=8, J1=1, Jz1=1, J2=0.5, Jz2=0.5), dict(Lx=16, Ly=6, heisenberg=1.0), dict(Lx=32, Ly=8, J1=1, Jz1=0, J2=1, Jz2=0)])
 def test_engine_hamiltonian_terms_match_oracle(opts):
     """Hamiltonians::J1J2XXZModel_SquareLattice::H(n) of the engine == the oracle's restatement of
     src/Hamiltonians.cpp:70-122, term by term and in order, for full and partial lattices."""
