@@ -244,6 +244,7 @@ trid_step_kernel(const TridArgs args, int j)
 // workgroup that is not served in time (its partners are not resident -- e.g. another process holds CUs with a persistent kernel of
 // its own) sets the status word and leaves; the host then repeats the step with the launch-per-column kernel (A is only read here).
 typedef unsigned long long u64;
+typedef double dbl2 __attribute__((ext_vector_type(2)));
 typedef u64 __attribute__((address_space(1))) gu64;
 #define DMRGX_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 constexpr int TC_THREADS = 512, TC_WAVES = TC_THREADS / 64;
@@ -291,17 +292,18 @@ trid_coop_kernel(const TcArgs args)
     if (mi == args.nm) return;
     const TcMat& m = args.m[mi];
     const int n = m.n, G = m.G, g = b - m.wg0, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nv = (n + 1) & ~1;                        // even stride: the row pass moves two columns per lane (ds_read_b128 / ds_write_b128)
     double* sw = shc;
-    double* sw_next = shc + n;
-    double* svp = shc + 2 * (size_t)n;
-    double* svj = shc + 3 * (size_t)n;
-    double* rows = shc + TC_VECS * (size_t)n;           // row t of this workgroup = row g + G t of the matrix
+    double* sw_next = shc + nv;
+    double* svp = shc + 2 * (size_t)nv;
+    double* svj = shc + 3 * (size_t)nv;
+    double* rows = shc + TC_VECS * (size_t)nv;          // row t of this workgroup = row g + G t of the matrix
     const int cnt = g < n ? (n - g + G - 1) / G : 0;
     for (int t = 0; t < cnt; ++t) {
         const double* src = m.A + (int64_t)(g + G * t) * m.lda;
-        for (int k = tid; k < n; k += TC_THREADS) rows[(size_t)t * n + k] = src[k];
+        for (int k = tid; k < nv; k += TC_THREADS) rows[(size_t)t * nv + k] = k < n ? src[k] : 0.0;
     }
-    for (int k = tid; k < n; k += TC_THREADS) { svj[k] = 0.0; svp[k] = 0.0; sw[k] = 0.0; sw_next[k] = 0.0; }
+    for (int k = tid; k < nv; k += TC_THREADS) { svj[k] = 0.0; svp[k] = 0.0; sw[k] = 0.0; sw_next[k] = 0.0; }
     if (g == 0) for (int k = tid; k < n; k += TC_THREADS) put_f64(m.rowbuf + 2 * (size_t)k, 1u, m.A[k]);     // row 0, epoch 1
     if (tid == 0) sfail = 0;
     __syncthreads();
@@ -396,30 +398,33 @@ trid_coop_kernel(const TcArgs args)
         u64* rbn = m.rowbuf + (size_t)((j + 1) & 1) * 2 * n;
         u64* ybn = m.ybuf + (size_t)(j & 1) * 2 * n;
         const int tmin = j >= g ? (j - g) / G + 1 : 0;                 // first row of this workgroup below the pivot (row j+1, if it is ours, is this one)
+        const int ks = (j + 1) & ~1;                                   // first (even) column of the pass; column j, if included, is dead
         for (int t0 = tmin + wave; t0 < cnt; t0 += 2 * TC_WAVES) {
             const int t1 = t0 + TC_WAVES;
             const int i0 = g + G * t0, i1 = g + G * t1;
             const bool a1 = t1 < cnt;
-            double* row0 = rows + (size_t)t0 * n;
-            double* row1 = rows + (size_t)(a1 ? t1 : t0) * n;
+            double* row0 = rows + (size_t)t0 * nv;
+            double* row1 = rows + (size_t)(a1 ? t1 : t0) * nv;
             const double vp0 = svp[i0], w0 = sw[i0], vp1 = a1 ? svp[i1] : 0.0, w1 = a1 ? sw[i1] : 0.0;
             const bool pub0 = i0 == j + 1;
             double acc0 = 0.0, acc1 = 0.0;
-            for (int kc = j + 1 + lane; kc < n + lane; kc += 64 * TC_MB) {
-                double wk[TC_MB], vpk[TC_MB], vjk[TC_MB], x0[TC_MB], x1[TC_MB];
+            for (int kc = ks + 2 * lane; kc - 2 * lane < n; kc += 128 * TC_MB) {       // (wave-uniform trip count)
+                dbl2 wk[TC_MB], vpk[TC_MB], vjk[TC_MB], x0[TC_MB], x1[TC_MB];
 #pragma unroll
                 for (int c = 0; c < TC_MB; ++c) {
-                    const int k = min(kc + 64 * c, n - 1);
-                    wk[c] = sw[k]; vpk[c] = svp[k]; vjk[c] = svj[k]; x0[c] = row0[k]; x1[c] = row1[k];
+                    const int k = min(kc + 128 * c, nv - 2);
+                    wk[c] = *(const dbl2*)(sw + k); vpk[c] = *(const dbl2*)(svp + k); vjk[c] = *(const dbl2*)(svj + k);
+                    x0[c] = *(const dbl2*)(row0 + k); x1[c] = *(const dbl2*)(row1 + k);
                 }
 #pragma unroll
                 for (int c = 0; c < TC_MB; ++c) {
-                    const int k = kc + 64 * c;
-                    if (k < n) {
-                        const double y0 = x0[c] - (vp0 * wk[c] + w0 * vpk[c]), y1 = x1[c] - (vp1 * wk[c] + w1 * vpk[c]);
-                        row0[k] = y0; acc0 += y0 * vjk[c];
-                        if (pub0) put_f64(rbn + 2 * (size_t)k, (unsigned)(j + 2), y0);
-                        if (a1) { row1[k] = y1; acc1 += y1 * vjk[c]; }
+                    const int k = kc + 128 * c;
+                    if (k < n) {                       // (the pad column of an odd n holds zeros in every vector and row: it stays zero)
+                        const dbl2 y0 = x0[c] - (vp0 * wk[c] + w0 * vpk[c]), y1 = x1[c] - (vp1 * wk[c] + w1 * vpk[c]);
+                        *(dbl2*)(row0 + k) = y0;
+                        acc0 += y0.x * vjk[c].x + y0.y * vjk[c].y;          // (v_j is zero in column j)
+                        if (pub0) { if (k > j) put_f64(rbn + 2 * (size_t)k, (unsigned)(j + 2), y0.x); if (k + 1 < n) put_f64(rbn + 2 * (size_t)(k + 1), (unsigned)(j + 2), y0.y); }
+                        if (a1) { *(dbl2*)(row1 + k) = y1; acc1 += y1.x * vjk[c].x + y1.y * vjk[c].y; }
                     }
                 }
             }
@@ -1070,7 +1075,7 @@ dmrgx_status symeig_batched(const std::vector<SymEigMat>& mats_in, hipStream_t s
         struct Round { std::vector<int> mats, G; int wgs = 0; };
         std::vector<Round> rounds;
         for (int q : order) {
-            const int64_t n = M[q].n, cap = (dyn_max / 8 - TC_VECS * n) / n;         // rows of this matrix one workgroup can hold
+            const int64_t n = M[q].n, nv = (n + 1) & ~(int64_t)1, cap = (dyn_max / 8 - TC_VECS * nv) / nv;      // rows of this matrix one workgroup can hold
             const int G = cap >= 1 ? (int)((n + cap - 1) / cap) : ncu + 1;
             if (G > ncu) { launch_set.push_back(q); continue; }
             Round* r = nullptr;
@@ -1099,7 +1104,7 @@ dmrgx_status symeig_batched(const std::vector<SymEigMat>& mats_in, hipStream_t s
                         const int q = r.mats[(size_t)i], n = M[q].n, G = r.G[(size_t)i];
                         ta.m[i] = TcMat{M[q].A, B + ws[q].VT, B + ws[q].d, B + ws[q].e, B + ws[q].tau, GB + goff[q], GB + goff[q] + 4 * (int64_t)n, n, M[q].lda, n, G, wg0, 0};
                         wg0 += G;
-                        lds = std::max(lds, (size_t)(TC_VECS + (n + G - 1) / G) * n * sizeof(double));
+                        lds = std::max(lds, (size_t)(TC_VECS + (n + G - 1) / G) * (size_t)((n + 1) & ~1) * sizeof(double));
                     } else ta.m[i] = TcMat{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 1 << 30, 0};
                 }
                 hipLaunchKernelGGL(trid_coop_kernel, dim3((unsigned)wg0), dim3(TC_THREADS), lds, st, ta);

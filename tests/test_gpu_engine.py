@@ -168,6 +168,46 @@ def test_step_by_step_parity_with_oracle_under_truncation_2d(tmp_path, Lx, Ly, J
     assert nonzero > 20
 
 
+def _big_golden():
+    return json.load(open(os.path.join(ROOT, "tests", "golden", "engine_big_lattices.json")))
+
+
+@pytest.mark.parametrize("name,ranks", [("cfg4_j1j2_20x8", 1), ("cfg4_j1j2_20x8", 2), ("cfg3_heisenberg_16x6", 1), ("cfg5_xy_32x8", 1)])
+def test_headline_lattices_step_by_step_against_the_oracle(tmp_path, name, ranks):
+    """The geometries BASELINE's numbers are quoted on -- J1-J2 20x8 (configs[3]; also on two ranks), Heisenberg 16x6 (configs[2]),
+    XY 32x8 with the NNN bonds dropped at Jz2 = 0 (configs[4]) -- at reduced m, step by step against the CPU oracle's DMRG
+    (tests/golden/engine_big_lattices.json, generated by tests/golden/make_engine_golden.py from oracle/dmrg.py: minutes of
+    single-threaded Python per lattice).  Up to and including the first step whose m-cut is ill-defined (degenerate or round-off
+    eigenvalues at the cut: the kept subspace is then decided by rounding noise in any implementation) the superblock sizes and
+    the ground-state energy must agree at 1e-10 relative, and before it the truncation errors and the rotated sizes too; after
+    it, energies agree at the scale of the truncation error.  Match: src/Hamiltonians.cpp:70-122 (74-, 20- and 18-term cuts of
+    the width-8 / width-6 cylinders), src/DMRGKron.cpp:1842-1864, include/DMRGBlockContainer.hpp:1656-1959."""
+    g = _big_golden()[name]
+    o = g["options"]
+    rows, run, _ = run_engine(tmp_path, "-Lx", o["Lx"], "-Ly", o["Ly"], "-J1", o["J1"], "-Jz1", o["Jz1"], "-J2", o["J2"], "-Jz2", o["Jz2"], "-qn_sector", g["qn_sector"],
+                              "-mwarmup", g["m"], "-nsweeps", g["nsweeps"], "-H_eps_tol", 1e-13, ranks=ranks)
+    steps = g["steps"]
+    assert len(rows) == len(steps) and run["Ranks"] == ranks
+    first_ill = next((i for i, st in enumerate(steps) if not st["well_defined"]), len(steps))
+    assert first_ill >= 2                                                     # the strict part is not empty
+    trunc = max(st["TruncErr_Sys"] for st in steps)
+    for i, (r, st) in enumerate(zip(rows, steps)):
+        for key in ("NSites_Sys", "NSites_Env"):
+            assert r[key] == st[key], (i, key)
+        if i <= first_ill:
+            for key in ("NStates_SysEnl", "NStates_EnvEnl", "NumStates_H"):
+                assert r[key] == st[key], (i, key)
+            assert abs(r["GSEnergy"] - st["GSEnergy"]) <= 1e-10 * abs(st["GSEnergy"]), (i, r["GSEnergy"], st["GSEnergy"])
+        else:
+            assert abs(r["GSEnergy"] - st["GSEnergy"]) <= 4.0 * trunc * abs(st["GSEnergy"]), (i, r["GSEnergy"], st["GSEnergy"])
+        if i < first_ill:
+            for key in ("NStates_SysRot", "NStates_EnvRot"):
+                assert r[key] == st[key], (i, key)
+            for side in ("TruncErr_Sys", "TruncErr_Env"):
+                assert abs(r[side] - st[side]) <= 1e-10 * abs(st[side]) + 1e-13, (i, side, r[side], st[side])
+    assert trunc > 1e-4                                                       # the truncation was real
+
+
 def test_baseline_config1_energy_against_the_oracle_at_reduced_m(tmp_path):
     """BASELINE configs[1] (J1-J2 8x4 cylinder, J2 = 0.5) is too large for exact diagonalisation and, at m = 512, for the CPU
     oracle.  In the Sz = 0 sector the +q/-q spectra are degenerate, so the kept subspaces of two implementations may differ by
