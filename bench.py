@@ -179,6 +179,10 @@ def sweep_legs():
     out = leg(run3, "configs[3] on one GPU: J1-J2 20x8 cylinder (160 sites), J2=0.5, m=2048, warm-up + two finite-system sweeps (real engine "
                     "run, -H_eps_type gd); sites_per_s is the second sweep, the first one (environment blocks still from the warm-up) is listed beside it")
     out["per_sweep"] = [{"sites_per_s": p["steps"] / p["seconds"], "matmults_per_s": p["matmults"] / p["seconds"], **p} for p in run3["PerSweep"]]
+    # the same lattice is tied to the CPU oracle step by step at m = 6 (tests/test_gpu_engine.py::test_headline_lattices_..., golden
+    # table tests/golden/engine_big_lattices.json: E = -121.10624750034 in the Sz = 1 sector); DMRG is variational in m and the
+    # Sz = 0 ground state lies below the Sz = 1 one, so the m = 2048 energy must lie below it
+    assert run3["GSEnergy"] < -121.10624750033969, run3["GSEnergy"]
     out["configs_1"] = leg(engine_run(["-Lx", 8, "-Ly", 4, "-mwarmup", 512, *j1j2, "-nsweeps", 1]),
                            "configs[1]: J1-J2 8x4 cylinder, J2=0.5, m=512, one finite-system sweep after warm-up (real engine run)")
     # The like-for-like figure beside the tuned one: the reference's own solver settings for this path -- Krylov-Schur type (here:

@@ -536,17 +536,23 @@ __global__ void __launch_bounds__(DC_LEAF_THREADS) dc_leaf_kernel(const DcMat* _
         if (tid + 1 < p) { const double ev = m.e[gi] * inv; S[tid][tid + 1] = ev; S[tid + 1][tid] = ev; }
     }
     __syncthreads();
+    // round-robin tournament over pe = p rounded up to even players (a leaf of 17 needs 17 rounds of 9 pairs per sweep, not the 31 x 16
+    // of the full 32 x 32 array; the odd player out meets the padding index p, whose row and column are zero: no rotation)
+    const int pe = (p + 1) & ~1, hp = pe / 2;
     for (int sweep = 0; sweep < 20; ++sweep) {
         double off = 0.0, dg = 0.0;
         for (int e = tid; e < P * P; e += DC_LEAF_THREADS) { const int i = e / P, c = e % P; const double v = S[i][c]; if (i == c) dg += v * v; else off += v * v; }
         off = block_sum<DC_LEAF_THREADS / 64>(off, red, tid);
         dg = block_sum<DC_LEAF_THREADS / 64>(dg, red, tid);
         if (off <= 2e-31 * dg || off == 0.0) break;          // off-diagonal norm <= 2 eps |T|; uniform over the workgroup
-        for (int r = 0; r < P - 1; ++r) {
-            if (tid < H) {                                   // pair tid of round r (round-robin tournament of 32 indices)
+        for (int r = 0; r < pe - 1; ++r) {
+            auto pair_of = [&](int t, int& a, int& bq) {
+                if (t == 0) { a = pe - 1; bq = r; } else { a = (r + t) % (pe - 1); bq = (r - t + pe - 1) % (pe - 1); }
+                if (a > bq) { const int x = a; a = bq; bq = x; }
+            };
+            if (tid < hp) {                                  // pair tid of round r
                 int a, bq;
-                if (tid == 0) { a = P - 1; bq = r; } else { a = (r + tid) % (P - 1); bq = (r - tid + P - 1) % (P - 1); }
-                if (a > bq) { const int t = a; a = bq; bq = t; }
+                pair_of(tid, a, bq);
                 const double apq = S[a][bq], app = S[a][a], aqq = S[bq][bq];
                 double c = 1.0, s = 0.0;
                 if (apq != 0.0) {
@@ -557,11 +563,10 @@ __global__ void __launch_bounds__(DC_LEAF_THREADS) dc_leaf_kernel(const DcMat* _
                 rc[tid] = c; rs[tid] = s;
             }
             __syncthreads();
-            for (int e = tid; e < H * P; e += DC_LEAF_THREADS) {         // columns: S <- S J, R <- R J
-                const int t = e / P, i = e % P;
+            for (int e = tid; e < hp * pe; e += DC_LEAF_THREADS) {         // columns: S <- S J, R <- R J
+                const int t = e / pe, i = e % pe;
                 int a, bq;
-                if (t == 0) { a = P - 1; bq = r; } else { a = (r + t) % (P - 1); bq = (r - t + P - 1) % (P - 1); }
-                if (a > bq) { const int x = a; a = bq; bq = x; }
+                pair_of(t, a, bq);
                 const double c = rc[t], s = rs[t];
                 const double sp = S[i][a], sq = S[i][bq];
                 S[i][a] = c * sp - s * sq; S[i][bq] = s * sp + c * sq;
@@ -569,11 +574,10 @@ __global__ void __launch_bounds__(DC_LEAF_THREADS) dc_leaf_kernel(const DcMat* _
                 R[i][a] = c * rp - s * rq; R[i][bq] = s * rp + c * rq;
             }
             __syncthreads();
-            for (int e = tid; e < H * P; e += DC_LEAF_THREADS) {         // rows: S <- J^T S
-                const int t = e / P, i = e % P;
+            for (int e = tid; e < hp * pe; e += DC_LEAF_THREADS) {         // rows: S <- J^T S
+                const int t = e / pe, i = e % pe;
                 int a, bq;
-                if (t == 0) { a = P - 1; bq = r; } else { a = (r + t) % (P - 1); bq = (r - t + P - 1) % (P - 1); }
-                if (a > bq) { const int x = a; a = bq; bq = x; }
+                pair_of(t, a, bq);
                 const double c = rc[t], s = rs[t];
                 const double sp = S[a][i], sq = S[bq][i];
                 S[a][i] = c * sp - s * sq; S[bq][i] = s * sp + c * sq;

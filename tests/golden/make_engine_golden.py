@@ -17,7 +17,7 @@ sys.path.insert(0, ROOT)
 
 CASES = {
     "cfg4_j1j2_20x8": dict(Lx=20, Ly=8, J1=1.0, Jz1=1.0, J2=0.5, Jz2=0.5, cand=[(8, 1), (6, 1), (10, 1), (8, 2)]),
-    "cfg3_heisenberg_16x6": dict(Lx=16, Ly=6, J1=0.5, Jz1=1.0, J2=0.0, Jz2=0.0, cand=[(6, 1), (10, 1), (8, 2), (12, 1)]),
+    "cfg3_heisenberg_16x6": dict(Lx=16, Ly=6, J1=0.5, Jz1=1.0, J2=0.0, Jz2=0.0, cand=[(4, 2), (6, 1), (10, 1), (8, 2), (12, 1)]),   # (4, 2): every one of its 134 cuts is well-defined
     "cfg5_xy_32x8": dict(Lx=32, Ly=8, J1=1.0, Jz1=0.0, J2=1.0, Jz2=0.0, cand=[(8, 1), (6, 1)]),      # Jz2 = 0: the reference drops the NNN bonds
 }
 KEYS = ("NSites_Sys", "NSites_Env", "NStates_SysEnl", "NStates_EnvEnl", "NumStates_H", "NStates_SysRot", "NStates_EnvRot", "GSEnergy", "TruncErr_Sys", "TruncErr_Env")
