@@ -215,7 +215,7 @@ ggemm_kernel(const GTile* __restrict__ tiles, const GGroup* __restrict__ groups,
         if (!have) break;                                                                     \
         GG_STEP(1, GUARD);                                                                    \
     }
-    if (TR * TC > 4 || wave_full) { GG_STREAM(true) }     // (the 128 x 128 kernel only ever gets interior tiles)
+    if (TR * TC > 6 || wave_full) { GG_STREAM(true) }     // (the 128 x 128 kernel only ever gets interior tiles; a 96-row tile is ragged by construction)
     else { GG_STREAM(mi < tr_eff && ni < tc_eff) }
 #undef GG_STREAM
 #undef GG_STEP
@@ -295,7 +295,7 @@ int ggemm_cluster()
 bool ggemm_use_big_tiles()
 {
     const char* e = getenv("DMRGX_TILES");
-    return e && std::string(e) == "mixed";   // the plan's ragged task tables currently balance better on 64 x 64 tiles only
+    return e && (std::string(e) == "mixed" || std::string(e) == "overlap");   // overlap: mixed tiles, the two launches of a stage on two streams
 }
 
 void ggemm_schedule(std::vector<GTile>& tiles, int unit)
@@ -343,7 +343,8 @@ void ggemm_schedule(std::vector<GTile>& tiles, int unit)
 dmrgx_status ggemm_launch(const GTile* d_tiles, const GGroup* d_groups, const GProd* d_prods, int32_t ntiles, hipStream_t st, int big)
 {
     if (ntiles <= 0) return DMRGX_OK;
-    if (big) hipLaunchKernelGGL((ggemm_kernel<4, 2, 2, 4>), dim3((unsigned)ntiles), dim3(512), 0, st, d_tiles, d_groups, d_prods, ntiles);
+    if (big == GG_SHAPE_TALL) hipLaunchKernelGGL((ggemm_kernel<3, 2, 2, 2>), dim3((unsigned)ntiles), dim3(256), 0, st, d_tiles, d_groups, d_prods, ntiles);
+    else if (big) hipLaunchKernelGGL((ggemm_kernel<4, 2, 2, 4>), dim3((unsigned)ntiles), dim3(512), 0, st, d_tiles, d_groups, d_prods, ntiles);
     else hipLaunchKernelGGL((ggemm_kernel<2, 2, 2, 2>), dim3((unsigned)ntiles), dim3(256), 0, st, d_tiles, d_groups, d_prods, ntiles);
     DMRGX_HIP(hipGetLastError());
     return DMRGX_OK;

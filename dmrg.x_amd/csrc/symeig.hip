@@ -30,7 +30,12 @@ constexpr int TRID_THREADS = 256, TRID_ROWS = 8;      // rows of the trailing ma
 constexpr int TRID_PF = 8;                            // chunks of 64 columns requested per row before they are used
 constexpr int DC_LEAF = 32;                           // largest leaf of the divide-and-conquer tree
 constexpr int DC_LEAF_THREADS = 256;                  // (one wave per leaf measured 2x slower: the sweep is bound by its LDS work, not by its barriers)
-constexpr int WY_NB = 64;                             // reflectors per block of the back-transformation
+#ifndef DMRGX_WY_NB
+#define DMRGX_WY_NB 64
+#endif
+constexpr int WY_NB = DMRGX_WY_NB;                    // reflectors per block of the back-transformation.  -DDMRGX_WY_NB=128 (T assembled from two 64-halves, half as
+                                                      // many dependent GEMM steps) measured SLOWER on the same box: 9.03-9.07 vs 8.72-8.74 ms per create at m = 2048
+constexpr int WY_SUB = 64;                            // its T factor is inverted in halves: T = [T1, -T1 (V1^T V2) T2; 0, T2]
 constexpr double DC_EPS = DBL_EPSILON;
 
 struct TridMat {
@@ -455,16 +460,17 @@ __global__ void __launch_bounds__(256) transpose_sq_kernel(const SqPair* __restr
 // ---------------------------------------------------------------------------------------------------------------------------
 // 3. compact-WY factor of a block of reflectors:  Tneg = -(striu(G) + diag(1 / tau))^-1,  G = V_b^T V_b  (64 x 64, row-major)
 // ---------------------------------------------------------------------------------------------------------------------------
-struct WyBlock { const double* G; const double* tau; double* Tneg; int32_t kb, pad; };
-__global__ void __launch_bounds__(WY_NB) wy_tinv_kernel(const WyBlock* __restrict__ blocks)
+struct WyBlock { const double* G; const double* tau; double* Tneg; int32_t kb, ld, zero_below, pad; };      // one 64 x 64 diagonal sub-block; G and Tneg with row stride ld;
+                                                                                                      // zero_below: rows of the (structurally zero) block under it to clear
+__global__ void __launch_bounds__(WY_SUB) wy_tinv_kernel(const WyBlock* __restrict__ blocks)
 {
-    __shared__ double S[WY_NB][WY_NB + 1];            // upper triangle + diagonal: S; strictly lower triangle: T^T (T[r][c] at [c][r])
+    __shared__ double S[WY_SUB][WY_SUB + 1];          // upper triangle + diagonal: S; strictly lower triangle: T^T (T[r][c] at [c][r])
     const WyBlock b = blocks[blockIdx.x];
     const int c = threadIdx.x, kb = b.kb;
-    for (int r = 0; r < WY_NB; ++r) {
+    for (int r = 0; r < WY_SUB; ++r) {
         double v = 0.0;
         if (r < kb && c < kb) {
-            if (c > r) v = b.G[r * WY_NB + c];
+            if (c > r) v = b.G[(int64_t)r * b.ld + c];
             else if (c == r) { const double t = b.tau[r]; v = t != 0.0 ? 1.0 / t : 1.0; }
         } else if (r == c) v = 1.0;
         if (c >= r) S[r][c] = v;
@@ -473,18 +479,19 @@ __global__ void __launch_bounds__(WY_NB) wy_tinv_kernel(const WyBlock* __restric
     // column c of S^-1 by back substitution (S upper triangular): t_c = 1 / S_cc;  t_r = -(sum_{l = r+1 .. c} S_rl t_l) / S_rr.
     // Thread c writes row c of the lower triangle only and reads the upper triangle, which nobody writes: no barrier in the loop.
     const double tcc = 1.0 / S[c][c];
-    for (int r = WY_NB - 2; r >= 0; --r) {
+    for (int r = WY_SUB - 2; r >= 0; --r) {
         if (r < c) {
             double acc = S[r][c] * tcc;
             for (int l = r + 1; l < c; ++l) acc += S[r][l] * S[c][l];
             S[c][r] = -acc / S[r][r];
         }
     }
-    for (int r = 0; r < WY_NB; ++r) {
-        double t = 0.0;
-        if (r < kb && c < kb) t = r < c ? S[c][r] : (r == c ? tcc : 0.0);
-        b.Tneg[r * WY_NB + c] = -t;
+    for (int r = 0; r < kb; ++r) {
+        if (c >= kb) break;
+        const double t = r < c ? S[c][r] : (r == c ? tcc : 0.0);
+        b.Tneg[(int64_t)r * b.ld + c] = -t;
     }
+    for (int r = 0; r < b.zero_below; ++r) b.Tneg[(int64_t)(WY_SUB + r) * b.ld + c] = 0.0;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
@@ -1138,10 +1145,10 @@ dmrgx_status symeig_batched(const std::vector<SymEigMat>& mats_in, hipStream_t s
     };
     std::vector<SqPair> tp(nm);
     std::vector<WyBlock> wyb;
-    GemmSet set_gram, set_tv;
+    GemmSet set_gram, set_tv, set_t12a, set_t12b;
     int max_nblk = 0;
     {
-        std::vector<GTile> gb, gs, tb, tsm;
+        std::vector<GTile> gb, gs, tb, tsm, pb_, ps_, qb_, qs_;
         for (int i = 0; i < nm; ++i) {
             const int n = M[i].n;
             const Ws& w = ws[i];
@@ -1151,11 +1158,21 @@ dmrgx_status symeig_batched(const std::vector<SymEigMat>& mats_in, hipStream_t s
                 const int b0 = b * WY_NB, kb = std::min(WY_NB, n - 2 - b0), r0 = b0 + 1;      // reflectors b0 .. b0+kb-1 live in rows >= b0+1
                 double* G = B + w.G + (int64_t)b * WY_NB * WY_NB;
                 double* Tn = B + w.Tn + (int64_t)b * WY_NB * WY_NB;
-                add_gemm(gb, gs, G, WY_NB, kb, kb, B + w.VT + (int64_t)b0 * n + r0, n, B + w.Vc + (int64_t)r0 * n + b0, n, n - r0, 0);
-                wyb.push_back(WyBlock{G, B + w.tau + b0, Tn, kb, 0});
+                add_gemm(gb, gs, G, WY_NB, kb, kb, B + w.VT + (int64_t)b0 * n + r0, n, B + w.Vc + (int64_t)r0 * n + b0, n, n - r0, 0);      // G = V_b^T V_b
+                const int k1 = std::min(kb, WY_SUB), k2 = kb - k1;
+                wyb.push_back(WyBlock{G, B + w.tau + b0, Tn, k1, WY_NB, k2, 0});
+                if (k2 > 0) {
+                    wyb.push_back(WyBlock{G + (int64_t)WY_SUB * WY_NB + WY_SUB, B + w.tau + b0 + WY_SUB, Tn + (int64_t)WY_SUB * WY_NB + WY_SUB, k2, WY_NB, 0, 0});
+                    // Tneg12 = Tneg1 . G12 . Tneg2 (= -T12): P = G12 . Tneg2 parked in the unused lower-left block of G, then Tneg12 = Tneg1 . P
+                    double* Pm = G + (int64_t)WY_SUB * WY_NB;
+                    add_gemm(pb_, ps_, Pm, WY_NB, k1, k2, G + WY_SUB, WY_NB, Tn + (int64_t)WY_SUB * WY_NB + WY_SUB, WY_NB, k2, 0);
+                    add_gemm(qb_, qs_, Tn + WY_SUB, WY_NB, k1, k2, Tn, WY_NB, Pm, WY_NB, k1, 0);
+                }
                 add_gemm(tb, tsm, B + w.TV + (int64_t)b0 * n, n, kb, n, Tn, WY_NB, B + w.VT + (int64_t)b0 * n, n, kb, 0);     // (T V^T)_b = Tneg_b . V_b^T
             }
         }
+        set_t12a = add_set(pb_, ps_);
+        set_t12b = add_set(qb_, qs_);
         set_gram = add_set(gb, gs);
         set_tv = add_set(tb, tsm);
     }
@@ -1235,7 +1252,7 @@ dmrgx_status symeig_batched(const std::vector<SymEigMat>& mats_in, hipStream_t s
     if (groups.empty()) groups.push_back(GGroup{nullptr, 0, 0, 0, 0, 0, 0, 0});
     if (tiles.empty()) tiles.push_back(GTile{-1, 0, 0, 0});
     if (merges.empty()) merges.push_back(DcMerge{0, 0, 0, 0, 0, 0});
-    if (wyb.empty()) wyb.push_back(WyBlock{nullptr, nullptr, nullptr, 0, 0});
+    if (wyb.empty()) wyb.push_back(WyBlock{nullptr, nullptr, nullptr, 0, 0, 0, 0});
     DevBuf d_prods, d_groups, d_tiles, d_tp, d_wyb, d_dm, d_leaves, d_merges;
     DMRGX_CHK(upload(d_prods, prods, st)); DMRGX_CHK(upload(d_groups, groups, st)); DMRGX_CHK(upload(d_tiles, tiles, st));
     DMRGX_CHK(upload(d_tp, tp, st)); DMRGX_CHK(upload(d_wyb, wyb, st)); DMRGX_CHK(upload(d_dm, dm, st));
@@ -1317,8 +1334,10 @@ dmrgx_status symeig_batched(const std::vector<SymEigMat>& mats_in, hipStream_t s
         hipLaunchKernelGGL(transpose_sq_kernel, dim3(t32, t32, (unsigned)nm), dim3(256), 0, st, d_tp.as<SqPair>());
         DMRGX_HIP(hipGetLastError());
         DMRGX_CHK(run_set(set_gram));
-        hipLaunchKernelGGL(wy_tinv_kernel, dim3((unsigned)wyb.size()), dim3(WY_NB), 0, st, d_wyb.as<WyBlock>());
+        hipLaunchKernelGGL(wy_tinv_kernel, dim3((unsigned)wyb.size()), dim3(WY_SUB), 0, st, d_wyb.as<WyBlock>());
         DMRGX_HIP(hipGetLastError());
+        DMRGX_CHK(run_set(set_t12a));
+        DMRGX_CHK(run_set(set_t12b));
         DMRGX_CHK(run_set(set_tv));
     }
 

@@ -1205,16 +1205,46 @@ public:
             auto rot = std::make_shared<dmrgx_host::BasisRotation>();
             rot->old_sizes = M[side]->Sizes32();
             std::vector<PetscReal> qn_list; std::vector<PetscInt> qn_size;
+            /* On several ranks the kept eigenvectors travel in ONE broadcast per owner and side (round 2: one per kept sector): the owner
+               gathers the rows of all its sectors into a staging buffer, broadcasts it, and every rank cuts its per-sector buffers out
+               of it with device copies (the reference broadcasts the whole rotation from rank 0, include/DMRGBlockContainer.hpp:1812-1925). */
+            std::vector<int64_t> stage_off;                              /* per kept sector: offset into its owner's staging buffer */
+            std::vector<int64_t> stage_len((size_t)W, 0);
+            for (const auto& kv : per) {
+                const PetscInt blk = kv.first, k = kv.second.first, cnt = kv.second.second, n = M[side]->Sizes(blk);
+                const int own = owner[(size_t)(2 * k + side)];
+                stage_off.push_back(own >= 0 ? stage_len[(size_t)own] : -1);
+                if (own >= 0) stage_len[(size_t)own] += (int64_t)cnt * n;
+            }
+            std::vector<std::shared_ptr<dmrgx_host::DevBuffer>> staging((size_t)W);
+            if (W > 1) for (int w = 0; w < W; ++w) if (stage_len[(size_t)w] > 0) staging[(size_t)w] = std::make_shared<dmrgx_host::DevBuffer>((size_t)stage_len[(size_t)w], dmrgx_host::DevBuffer::device_only_t{});
+            size_t si = 0;
             for (const auto& kv : per) {
                 const PetscInt blk = kv.first, k = kv.second.first, cnt = kv.second.second, n = M[side]->Sizes(blk);
                 rot->old_sector.push_back((int32_t)blk); rot->kept.push_back((int32_t)cnt);
                 const int own = owner[(size_t)(2 * k + side)];
+                const int64_t soff = stage_off[si++];
                 if (own < 0) { rot->rt.push_back(nullptr); qn_list.push_back(M[side]->List(blk)); qn_size.push_back(cnt); continue; }   /* spectrum only */
                 auto buf = std::make_shared<dmrgx_host::DevBuffer>((size_t)cnt * n, dmrgx_host::DevBuffer::device_only_t{});
-                if (own == me && dmrgx_rdm_eigenvectors(rdm, side, (int32_t)k, (int32_t)cnt, buf->dev_uninitialised(), n, nullptr)) { dmrgx_rdm_destroy(rdm); SETERRQ1(mpi_comm, 1, "dmrgx_rdm_eigenvectors: %s", dmrgx_last_error()); }
-                if (W > 1 && dmrgx_comm_bcast(comm, buf->dev_uninitialised(), (size_t)cnt * (size_t)n * sizeof(double), own, nullptr)) { dmrgx_rdm_destroy(rdm); SETERRQ1(mpi_comm, 1, "dmrgx_comm_bcast: %s", dmrgx_last_error()); }
+                double* dst = W > 1 ? staging[(size_t)own]->dev_uninitialised() + soff : buf->dev_uninitialised();
+                if (own == me && dmrgx_rdm_eigenvectors(rdm, side, (int32_t)k, (int32_t)cnt, dst, n, nullptr)) { dmrgx_rdm_destroy(rdm); SETERRQ1(mpi_comm, 1, "dmrgx_rdm_eigenvectors: %s", dmrgx_last_error()); }
                 rot->rt.push_back(buf);
                 qn_list.push_back(M[side]->List(blk)); qn_size.push_back(cnt);
+            }
+            if (W > 1) {
+                for (int w = 0; w < W; ++w)
+                    if (staging[(size_t)w] && dmrgx_comm_bcast(comm, staging[(size_t)w]->dev_uninitialised(), (size_t)stage_len[(size_t)w] * sizeof(double), w, nullptr)) { dmrgx_rdm_destroy(rdm); SETERRQ1(mpi_comm, 1, "dmrgx_comm_bcast: %s", dmrgx_last_error()); }
+                si = 0;
+                size_t ri = 0;
+                for (const auto& kv : per) {
+                    const PetscInt blk = kv.first, k = kv.second.first, cnt = kv.second.second, n = M[side]->Sizes(blk);
+                    const int own = owner[(size_t)(2 * k + side)];
+                    const int64_t soff = stage_off[si++];
+                    const auto& buf = rot->rt[ri++];
+                    if (own < 0 || !buf) continue;
+                    if (dmrgx_memcpy_d2d(buf->dev_uninitialised(), staging[(size_t)own]->dev_uninitialised() + soff, (size_t)cnt * (size_t)n * sizeof(double), nullptr)) { dmrgx_rdm_destroy(rdm); SETERRQ1(mpi_comm, 1, "dmrgx_memcpy_d2d: %s", dmrgx_last_error()); }
+                }
+                dmrgx_stream_sync(nullptr);                              /* the staging buffers go out of scope below */
             }
             BT[side]->RotMatT = std::make_shared<dmrgx_host::SectorMat>();
             BT[side]->RotMatT->rot = rot;
