@@ -3,6 +3,8 @@
 Tolerances: f64 throughout; the HIP path sums in a different order than the reference's row loop
 (src/DMRGKron.cpp:1844-1864), so the bar is 1e-13 relative to max|y| (north_star: 1e-10 relative on E0).
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -12,6 +14,7 @@ from oracle.kron_c import ShellApplyC
 
 pytestmark = pytest.mark.gpu
 RTOL = 1e-13
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -263,6 +266,73 @@ def test_rdm_spectra_and_eigenvectors_vs_lapack(mods, sizes):
             tot[side] += w.sum()
     assert abs(tot[0] - 1.0) < 1e-13 and abs(tot[1] - 1.0) < 1e-13      # Tr rho = <psi|psi>
     rdm.destroy()
+
+
+def _rdm_check(sbm, ls, rs, blocks, psi, tol_orth=1e-13):
+    rdm = sbm.ReducedDensityMatrices(ls, rs, blocks, torch.from_numpy(psi).cuda())
+    off = 0
+    for k, (a, b) in enumerate(blocks):
+        Psi = psi[off:off + ls[a] * rs[b]].reshape(ls[a], rs[b]); off += ls[a] * rs[b]
+        for side, rho in ((0, Psi @ Psi.T), (1, Psi.T @ Psi)):
+            n = rho.shape[0]
+            w_ref = np.linalg.eigvalsh(rho)[::-1]
+            w = rdm.eigenvalues(side, k)
+            assert np.abs(w - w_ref).max() <= 3e-15 * n * np.abs(w_ref).max() + 1e-17, (n, side)
+            U = rdm.eigenvectors(side, k, n).cpu().numpy()
+            assert np.abs(U @ U.T - np.eye(n)).max() < tol_orth, (n, side)
+            assert np.abs(U @ rho @ U.T - np.diag(w)).max() < 1e-11 * np.linalg.norm(rho) + 1e-16, (n, side)
+    rdm.destroy()
+
+
+def test_rdm_direct_solver_degenerate_and_boundary_cases(mods):
+    """The tridiagonalisation + divide-and-conquer solver (csrc/symeig.hip) where its special paths run: exactly degenerate Schmidt
+    values (type-2 deflation: Givens chains applied to the rows of the merge matrices), orders around the leaf size and the tree's
+    split points (1, 2, 3, 31 .. 34, 63 .. 66), rank one, and a multiple of the identity."""
+    sbm, _, _ = mods
+    rng = np.random.default_rng(11)
+    # degenerate pairs and a triple, graded over 12 decades
+    n = 257
+    U, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    V, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    s = np.exp(-0.1 * np.arange(n)); s[1::2] = s[0::2][:len(s[1::2])]; s[10] = s[11] = s[12]
+    Psi = (U * s) @ V.T
+    _rdm_check(sbm, [n], [n], [(0, 0)], (Psi / np.linalg.norm(Psi)).ravel())
+    # tiny orders and the boundaries of the divide-and-conquer tree, all in one call (one persistent round, many matrices)
+    ls = [1, 2, 3, 31, 32, 33, 34, 63, 64, 65, 66]
+    rs = list(reversed(ls))
+    blocks = [(i, i) for i in range(len(ls))]
+    psi = rng.standard_normal(sum(a * b for a, b in zip(ls, rs)))
+    _rdm_check(sbm, ls, rs, blocks, psi / np.linalg.norm(psi))
+    # rank one; and Psi = orthogonal / sqrt(n): rho = I / n (every merge deflates completely)
+    u, v = rng.standard_normal(90), rng.standard_normal(70)
+    P1 = np.outer(u, v)
+    Q, _ = np.linalg.qr(rng.standard_normal((48, 48)))
+    psi = np.concatenate([P1.ravel(), Q.ravel()])
+    _rdm_check(sbm, [90, 48], [70, 48], [(0, 0), (1, 1)], psi / np.linalg.norm(psi))
+
+
+def test_rdm_direct_solver_large_orders(mods):
+    """Orders above the configs[3] sizes: 1500 (persistent kernel, 9 rows per workgroup) and 2200 (beyond the LDS budget of 256
+    workgroups: one launch per column)."""
+    sbm, _, _ = mods
+    rng = np.random.default_rng(12)
+    for n, r in ((1500, 700), (2200, 300)):
+        psi = rng.standard_normal(n * r)
+        _rdm_check(sbm, [n], [r], [(0, 0)], psi / np.linalg.norm(psi), tol_orth=2e-13)
+
+
+@pytest.mark.parametrize("env", [dict(DMRGX_TRID="launch"), dict(DMRGX_RDM_SOLVER="jacobi")])
+def test_rdm_alternative_paths_stay_correct(mods, env):
+    """The launch-per-column tridiagonalisation (the fallback of the persistent kernel) and the round-2 block-Jacobi solver are chosen
+    by process-wide switches: the LAPACK comparison in a child process with the switch set."""
+    import subprocess, sys
+    code = ("import sys, numpy as np, torch; sys.path.insert(0, %r); sys.path.insert(0, %r);"
+            "from __graft_entry__ import load_package; load_package();"
+            "import test_gpu_kron as t; from dmrgx_amd import superblock as sbm;"
+            "rng = np.random.default_rng(5); ls, rs = [300, 77], [120, 260]; psi = rng.standard_normal(300 * 120 + 77 * 260);"
+            "t._rdm_check(sbm, ls, rs, [(0, 0), (1, 1)], psi / np.linalg.norm(psi)); print('alt path ok')") % (ROOT, os.path.join(ROOT, "tests"))
+    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "alt path ok" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
 
 
 def _secop_from(op, keep):
