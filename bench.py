@@ -185,6 +185,11 @@ def sweep_legs():
     assert run3["GSEnergy"] < -121.10624750033969, run3["GSEnergy"]
     out["configs_1"] = leg(engine_run(["-Lx", 8, "-Ly", 4, "-mwarmup", 512, *j1j2, "-nsweeps", 1]),
                            "configs[1]: J1-J2 8x4 cylinder, J2=0.5, m=512, one finite-system sweep after warm-up (real engine run)")
+    # configs[2]'s lattice and m on ONE GPU (BASELINE names it for 2 GPUs: the N = 2 bench line runs it there); its geometry is tied
+    # to the oracle step by step at reduced m (tests/test_gpu_engine.py, golden table: E = -51.658556812379 at m = 4, Sz = 2)
+    run2 = engine_run(["-Lx", 16, "-Ly", 6, "-heisenberg", 1, "-mwarmup", 1024, "-nsweeps", 1, "-H_eps_type", "gd"], timeout=600)
+    out["configs_2"] = leg(run2, "configs[2] on one GPU: Heisenberg 16x6 cylinder (96 sites), m=1024, one finite-system sweep after warm-up (real engine run, -H_eps_type gd)")
+    assert run2["GSEnergy"] < -51.65855681237887, run2["GSEnergy"]
     # The like-for-like figure beside the tuned one: the reference's own solver settings for this path -- Krylov-Schur type (here:
     # thick-restart Lanczos) from a RANDOM start vector, as include/DMRGBlockContainer.hpp:1488-1499 runs every eigensolve
     # (-wavefunction_guess 0).  configs[1] always; configs[3] (warm-up + one sweep, about a minute) unless the legs above already
