@@ -369,7 +369,7 @@ public:
         if (min_block < 1) SETERRQ1(mpi_comm, 1, "MinBlock must at least be 1. Got %lld.", LLD(min_block));
         PetscLogDouble ts0, ts1;
         ierr = PetscTime(&ts0); CHKERRQ(ierr);
-        const PetscInt steps0 = GlobIdx, mm0 = total_matmults;
+        const PetscInt steps0 = GlobIdx, mm0 = total_matmults, rot0 = rot_ops_total;
         LoopType = SweepStep; StepIdx = 0;
         for (PetscInt iblock = num_sites / 2; iblock < num_sites - min_block - 2; ++iblock) {
             const PetscInt insys = iblock - 1, inenv = num_sites - iblock - 3, outsys = iblock, outenv = num_sites - iblock - 2;
@@ -395,6 +395,9 @@ public:
         }
         sweeps_mstates.push_back(MStates);
         ierr = PetscTime(&ts1); CHKERRQ(ierr);
+        if (dmrgx_host::WorldComm() && dmrgx_host::WorldSize() > 1) {      /* every rank: its own share of the rotation work (the correlators are dealt over the ranks) */
+            printf("[rank %d] SWEEP rotated operators = %lld\n", dmrgx_host::WorldRank(), LLD(rot_ops_total - rot0)); fflush(stdout);
+        }
         if (!mpi_rank) printf("SWEEP DONE  steps=%lld  time=%.6f s  sites/s=%.3f  MatMults=%lld  E=%.12g\n", LLD(GlobIdx - steps0), ts1 - ts0,
                               (GlobIdx - steps0) / (ts1 - ts0), LLD(total_matmults - mm0), gse);
         last_sweep_seconds = ts1 - ts0; last_sweep_steps = GlobIdx - steps0; last_sweep_matmults = total_matmults - mm0;
@@ -574,6 +577,7 @@ public:
             else { ierr = EnvBlockOut.RotateOperators(EnvBlockEnl, BT_R.RotMatT, hints && !hints->keep_env.empty() ? &hints->keep_env : nullptr); CHKERRQ(ierr); }
         }
         timings.nRotOps = (SysBlockOut.Dead() ? 0 : SysBlockOut.NumRotatedOps()) + ((same || EnvBlockOut.Dead()) ? 0 : EnvBlockOut.NumRotatedOps());
+        rot_ops_total += timings.nRotOps;
         step.NumStates_SysRot = SysBlockOut.NumStates(); step.NumStates_EnvRot = EnvBlockOut.NumStates();
         step.TruncErr_Sys = BT_L.TruncErr; step.TruncErr_Env = BT_R.TruncErr;
         ierr = PetscTime(&trotb); CHKERRQ(ierr);
@@ -927,13 +931,19 @@ public:
         DenseCache cacheL, cacheR;
         const PetscInt nkb = KronBlocks.size();
         dmrgx_host::DevBuffer dev_vals(std::max<size_t>(measurements.size(), 1), dmrgx_host::DevBuffer::device_only_t{});
+        if (dmrgx_memset_zero(dev_vals.dev_uninitialised(), std::max<size_t>(measurements.size(), 1) * sizeof(double), nullptr)) SETERRQ1(mpi_comm, 1, "%s", dmrgx_last_error());
         std::vector<char> queued(measurements.size(), 0);
+        BuildNeedTables();
+        dmrgx_comm* corr_comm = dmrgx_host::WorldComm();
+        const int corr_me = corr_comm ? dmrgx_host::WorldRank() : 0;
+        auto mine = [&](size_t ic) { return corr_owner.size() != measurements.size() || corr_owner[ic] < 0 || corr_owner[ic] == corr_me; };
         PetscLogDouble tc0, tc1, t_one = 0, t_two = 0, t_batch = 0; PetscInt n_one = 0, n_two = 0, n_batch = 0;
         /* ---- system-block correlators of one or two operators (magnetisations, neighbour pairs: the bulk of the table), batched:
                 <psi| P (x) 1 |psi> = sum_k < P[IL(k)], X_k X_k^T >_F
            so the Gram blocks G_k = X_k X_k^T are formed once (one grouped GEMM), all operator pairs are multiplied in one
            grouped GEMM per chunk, and all expectation values are one batch of 2-D inner products. */
         std::vector<char> done(measurements.size(), 0);
+        for (size_t ic = 0; ic < measurements.size(); ++ic) if (!mine(ic)) done[ic] = 1;      /* another rank's: its value arrives with the all-reduce */
         if (use_corr_batch) {
             PetscTime(&tc0);
             std::vector<int64_t> g_off((size_t)nkb + 1, 0);
@@ -971,6 +981,7 @@ public:
             };
             for (size_t ic = 0; ic < measurements.size(); ++ic) {
                 const Correlator& c = measurements[ic];
+                if (done[ic]) continue;
                 if (!c.EnvOps.empty() || c.SysOps.empty() || c.SysOps.size() > 2) continue;
                 int shift = 0;
                 for (const Op& o : c.SysOps) shift += int(o.OpType);
@@ -1062,8 +1073,10 @@ public:
         }
         {
             std::vector<double> hv(measurements.size(), 0.0);
+            const bool dealt = corr_comm && corr_owner.size() == measurements.size() && !measurements.empty() && corr_owner[0] >= 0;
+            if (dealt && dmrgx_comm_allreduce_sum(corr_comm, dev_vals.dev_uninitialised(), (int64_t)measurements.size(), nullptr)) SETERRQ1(mpi_comm, 1, "dmrgx_comm_allreduce_sum: %s", dmrgx_last_error());
             if (!hv.empty() && dmrgx_memcpy_d2h(hv.data(), dev_vals.dev_ro(), hv.size() * sizeof(double), nullptr)) SETERRQ1(mpi_comm, 1, "%s", dmrgx_last_error());
-            for (size_t i = 0; i < hv.size(); ++i) if (queued[i]) CorrValues[i] = hv[i];
+            for (size_t i = 0; i < hv.size(); ++i) if (queued[i] || dealt) CorrValues[i] = hv[i];      /* (an entry nobody queued stayed zero) */
         }
         if (!mpi_rank && verbose) printf("  * Calc. of Correlators: %lld batched through the Gram blocks %.6f s, %lld more on the system block %.6f s, %lld across the cut %.6f s\n", LLD(n_batch), t_batch, LLD(n_one), t_one, LLD(n_two), t_two);
         if (need_sm && !l_had) { ierr = L.DestroySm(); CHKERRQ(ierr); }
@@ -1278,8 +1291,55 @@ public:
                     need_right[(size_t)nb][(size_t)s] = 1;
                 }
         }
+        /* On W ranks the correlators are dealt over the ranks (round 3): a rank measures only its share, so it carries only the site
+           operators ITS correlators read on the way back to the centre (in round 2 every rank rotated all of them, up to 124
+           correlator-only operators per step at configs[3]); the values are summed over the ranks at the measurement.  Site i of the
+           half-lattice block is rotated N/2 - i times on the way back, so the one- and two-site correlators are cut into W runs of
+           equal carried weight by their lowest site (low sites are dear: rank 0's run is the shortest), and each string (row,
+           column, loop) then goes to the rank whose carried weight it raises the least.  The reference splits this work the other
+           way round, rotating operators on sub-communicators (src/DMRGBlock.cpp:761-773, -rot_nsubcomm). */
+        {
+            const int W = dmrgx_host::WorldComm() ? dmrgx_host::WorldSize() : 1;
+            corr_owner.assign(measurements.size(), -1);                      /* -1: measured by every rank (one-rank runs) */
+            if (W > 1 && !measurements.empty()) {
+                const PetscInt H = std::max<PetscInt>(N / 2, 1);
+                auto weight = [&](PetscInt i) { return (double)std::max<PetscInt>(H - i, 1); };
+                auto sites_of = [&](const Correlator& c) { std::vector<PetscInt> v; for (const Op& o : c.SysOps) v.push_back(o.idx); for (const Op& o : c.EnvOps) v.push_back(o.idx); return v; };
+                double total = 0; for (PetscInt i = 0; i < H; ++i) total += weight(i);
+                std::vector<int> site_rank((size_t)N, W - 1);
+                { double acc = 0; for (PetscInt i = 0; i < H; ++i) { site_rank[(size_t)i] = std::min(W - 1, (int)(acc * W / total)); acc += weight(i); } }
+                std::vector<std::vector<char>> has((size_t)W, std::vector<char>((size_t)N, 0));
+                std::vector<double> carried((size_t)W, 0.0);
+                auto give = [&](size_t ic, int r, const std::vector<PetscInt>& v) {
+                    corr_owner[ic] = r;
+                    for (PetscInt i : v) if (i >= 0 && i < N && !has[(size_t)r][(size_t)i]) { has[(size_t)r][(size_t)i] = 1; carried[(size_t)r] += weight(i); }
+                };
+                for (size_t ic = 0; ic < measurements.size(); ++ic) {
+                    const std::vector<PetscInt> v = sites_of(measurements[ic]);
+                    if (v.empty()) { corr_owner[ic] = 0; continue; }
+                    if (v.size() > 2) continue;
+                    const PetscInt lo = *std::min_element(v.begin(), v.end());
+                    give(ic, lo >= 0 && lo < N ? site_rank[(size_t)lo] : 0, v);
+                }
+                for (size_t ic = 0; ic < measurements.size(); ++ic) {
+                    if (corr_owner[ic] >= 0) continue;
+                    const std::vector<PetscInt> v = sites_of(measurements[ic]);
+                    int best = 0; double best_cost = 0;
+                    for (int r = 0; r < W; ++r) {
+                        double c = carried[(size_t)r];
+                        std::vector<char> seen((size_t)N, 0);
+                        for (PetscInt i : v) if (i >= 0 && i < N && !has[(size_t)r][(size_t)i] && !seen[(size_t)i]) { seen[(size_t)i] = 1; c += weight(i); }
+                        if (r == 0 || c < best_cost) { best = r; best_cost = c; }
+                    }
+                    give(ic, best, v);
+                }
+            }
+        }
+        const int me_rank = dmrgx_host::WorldComm() ? dmrgx_host::WorldRank() : 0;
         corr_sites.assign((size_t)N, 0);
-        for (const Correlator& c : measurements) {
+        for (size_t ic = 0; ic < measurements.size(); ++ic) {
+            if (corr_owner[ic] >= 0 && corr_owner[ic] != me_rank) continue;
+            const Correlator& c = measurements[ic];
             for (const Op& o : c.SysOps) if (o.idx >= 0 && o.idx < N) corr_sites[(size_t)o.idx] = 1;
             for (const Op& o : c.EnvOps) if (o.idx >= 0 && o.idx < N) corr_sites[(size_t)o.idx] = 1;
         }
@@ -1368,12 +1428,12 @@ private:
     }
     PetscErrorCode SaveTimingsHeaders()
     {
-        fprintf(fp_timings, "{\n  \"headers\" : [\"GlobIdx\", \"Total\", \"Enlr\", \"Kron\", \"Diag\", \"Rdms\", \"Rotb\", \"MatMults\" ],\n  \"table\" : ");
+        fprintf(fp_timings, "{\n  \"headers\" : [\"GlobIdx\", \"Total\", \"Enlr\", \"Kron\", \"Diag\", \"Rdms\", \"Rotb\", \"MatMults\", \"RotOps\" ],\n  \"table\" : ");
         return 0;
     }
     PetscErrorCode SaveTimingsData(const TimingsData& d)
     {
-        fprintf(fp_timings, "%s    [ %lld, %.9g, %.9g, %.9g, %.9g, %.9g, %.9g, %lld ]", rows_written ? ",\n" : "", LLD(GlobIdx), d.Total, d.tEnlr, d.tKron, d.tDiag, d.tRdms, d.tRotb, LLD(d.nMatMult));
+        fprintf(fp_timings, "%s    [ %lld, %.9g, %.9g, %.9g, %.9g, %.9g, %.9g, %lld, %lld ]", rows_written ? ",\n" : "", LLD(GlobIdx), d.Total, d.tEnlr, d.tKron, d.tDiag, d.tRdms, d.tRotb, LLD(d.nMatMult), LLD(d.nRotOps));
         fflush(fp_timings);
         return 0;
     }
@@ -1423,6 +1483,7 @@ private:
     PetscInt kron_rows = 0;
     PetscBool prune_ops = PETSC_TRUE;          /* -prune_ops 0: rotate and keep every site operator of every block, as the reference does */
     PetscBool step_profile = PETSC_FALSE;      /* -step_profile 1: HIP-event timing of the GEMM stages of every MatMult (KronStats.json) */
+    PetscInt rot_ops_total = 0;         /**< site operators this rank rotated so far */
     bool need_built = false;
     std::vector<std::vector<char>> need_left, need_right;
     std::vector<char> corr_sites;
@@ -1447,6 +1508,7 @@ private:
         std::string name, desc1, desc2, desc3;
     };
     std::vector<Correlator> measurements;
+    std::vector<int> corr_owner;        /**< per correlator: the rank that measures it, -1 = every rank (BuildNeedTables) */
     PetscBool corr_headers_printed = PETSC_FALSE, corr_printed_first = PETSC_FALSE;
     PetscBool do_scratch_dir = PETSC_FALSE, restart = PETSC_FALSE, restart_options = PETSC_FALSE;
     std::string restart_dir;

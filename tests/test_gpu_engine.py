@@ -2,6 +2,7 @@
 computation through the C ABI) against exact diagonalisation and against the CPU oracle's DMRG step by step."""
 import json
 import os
+import re
 import subprocess
 
 import numpy as np
@@ -42,6 +43,7 @@ def run_engine(tmp_path, *opts, ranks=1):
                     pr.kill()
         for r, (pr, o) in enumerate(zip(procs, outs)):
             assert pr.returncode == 0, "rank %d: %s" % (r, o[-3000:])
+            open(d + "rank%d.log" % r, "w").write(o)
     steps = json.load(open(d + "DMRGSteps.json"))
     rows = [dict(zip(steps["headers"], r)) for r in steps["table"]]
     run = json.load(open(d + "DMRGRun.json"))
@@ -98,7 +100,7 @@ def test_step_by_step_parity_with_oracle_under_truncation(tmp_path):
         for side in ("TruncErr_Sys", "TruncErr_Env"):
             assert abs(r[side] - o[side]) <= 1e-10 * abs(o[side]) + 1e-13, (r["GlobIdx"], side, r[side], o[side])
     assert max(o["TruncErr_Sys"] for o in orc.steps) > 1e-4               # the truncation was real
-    assert run["MatMults"] > 0 and timings["headers"][-1] == "MatMults"
+    assert run["MatMults"] > 0 and timings["headers"][-2:] == ["MatMults", "RotOps"]
     # correlators: same measurement steps, same values as the oracle's restatement
     corr = json.load(open(str(tmp_path) + "/Correlations.json"))
     orc2 = DMRGOracle(H, 4, qn_sector=1.0)
@@ -248,6 +250,29 @@ def test_multi_rank_engine_sweep_reproduces_the_single_rank_run(tmp_path):
     assert abs(run1["GSEnergy"] - run3["GSEnergy"]) <= 10.0 * trunc * abs(run1["GSEnergy"])
     c1, c3 = (json.load(open(str(tmp_path / d) + "/Correlations.json")) for d in ("w1", "w3"))
     assert len(c1["values"]) == len(c3["values"]) == 2
+
+
+def test_correlators_dealt_over_the_ranks_carry_fewer_operators(tmp_path):
+    """On W ranks every rank measures only its share of the correlators (values summed at the measurement), so on the way back to
+    the centre a rank rotates only the site operators ITS correlators read: the per-step operator counts of rank 0 (Timings.json,
+    column RotOps) drop against the one-rank run while Correlations.json stays the same table."""
+    # (a long, narrow lattice: most sites of a block are correlator-only there; on 6x4 nearly every site is a coupling site)
+    model = ["-Lx", 24, "-Ly", 2, "-J1", 0.7, "-Jz1", 1.0, "-J2", 0.4, "-Jz2", 0.6, "-qn_sector", 1, "-mwarmup", 4, "-nsweeps", 1, "-H_eps_tol", 1e-13]
+    _, _, t1 = run_engine(tmp_path / "w1", *model)
+    _, _, t3 = run_engine(tmp_path / "w3", *model, ranks=3)
+    c1, c3 = (json.load(open(str(tmp_path / d) + "/Correlations.json")) for d in ("w1", "w3"))
+    assert len(c1["values"]) == len(c3["values"]) == 2
+    for a, b in zip(c1["values"], c3["values"]):
+        assert np.abs(np.array(a) - np.array(b)).max() <= 1e-8      # (truncating run: the three-rank reductions sum in another order)
+    col = t1["headers"].index("RotOps")
+    r1, r3 = [row[col] for row in t1["table"]], [row[col] for row in t3["table"]]
+    assert len(r1) == len(r3) and all(b <= a for a, b in zip(r1, r3))
+    nsweep = 48 - 4
+    one = sum(r1[-nsweep:])
+    per_rank = [int(re.search(r"\[rank %d\] SWEEP rotated operators = (\d+)" % r, open(str(tmp_path / "w3") + "/rank%d.log" % r).read()).group(1)) for r in range(3)]
+    assert per_rank[0] == sum(r3[-nsweep:])
+    # the way out of the centre (left-only masks) is the same on every rank; of the way back each rank carries its run of sites
+    assert max(per_rank) < 0.8 * one, (one, per_rank)
 
 
 def test_engine_with_generalized_davidson_solver(tmp_path):
