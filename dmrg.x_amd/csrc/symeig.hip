@@ -1085,9 +1085,24 @@ dmrgx_status symeig_batched(const std::vector<SymEigMat>& mats_in, hipStream_t s
         std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return M[a].n > M[b].n; });
         struct Round { std::vector<int> mats, G; int wgs = 0; };
         std::vector<Round> rounds;
+        // Workgroups per matrix: at least what LDS capacity asks for; when that leaves CUs idle (small m: a dozen small matrices on 256
+        // CUs) the rows are spread further, down to `rows_target` rows per workgroup -- the column step is a latency chain in which
+        // a workgroup's own row pass (rows / 8 per wave) is one link, and more workgroups cost the all-gather almost nothing.
+        static const int rows_target = [] { const char* e = getenv("DMRGX_TRID_ROWS"); const int v = e ? atoi(e) : 16; return v < 1 ? 1 : v; }();
+        std::vector<int> Gmin(nm, 0), Gof(nm, 0);
+        {
+            int64_t sum_min = 0, sum_want = 0;
+            for (int q = 0; q < nm; ++q) {
+                const int64_t n = M[q].n, nv = (n + 1) & ~(int64_t)1, cap = (dyn_max / 8 - TC_VECS * nv) / nv;      // rows of this matrix one workgroup can hold
+                Gmin[q] = cap >= 1 ? (int)((n + cap - 1) / cap) : ncu + 1;
+                Gof[q] = std::max<int>(Gmin[q], (int)((n + rows_target - 1) / rows_target));
+                if (Gmin[q] <= ncu) { sum_min += Gmin[q]; sum_want += std::min(Gof[q], ncu); }
+            }
+            const double f = sum_want <= ncu ? 1.0 : (sum_min >= ncu ? 0.0 : double(ncu - sum_min) / double(sum_want - sum_min));
+            for (int q = 0; q < nm; ++q) if (Gmin[q] <= ncu) Gof[q] = Gmin[q] + (int)(f * (std::min(Gof[q], ncu) - Gmin[q]));
+        }
         for (int q : order) {
-            const int64_t n = M[q].n, nv = (n + 1) & ~(int64_t)1, cap = (dyn_max / 8 - TC_VECS * nv) / nv;      // rows of this matrix one workgroup can hold
-            const int G = cap >= 1 ? (int)((n + cap - 1) / cap) : ncu + 1;
+            const int G = Gof[q];
             if (G > ncu) { launch_set.push_back(q); continue; }
             Round* r = nullptr;
             for (Round& c : rounds) if (c.wgs + G <= ncu && (int)c.mats.size() < TRID_MAXM) { r = &c; break; }

@@ -17,6 +17,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <climits>
 #include <iomanip>
 #include <fstream>
 #include <array>
@@ -110,6 +111,18 @@ public:
 
     /** one (old sector, site state) piece of a sector of `block (x) site` */
     struct EnlPart { int32_t old_sector, site_sector, off, size; };
+    /* (see block_rot below) */
+    struct RotMeta {
+        int64_t parent_ver = -1;                          /**< version of sys_blocks[i-1] the rotation was computed in */
+        std::vector<std::vector<EnlPart>> parts;          /**< enlarged sectors of (that parent (x) site) */
+        std::vector<int> parent_qn2, enl_qn2;             /**< 2 Sz of the parent's sectors / of the enlarged sectors */
+        std::vector<int32_t> enl_sizes;
+    };
+    struct BasisOverlap {                                 /**< <version from | version to> of one block, sector by sector (key 2 Sz) */
+        int64_t from_ver = -1, to_ver = -1;
+        struct Cell { int32_t rows = 0, cols = 0; std::shared_ptr<dmrgx_host::DevBuffer> buf; };
+        std::map<int, Cell> cells;
+    };
 
     explicit DMRGBlockContainer(const MPI_Comm& mpi_comm) : mpi_comm(mpi_comm) {}
     ~DMRGBlockContainer() { PetscErrorCode ierr = Destroy(); CPP_CHKERR(ierr); }
@@ -173,6 +186,7 @@ public:
         if (no_symm) SETERRQ(mpi_comm, PETSC_ERR_SUP, "Unsupported option: no_symm.");
         ierr = PetscOptionsGetBool(NULL, NULL, "-debug_check_symmetry", &debug_symm, NULL); CHKERRQ(ierr);
         ierr = PetscOptionsGetBool(NULL, NULL, "-wavefunction_guess", &use_guess, NULL); CHKERRQ(ierr);
+        ierr = PetscOptionsGetBool(NULL, NULL, "-wavefunction_guess_overlap", &use_guess_overlap, NULL); CHKERRQ(ierr);
         ierr = PetscOptionsGetBool(NULL, NULL, "-rdm_warm_start", &use_rdm_warm, NULL); CHKERRQ(ierr);
         ierr = PetscOptionsGetBool(NULL, NULL, "-corr_batch", &use_corr_batch, NULL); CHKERRQ(ierr);
         ierr = PetscOptionsGetBool(NULL, NULL, "-prune_ops", &prune_ops, NULL); CHKERRQ(ierr);
@@ -427,8 +441,8 @@ public:
             size_t in_use = 0, cached = 0, peak = 0;
             dmrgx_mem_stats(&in_use, &cached, &peak);
             fprintf(fp_data, "],\n  \"GSEnergy\": %.16g,\n  \"MatMults\": %lld,\n  \"LastSweepSeconds\": %.9g,\n  \"LastSweepSteps\": %lld,\n  \"LastSweepMatMults\": %lld,\n  \"EigensolveSeconds\": %.9g,\n"
-                             "  \"DeviceBytesResidentAfterSweep\": %zu,\n  \"DeviceBytesPeak\": %zu,\n  \"DeviceBytesCached\": %zu,\n  \"Ranks\": %d\n}\n",
-                    gse, LLD(total_matmults), last_sweep_seconds, LLD(last_sweep_steps), LLD(last_sweep_matmults), total_eigs_seconds, device_bytes_after_sweep, peak, cached, (int)mpi_size);
+                             "  \"DeviceBytesResidentAfterSweep\": %zu,\n  \"DeviceBytesPeak\": %zu,\n  \"DeviceBytesCached\": %zu,\n  \"StartVectorsTransformed\": %lld,\n  \"StartVectorsThroughOverlap\": %lld,\n  \"Ranks\": %d\n}\n",
+                    gse, LLD(total_matmults), last_sweep_seconds, LLD(last_sweep_steps), LLD(last_sweep_matmults), total_eigs_seconds, device_bytes_after_sweep, peak, cached, LLD(guesses_used), LLD(guesses_projected), (int)mpi_size);
             fclose(fp_data); fp_data = NULL;
         }
         init = PETSC_FALSE;
@@ -556,9 +570,12 @@ public:
                 ierr = EnlargedParts(SysBlock, prev.partsL); CHKERRQ(ierr);
                 ierr = EnlargedParts(EnvBlock, prev.partsR); CHKERRQ(ierr);
                 prev.rotL = BT_L.RotMatT->rot; prev.rotR = BT_R.RotMatT->rot;
-                if (block_rot.size() < sys_blocks.size()) block_rot.resize(sys_blocks.size());
-                block_rot[(size_t)prev.outsys] = prev.rotL;
-                block_rot[(size_t)prev.outenv] = same ? prev.rotL : prev.rotR;
+                if (block_rot.size() < sys_blocks.size()) { block_rot.resize(sys_blocks.size()); rot_meta.resize(sys_blocks.size()); block_ver.resize(sys_blocks.size(), 0); block_ovl.resize(sys_blocks.size()); }
+                const int64_t pv_sys = block_ver[(size_t)prev.insys], pv_env = block_ver[(size_t)prev.inenv];      /* (read before either output index is re-versioned) */
+                try {
+                    ierr = RecordBlockBasis(prev.outsys, prev.rotL, pv_sys, prev.partsL, SysBlock); CHKERRQ(ierr);
+                    if (!same) { ierr = RecordBlockBasis(prev.outenv, prev.rotR, pv_env, prev.partsR, EnvBlock); CHKERRQ(ierr); }
+                } catch (const std::exception& e) { SETERRQ1(mpi_comm, 1, "basis overlap: %s", e.what()); }
                 prev.valid = true;
             }
         }
@@ -627,11 +644,175 @@ public:
         }
         return 0;
     }
+    static int Qn2(PetscReal q) { return (int)std::lround(2.0 * q); }
+    static bool HasVectors(const dmrgx_host::BasisRotation& R)
+    {
+        for (size_t a = 0; a < R.kept.size(); ++a) if (R.kept[a] > 0 && !R.rt[a]) return false;
+        return true;
+    }
+    /** Description of (parent (x) site) for a rotation: sector decomposition, quantum numbers, sizes. */
+    PetscErrorCode DescribeEnlarged(Block& parent, const std::vector<std::vector<EnlPart>>& parts, RotMeta& m)
+    {
+        m.parts = parts;
+        m.parent_qn2.clear(); m.enl_qn2.clear(); m.enl_sizes.clear();
+        for (PetscReal q : parent.Magnetization.ListRef()) m.parent_qn2.push_back(Qn2(q));
+        std::vector<int> site_qn2;
+        for (PetscReal q : AddSite().Magnetization.ListRef()) site_qn2.push_back(Qn2(q));
+        for (const std::vector<EnlPart>& sec : parts) {
+            int32_t n = 0;
+            for (const EnlPart& e : sec) n += e.size;
+            m.enl_sizes.push_back(n);
+            m.enl_qn2.push_back(sec.empty() ? INT_MIN : m.parent_qn2.at((size_t)sec[0].old_sector) + site_qn2.at((size_t)sec[0].site_sector));
+        }
+        return 0;
+    }
+    /** R maps (parent (x) site) -> block and is written in the enlarged basis `from` describes.  Returns the same rotation written
+        in the enlarged basis of ANOTHER version of the parent (`to`), every (parent sector, site state) part carried over through
+        `inner` = <parent version of `from` | parent version of `to`>.  Sectors or parts without a counterpart drop out (zero). */
+    std::shared_ptr<dmrgx_host::BasisRotation> ProjectRotation(const dmrgx_host::BasisRotation& R, const RotMeta& from, const BasisOverlap& inner, const RotMeta& to)
+    {
+        auto out = std::make_shared<dmrgx_host::BasisRotation>();
+        const size_t na = R.kept.size();
+        out->old_sizes = to.enl_sizes; out->kept = R.kept; out->old_sector.assign(na, -1); out->rt.assign(na, nullptr);
+        std::vector<int64_t> off(na, -1);
+        int64_t tot = 0;
+        for (size_t a = 0; a < na; ++a) {
+            if (R.kept[a] <= 0 || !R.rt[a] || R.old_sector[a] < 0) continue;
+            const int q2 = from.enl_qn2.at((size_t)R.old_sector[a]);
+            for (size_t I = 0; I < to.enl_qn2.size(); ++I) if (to.enl_qn2[I] == q2) { out->old_sector[a] = (int32_t)I; break; }
+            if (out->old_sector[a] < 0) continue;
+            off[a] = tot; tot += (int64_t)R.kept[a] * to.enl_sizes[(size_t)out->old_sector[a]];
+        }
+        if (tot == 0) return out;
+        auto arena = std::make_shared<dmrgx_host::DevBuffer>((size_t)tot, dmrgx_host::DevBuffer::device_only_t{});
+        double* base = arena->dev_uninitialised();
+        if (dmrgx_memset_zero(base, (size_t)tot * sizeof(double), nullptr)) throw std::runtime_error(dmrgx_last_error());
+        std::vector<dmrgx_gemm_task> tasks;
+        for (size_t a = 0; a < na; ++a) {
+            if (off[a] < 0) continue;
+            const int32_t If = R.old_sector[a], It = out->old_sector[a], nF = from.enl_sizes.at((size_t)If), nT = to.enl_sizes[(size_t)It], ka = R.kept[a];
+            /* the sector's rows live in the arena; DevBuffer views are not available, so every sector gets its own small handle on it */
+            out->rt[a] = std::make_shared<dmrgx_host::DevBuffer>(arena, (size_t)off[a], (size_t)ka * nT);
+            for (const EnlPart& pf : from.parts.at((size_t)If)) {
+                if (pf.size == 0) continue;
+                const int qj = from.parent_qn2.at((size_t)pf.old_sector);
+                auto ic = inner.cells.find(qj);
+                if (ic == inner.cells.end() || ic->second.rows != pf.size) continue;
+                for (const EnlPart& pt : to.parts[(size_t)It]) {
+                    if (pt.site_sector != pf.site_sector || to.parent_qn2.at((size_t)pt.old_sector) != qj || pt.size == 0 || ic->second.cols != pt.size) continue;
+                    tasks.push_back(dmrgx_gemm_task{ka, pt.size, pf.size, 0, R.rt[a]->dev_ro() + pf.off, nF, ic->second.buf->dev_ro(), pt.size, base + off[a] + pt.off, nT});
+                }
+            }
+        }
+        if (!tasks.empty() && dmrgx_dgemm_batch((int32_t)tasks.size(), tasks.data(), nullptr)) throw std::runtime_error(dmrgx_last_error());
+        return out;
+    }
+    /** <old version | new version> of one block from its two creation rotations written in the SAME enlarged basis:
+        O[q] = R_old[q] R_new[q]^T. */
+    std::shared_ptr<BasisOverlap> OverlapOfRotations(const dmrgx_host::BasisRotation& RX, const dmrgx_host::BasisRotation& RY, const std::vector<int>& enl_qn2)
+    {
+        auto O = std::make_shared<BasisOverlap>();
+        struct Pair { size_t a, b; int64_t toff, ooff; };
+        std::vector<Pair> pairs;
+        int64_t ttot = 0, otot = 0;
+        for (size_t a = 0; a < RX.kept.size(); ++a) {
+            if (RX.kept[a] <= 0 || !RX.rt[a] || RX.old_sector[a] < 0) continue;
+            for (size_t b = 0; b < RY.kept.size(); ++b) {
+                if (RY.kept[b] <= 0 || !RY.rt[b] || RY.old_sector[b] != RX.old_sector[a]) continue;
+                pairs.push_back(Pair{a, b, ttot, otot});
+                ttot += (int64_t)RY.kept[b] * RY.old_sizes.at((size_t)RY.old_sector[b]);
+                otot += (int64_t)RX.kept[a] * RY.kept[b];
+            }
+        }
+        if (pairs.empty()) return O;
+        auto tarena = std::make_shared<dmrgx_host::DevBuffer>((size_t)ttot, dmrgx_host::DevBuffer::device_only_t{});
+        auto oarena = std::make_shared<dmrgx_host::DevBuffer>((size_t)otot, dmrgx_host::DevBuffer::device_only_t{});
+        if (dmrgx_memset_zero(tarena->dev_uninitialised(), (size_t)ttot * sizeof(double), nullptr)) throw std::runtime_error(dmrgx_last_error());
+        std::vector<dmrgx_axpy_task> tr;
+        std::vector<dmrgx_gemm_task> gm;
+        for (const Pair& p : pairs) {
+            const int32_t nE = RY.old_sizes[(size_t)RY.old_sector[p.b]], kx = RX.kept[p.a], ky = RY.kept[p.b];
+            if (RX.old_sizes.at((size_t)RX.old_sector[p.a]) != nE) throw std::runtime_error("the two rotations are not written in the same enlarged basis");
+            dmrgx_axpy_task t;
+            t.dst = tarena->dev_uninitialised() + p.toff; t.dst_base = nullptr; t.src = RY.rt[p.b]->dev_ro(); t.ldd = ky; t.lds = nE; t.nr = nE; t.nc = ky; t.transposed = 1; t.alpha = 1.0;
+            tr.push_back(t);
+            gm.push_back(dmrgx_gemm_task{kx, ky, nE, 0, RX.rt[p.a]->dev_ro(), nE, tarena->dev_ro() + p.toff, ky, oarena->dev_uninitialised() + p.ooff, ky});
+            typename BasisOverlap::Cell c;
+            c.rows = kx; c.cols = ky; c.buf = std::make_shared<dmrgx_host::DevBuffer>(oarena, (size_t)p.ooff, (size_t)kx * ky);
+            O->cells[enl_qn2.at((size_t)RX.old_sector[p.a])] = c;
+        }
+        if (dmrgx_cells_axpy((int32_t)tr.size(), tr.data(), nullptr)) throw std::runtime_error(dmrgx_last_error());
+        if (dmrgx_dgemm_batch((int32_t)gm.size(), gm.data(), nullptr)) throw std::runtime_error(dmrgx_last_error());
+        return O;
+    }
+    /** <a|c> ~ <a|b><b|c> (exact on the part of a's span that version b holds) */
+    std::shared_ptr<BasisOverlap> ComposeOverlaps(const BasisOverlap& ab, const BasisOverlap& bc)
+    {
+        auto O = std::make_shared<BasisOverlap>();
+        std::vector<dmrgx_gemm_task> gm;
+        int64_t tot = 0;
+        for (const auto& kv : ab.cells) { auto it = bc.cells.find(kv.first); if (it != bc.cells.end() && it->second.rows == kv.second.cols) tot += (int64_t)kv.second.rows * it->second.cols; }
+        if (tot == 0) return O;
+        auto arena = std::make_shared<dmrgx_host::DevBuffer>((size_t)tot, dmrgx_host::DevBuffer::device_only_t{});
+        int64_t off = 0;
+        for (const auto& kv : ab.cells) {
+            auto it = bc.cells.find(kv.first);
+            if (it == bc.cells.end() || it->second.rows != kv.second.cols) continue;
+            typename BasisOverlap::Cell c;
+            c.rows = kv.second.rows; c.cols = it->second.cols; c.buf = std::make_shared<dmrgx_host::DevBuffer>(arena, (size_t)off, (size_t)c.rows * c.cols);
+            gm.push_back(dmrgx_gemm_task{c.rows, c.cols, kv.second.cols, 0, kv.second.buf->dev_ro(), kv.second.cols, it->second.buf->dev_ro(), it->second.cols, arena->dev_uninitialised() + off, c.cols});
+            O->cells[kv.first] = c;
+            off += (int64_t)c.rows * c.cols;
+        }
+        if (dmrgx_dgemm_batch((int32_t)gm.size(), gm.data(), nullptr)) throw std::runtime_error(dmrgx_last_error());
+        return O;
+    }
+    /** sys_blocks[k] has just been (re)created by `Rnew` from version `parent_ver` of sys_blocks[k-1] (`parent`, decomposition
+        `parts`).  If a stored block k+1 is the child of an earlier version of block k, the overlap <that version | new version> is
+        formed -- R_old (O_{k-1} (x) 1) R_new^T, with O_{k-1} the overlap of the two parents' versions one level down, composed with
+        the overlap block k already carried -- so that block k+1's creation rotation stays usable for the wavefunction
+        transformation (TransformedGuess); costs about two operator rotations. */
+    PetscErrorCode RecordBlockBasis(PetscInt k, const std::shared_ptr<dmrgx_host::BasisRotation>& Rnew, int64_t parent_ver, const std::vector<std::vector<EnlPart>>& parts, Block& parent)
+    {
+        if (k < 0 || k >= (PetscInt)block_rot.size()) return 0;
+        RotMeta mnew;
+        mnew.parent_ver = parent_ver;
+        PetscErrorCode ierr = DescribeEnlarged(parent, parts, mnew); CHKERRQ(ierr);
+        const int64_t new_ver = ++ver_counter;
+        std::shared_ptr<BasisOverlap> novl;
+        const size_t K = (size_t)k;
+        const bool child = K + 1 < block_rot.size() && block_rot[K + 1] && rot_meta[K + 1].parent_ver >= 0;
+        if (use_guess && use_guess_overlap && child && Rnew && block_rot[K] && HasVectors(*Rnew) && HasVectors(*block_rot[K]) && Rnew->old_sizes == mnew.enl_sizes) {
+            const int64_t P = rot_meta[K + 1].parent_ver, old_ver = block_ver[K];
+            const BasisOverlap* carried = nullptr;
+            bool ok = (P == old_ver);
+            if (!ok && block_ovl[K] && block_ovl[K]->from_ver == P && block_ovl[K]->to_ver == old_ver) { carried = block_ovl[K].get(); ok = true; }
+            const RotMeta& mold = rot_meta[K];
+            std::shared_ptr<dmrgx_host::BasisRotation> RX;
+            if (ok) {
+                if (mold.parent_ver == parent_ver && mold.enl_sizes == mnew.enl_sizes) RX = block_rot[K];
+                else if (K >= 1 && block_ovl[K - 1] && block_ovl[K - 1]->from_ver == mold.parent_ver && block_ovl[K - 1]->to_ver == parent_ver)
+                    RX = ProjectRotation(*block_rot[K], mold, *block_ovl[K - 1], mnew);
+            }
+            if (RX) {
+                novl = OverlapOfRotations(*RX, *Rnew, mnew.enl_qn2);
+                if (carried) novl = ComposeOverlaps(*carried, *novl);
+                novl->from_ver = P; novl->to_ver = new_ver;
+            }
+        }
+        block_ovl[K] = novl;
+        block_ver[K] = new_ver;
+        rot_meta[K] = std::move(mnew);
+        block_rot[K] = Rnew;
+        return 0;
+    }
+
     /** Fills `guess` (device, layout of KronBlocks) from the previous step if the two steps are consecutive positions
         of a sweep; returns used = false (guess untouched) otherwise or when any dimension does not line up. */
     PetscErrorCode TransformedGuess(KronBlocks_t& KronBlocks, Block& SysBlock, Block& EnvBlock, const Vec& guess, bool& used)
     {
         used = false;
+        bool projected = false;
         if (!use_guess || !prev.valid) return 0;
         const PetscInt insys = BlockIndex(SysBlock), inenv = BlockIndex(EnvBlock);
         if (insys < 0 || inenv < 0) return 0;
@@ -643,7 +824,20 @@ public:
         const std::shared_ptr<BasisRotation> G = grow_left ? prev.rotL : prev.rotR;
         const PetscInt shrink_idx = grow_left ? prev.inenv : prev.insys;
         if (shrink_idx < 0 || shrink_idx >= (PetscInt)block_rot.size() || !block_rot[(size_t)shrink_idx] || !G) return 0;
-        const std::shared_ptr<BasisRotation> S = block_rot[(size_t)shrink_idx];
+        std::shared_ptr<BasisRotation> S = block_rot[(size_t)shrink_idx];
+        /* S was computed in a version of block shrink_idx - 1; the block stored there now may be a later one (warm-up) */
+        if (shrink_idx >= 1 && (size_t)shrink_idx < rot_meta.size() && rot_meta[(size_t)shrink_idx].parent_ver >= 0 && rot_meta[(size_t)shrink_idx].parent_ver != block_ver[(size_t)shrink_idx - 1]) {
+            const RotMeta& mS = rot_meta[(size_t)shrink_idx];
+            const std::shared_ptr<BasisOverlap>& ov = block_ovl[(size_t)shrink_idx - 1];
+            if (!use_guess_overlap || !ov || ov->from_ver != mS.parent_ver || ov->to_ver != block_ver[(size_t)shrink_idx - 1] || !HasVectors(*S)) return 0;
+            RotMeta mC;
+            std::vector<std::vector<EnlPart>> parts_now;
+            Block& shrink_now = grow_left ? EnvBlock : SysBlock;
+            PetscErrorCode ierr0 = EnlargedParts(shrink_now, parts_now); CHKERRQ(ierr0);
+            ierr0 = DescribeEnlarged(shrink_now, parts_now, mC); CHKERRQ(ierr0);
+            S = ProjectRotation(*S, mS, *ov, mC);
+            projected = true;
+        }
         Block& Lnew = KronBlocks.LeftBlockRefMod();
         Block& Rnew = KronBlocks.RightBlockRefMod();
         /* new enlarged sectors: growing side = (new block (x) site), shrinking side must equal S's source basis */
@@ -689,7 +883,7 @@ public:
             };
             std::vector<int32_t> ia, ij;
             for (int32_t a = 0; a < nG; ++a) if (G->kept[(size_t)a] > 0 && G->rt[(size_t)a]) { add(G->rt[(size_t)a], G->kept[(size_t)a], G->old_sizes[(size_t)G->old_sector[(size_t)a]]); ia.push_back(a); }
-            for (int32_t j = 0; j < nS; ++j) if (S->kept[(size_t)j] > 0 && S->rt[(size_t)j]) { add(S->rt[(size_t)j], S->kept[(size_t)j], S->old_sizes[(size_t)S->old_sector[(size_t)j]]); ij.push_back(j); }
+            for (int32_t j = 0; j < nS; ++j) if (S->kept[(size_t)j] > 0 && S->rt[(size_t)j] && S->old_sector[(size_t)j] >= 0) { add(S->rt[(size_t)j], S->kept[(size_t)j], S->old_sizes[(size_t)S->old_sector[(size_t)j]]); ij.push_back(j); }
             if (tot > 0) {
                 tarena = std::make_shared<dmrgx_host::DevBuffer>((size_t)tot, dmrgx_host::DevBuffer::device_only_t{});
                 double* base = tarena->dev_uninitialised();
@@ -747,6 +941,7 @@ public:
                 const int32_t j = e.old_sector;
                 if (j >= nS || S->kept[(size_t)j] != e.size) return 0;
                 if (e.size == 0) continue;
+                if (S->old_sector[(size_t)j] < 0) continue;                     /* (projected rotation: that sector has no counterpart in the current basis) */
                 if (!S->rt[(size_t)j]) return 0;
                 const int32_t Jnew = S->old_sector[(size_t)j], nJ = S->old_sizes[(size_t)Jnew];
                 auto it = where.find({pb.a, e.site_sector});
@@ -772,6 +967,7 @@ public:
         if (dmrgx_dgemm_batch((int32_t)t1.size(), t1.data(), nullptr)) SETERRQ1(mpi_comm, 1, "wavefunction transformation: %s", dmrgx_last_error());
         if (dmrgx_dgemm_batch((int32_t)t2.size(), t2.data(), nullptr)) SETERRQ1(mpi_comm, 1, "wavefunction transformation: %s", dmrgx_last_error());
         used = true;
+        if (projected) ++guesses_projected;
         return 0;
     }
 
@@ -1525,7 +1721,16 @@ private:
         std::shared_ptr<dmrgx_host::BasisRotation> rotL, rotR;     /**< this step's truncations */
     } prev;
     std::vector<std::shared_ptr<dmrgx_host::BasisRotation>> block_rot;   /**< rotation that created sys_blocks[i] from sys_blocks[i-1] (x) site */
+    /* Which VERSION of sys_blocks[i-1] that was.  The warm-up re-derives the environment blocks in decreasing order, so a stored
+       block i is in general the child of a version of block i-1 that has been overwritten since; the overlap between the two
+       versions' bases is carried along (RecordBlockBasis) so that the stored rotation can still be read in the current basis. */
+    std::vector<RotMeta> rot_meta;
+    std::vector<int64_t> block_ver;                       /**< current version of every stored block (0: as initialised) */
+    std::vector<std::shared_ptr<BasisOverlap>> block_ovl; /**< [i]: parent version of block_rot[i+1] -> current version of block i */
+    int64_t ver_counter = 0;
+    PetscInt guesses_projected = 0;                       /**< start vectors that went through a basis overlap */
     PetscBool use_guess = PETSC_TRUE;
+    PetscBool use_guess_overlap = PETSC_TRUE;   /* -wavefunction_guess_overlap 0: no start vector where the stored chain of bases is broken (round-2 behaviour) */
     PetscInt guesses_used = 0;
     /* eigenbases of the density matrices at the previous visit of every block: warm start of the Jacobi eigensolver */
     struct WarmBasis { std::vector<int32_t> sizes; std::map<int32_t, std::shared_ptr<dmrgx_host::DevBuffer>> E; };

@@ -23,9 +23,12 @@ public:
     /** device-resident buffer whose content is produced by a kernel: no host mirror is allocated until someone asks for it */
     struct device_only_t {};
     DevBuffer(size_t n, device_only_t) : n_(n), where_(DEVICE) { alloc_dev(); }
+    /** n elements of `owner`'s device storage starting at `offset`: a device-only view that keeps the owner alive (one arena,
+        one allocation, many sector blocks) */
+    DevBuffer(const std::shared_ptr<DevBuffer>& owner, size_t offset, size_t n) : n_(n), d_(owner->dev_uninitialised() + offset), where_(DEVICE), owner_(owner) {}
     DevBuffer(const DevBuffer&) = delete;
     DevBuffer& operator=(const DevBuffer&) = delete;
-    ~DevBuffer() { if (d_) dmrgx_free(d_); }
+    ~DevBuffer() { if (d_ && !owner_) dmrgx_free(d_); }
     size_t size() const { return n_; }
     /** host pointer for reading and writing (device copy becomes stale) */
     double* host() { sync_host(); where_ = HOST; return h_.data(); }
@@ -65,6 +68,7 @@ private:
     std::vector<double> h_;
     double* d_ = nullptr;
     Where where_;
+    std::shared_ptr<DevBuffer> owner_;
 };
 
 struct MatCell {

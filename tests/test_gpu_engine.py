@@ -413,6 +413,34 @@ def test_transformed_start_vector_saves_matmults_not_accuracy(tmp_path):
     assert run_g["LastSweepMatMults"] * 2 < run_r["LastSweepMatMults"], (run_g["LastSweepMatMults"], run_r["LastSweepMatMults"])
 
 
+def test_start_vectors_of_the_first_sweep_go_through_basis_overlaps(tmp_path):
+    """The warm-up re-derives the environment blocks in decreasing order (the reference's order), so in the first sweep a stored
+    block is usually the child of a version of its predecessor that has been overwritten since, and the stored rotation cannot
+    carry the wavefunction into the current basis.  The engine carries the overlap of the two versions' bases along and projects the
+    previous ground state through it (round 2 fell back to a random start vector there): same energies and truncation errors step by
+    step, and the first sweep needs markedly fewer MatMults; the second sweep (consistent chain of bases) is untouched."""
+    model = ["-Lx", 12, "-Ly", 4, "-J1", 1, "-Jz1", 1, "-J2", 0.5, "-Jz2", 0.5, "-mwarmup", 128, "-nsweeps", 2, "-H_eps_tol", 1e-12, "-H_eps_type", "gd"]
+    rows_0, run_0, t_0 = run_engine(tmp_path / "off", *model, "-wavefunction_guess_overlap", 0)
+    rows_1, run_1, t_1 = run_engine(tmp_path / "on", *model)
+    assert len(rows_0) == len(rows_1)
+    # (two converged runs that differ in their start vectors: equal up to what near-ties at a truncation cut amplify -- the oracle
+    #  tests use sectors with gapped cuts for 1e-10; this lattice at m = 128 has cuts with gaps of 1e-9)
+    for r, g in zip(rows_0, rows_1):
+        assert abs(r["GSEnergy"] - g["GSEnergy"]) <= 1e-8 * abs(r["GSEnergy"]), r["GlobIdx"]
+        assert abs(r["TruncErr_Sys"] - g["TruncErr_Sys"]) <= 1e-3 * abs(r["TruncErr_Sys"]) + 1e-12, r["GlobIdx"]
+    assert abs(run_0["GSEnergy"] - run_1["GSEnergy"]) <= 1e-9 * abs(run_0["GSEnergy"])
+    assert run_0["StartVectorsThroughOverlap"] == 0 and run_1["StartVectorsThroughOverlap"] >= 5
+    col = t_0["headers"].index("MatMults")
+    def per_loop(rows, t):
+        out = {}
+        for r, tr in zip(rows, t["table"]):
+            out[r["LoopIdx"]] = out.get(r["LoopIdx"], 0) + tr[col]
+        return out
+    m0, m1 = per_loop(rows_0, t_0), per_loop(rows_1, t_1)
+    assert m1[1] < 0.8 * m0[1], (m0, m1)
+    assert abs(m1[2] - m0[2]) <= 0.05 * m0[2], (m0, m1)
+
+
 @pytest.mark.parametrize("flag,kw", [("-BCopen", dict(BCopen=True)), ("-BCperiodic", dict(BCperiodic=True))])
 def test_boundary_condition_options_match_exact_diagonalisation(tmp_path, flag, kw):
     """-BCopen / -BCperiodic (src/Hamiltonians.cpp:28-45; the default is the cylinder): 4x2 J1-J2 lattice with all four
