@@ -606,6 +606,96 @@ __global__ void __launch_bounds__(DC_LEAF_THREADS) dc_leaf_kernel(const DcMat* _
     for (int e = tid; e < p * p; e += DC_LEAF_THREADS) { const int i = e / p, c = e % p; Q[(int64_t)(lf.lo + i) * ldq + lf.lo + rnk[c]] = R[i][c]; }
 }
 
+// Leaf, second form (round 3, behind DMRGX_LEAF=ql): implicit-shift QL iteration on the tridiagonal leaf itself, ONE WAVE per leaf and no
+// barrier.  The rotation recurrence (a chain of ~900 dependent plane rotations for a leaf of 32) is computed redundantly by every
+// lane -- uniform values, uniform branches -- and lane k applies each rotation to row k of the eigenvector array in LDS, holding
+// the column it will touch again in a register (one LDS read and one write per rotation and lane).  The Jacobi leaf above spends
+// its time in ~600 workgroup barriers; this one in the latency of the rotation recurrence -- measured the same 250 us.
+__global__ void __launch_bounds__(64) dc_leaf_ql_kernel(const DcMat* __restrict__ mats, const DcLeaf* __restrict__ leaves)
+{
+    constexpr int P = DC_LEAF;
+    __shared__ double Z[P][P + 1];
+    __shared__ double D[P + 1], E[P + 1];
+    const DcLeaf lf = leaves[blockIdx.x];
+    const DcMat m = mats[lf.mat];
+    const int p = lf.hi - lf.lo, k = threadIdx.x;
+    const double inv = 1.0 / m.scale[0];
+    if (k < P) {
+        for (int c = 0; c < P; ++c) Z[k][c] = k == c ? 1.0 : 0.0;
+        double dv = 0.0, ev = 0.0;
+        if (k < p) {
+            dv = m.d[lf.lo + k] * inv;
+            if (k == 0 && lf.lo > 0) dv -= fabs(m.e[lf.lo - 1] * inv);
+            if (k == p - 1 && lf.hi < m.n) dv -= fabs(m.e[lf.hi - 1] * inv);
+            if (k + 1 < p) ev = m.e[lf.lo + k] * inv;
+        }
+        D[k] = dv; E[k] = ev;
+    }
+    if (k == 0) { D[P] = 0.0; E[P] = 0.0; }
+    __syncthreads();                                   // (one wave: orders the initialisation, costs nothing)
+    const bool mine = k < p;
+    bool failed = false;
+    for (int l = 0; l < p; ++l) {
+        for (int iter = 0;; ++iter) {
+            int mm = l;
+            for (; mm < p - 1; ++mm) { const double dd = fabs(D[mm]) + fabs(D[mm + 1]); if (fabs(E[mm]) <= 1.1102230246251565e-16 * dd) break; }
+            if (mm == l) break;
+            if (iter >= 80) { failed = true; break; }
+            double g = (D[l + 1] - D[l]) / (2.0 * E[l]);
+            double r = sqrt(g * g + 1.0);
+            g = D[mm] - D[l] + E[l] / (g + (g >= 0.0 ? r : -r));
+            double s = 1.0, c = 1.0, pp = 0.0;
+            double zhold = mine ? Z[k][mm] : 0.0;              // column i + 1 of this lane's row, carried from rotation to rotation
+            double dhold = D[mm];                              // D[i + 1], likewise (nobody else touches it between two rotations)
+            bool underflow = false;
+            // operands of rotation i are loaded one rotation ahead: the dependent chain is arithmetic only
+            double ei = E[mm - 1], di = D[mm - 1], zi = mine ? Z[k][mm - 1] : 0.0;
+            for (int i = mm - 1; i >= l; --i) {
+                const int in = i > l ? i - 1 : i;
+                const double en = E[in], dn = D[in], zn = mine ? Z[k][in] : 0.0;
+                const double f = s * ei, b = c * ei;
+                const double rr = f * f + g * g;
+                if (rr == 0.0) { E[i + 1] = 0.0; D[i + 1] = dhold - pp; E[mm] = 0.0; underflow = true; if (mine) Z[k][i + 1] = zhold; break; }
+                double rinv = __builtin_amdgcn_rsq(rr);            // 1 / sqrt(rr), refined to full precision (two Newton steps)
+                rinv = rinv * (1.5 - 0.5 * rr * rinv * rinv);
+                rinv = rinv * (1.5 - 0.5 * rr * rinv * rinv);
+                E[i + 1] = rr * rinv;
+                s = f * rinv; c = g * rinv;
+                g = dhold - pp;
+                r = (di - g) * s + 2.0 * c * b;
+                pp = s * r;
+                D[i + 1] = g + pp;
+                g = c * r - b;
+                if (mine) Z[k][i + 1] = s * zi + c * zhold;
+                zhold = c * zi - s * zhold;
+                dhold = di;
+                ei = en; di = dn; zi = zn;
+            }
+            if (underflow) continue;
+            if (mine) Z[k][l] = zhold;
+            D[l] = dhold - pp; E[l] = g; E[mm] = 0.0;
+        }
+        if (failed) break;
+    }
+    // (80 iterations on one eigenvalue do not happen -- LAPACK allows 30 n in total; if they ever do, the spectrum is poisoned so that
+    //  the caller's truncation fails visibly instead of using half-converged vectors)
+    if (failed && k < p) D[k] = __longlong_as_double(0x7ff8000000000000ll);
+    __syncthreads();
+    // ascending order
+    int rk = 0;
+    if (mine) {
+        const double v = D[k];
+        for (int q = 0; q < p; ++q) { const double u = D[q]; rk += (u < v) || (u == v && q < k); }
+        m.dcur[lf.lo + rk] = v;
+    }
+    __shared__ int rnk[P];
+    if (mine) rnk[k] = rk;
+    __syncthreads();
+    double* Q = m.Q[lf.buf];
+    const int ldq = m.ldq[lf.buf];
+    for (int e = k; e < p * p; e += 64) { const int i = e / p, c = e % p; Q[(int64_t)(lf.lo + i) * ldq + lf.lo + rnk[c]] = Z[i][c]; }
+}
+
 // Deflation of one merge (LAPACK dlaed2 in this solver's data flow): z from the children's boundary rows, poles ranked by brute-
 // force counting (no sortedness assumed), type-1 (rho |z_i| tiny) and type-2 (two close poles: one Givens rotation moves the
 // weight to one of them) deflation in one sequential scan by thread 0 -- the only serial part of the solver.
@@ -1359,7 +1449,12 @@ dmrgx_status symeig_batched(const std::vector<SymEigMat>& mats_in, hipStream_t s
     // ---- 2: launches -------------------------------------------------------------------------------------------------------------
     const DcMat* ddm = d_dm.as<DcMat>();
     hipLaunchKernelGGL(dc_scale_kernel, dim3((unsigned)nm), dim3(256), 0, st, ddm);
-    hipLaunchKernelGGL(dc_leaf_kernel, dim3((unsigned)leaves.size()), dim3(DC_LEAF_THREADS), 0, st, ddm, d_leaves.as<DcLeaf>());
+    // (A/B: DMRGX_LEAF=ql runs the one-wave QL leaf instead.  Measured equal: 250 us per call at m = 512 for both, 8.85 ms per
+    //  truncation at m = 2048 for both -- the QL chain is ~25 dependent f64 operations per rotation for ~900 rotations plus a serial scan
+    //  for the split point per iteration; Jacobi stays the default because it has no failure mode.)
+    static const bool leaf_jacobi = !(getenv("DMRGX_LEAF") && std::string(getenv("DMRGX_LEAF")) == "ql");
+    if (leaf_jacobi) hipLaunchKernelGGL(dc_leaf_kernel, dim3((unsigned)leaves.size()), dim3(DC_LEAF_THREADS), 0, st, ddm, d_leaves.as<DcLeaf>());
+    else hipLaunchKernelGGL(dc_leaf_ql_kernel, dim3((unsigned)leaves.size()), dim3(64), 0, st, ddm, d_leaves.as<DcLeaf>());
     DMRGX_HIP(hipGetLastError());
     for (const Step& s : steps) {
         if (s.nmerge == 0) continue;
