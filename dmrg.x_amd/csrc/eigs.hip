@@ -172,11 +172,14 @@ axpy_normalise_kernel(const double* __restrict__ V, int64_t ldv, int nv, const d
     if (threadIdx.x <= nv) cs[threadIdx.x] = c[threadIdx.x];
     __syncthreads();
     if (blockIdx.x == 0 && threadIdx.x < nv && hacc) hacc[threadIdx.x] += cs[threadIdx.x];
-    double s2 = cs[nv];
-    for (int i = 0; i < nv; ++i) s2 -= cs[i] * cs[i];          // same order in every thread: one value for the whole grid
+    double s2 = cs[nv], sc = 0.0;
+    for (int i = 0; i < nv; ++i) { s2 -= cs[i] * cs[i]; sc += cs[i] * cs[i]; }          // same order in every thread: one value for the whole grid
     s2 = s2 > 0.0 ? s2 : 0.0;
     if (blockIdx.x == 0 && threadIdx.x == 0 && beta2_out) *beta2_out = s2;
     const double inv = s2 > 1e-290 ? 1.0 / sqrt(s2) : 0.0;
+    // The second Gram-Schmidt pass is a correction of relative size |c| / |w|: when the first pass already left less than 1e-12 of
+    // the vector inside the basis (the usual case: ~1e-15) the basis is not read again -- the vector is only scaled.  (Grid-uniform.)
+    if (sc <= 1e-24 * cs[nv]) nv = 0;
     if (VEC2) {
         const double2* __restrict__ w2 = reinterpret_cast<const double2*>(w);
         double2* __restrict__ d2 = reinterpret_cast<double2*>(dst);
