@@ -18,6 +18,7 @@
 //
 // tools/proto_trid_dc.py is the numpy statement of exactly this data flow.
 #include "symeig.h"
+#include <chrono>
 #include "ggemm.h"
 #include <cfloat>
 #include <cmath>
@@ -1106,6 +1107,11 @@ dmrgx_status symeig_batched(const std::vector<SymEigMat>& mats_in, hipStream_t s
     }
     const int nm = (int)M.size();
     if (nm == 0) return DMRGX_OK;
+    // developer aid (DMRGX_SYMEIG_TRACE): host clock at the milestones of the call, no synchronisation -- where the HOST spends its time
+    static const bool host_trace = getenv("DMRGX_SYMEIG_TRACE") != nullptr;
+    const auto ht0 = std::chrono::steady_clock::now();
+    std::vector<std::pair<const char*, double>> hmarks;
+    auto hmark = [&](const char* what) { if (host_trace) hmarks.push_back({what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - ht0).count()}); };
     int nmax = 0;
     for (const SymEigMat& s : M) nmax = std::max(nmax, s.n);
 
@@ -1137,6 +1143,7 @@ dmrgx_status symeig_batched(const std::vector<SymEigMat>& mats_in, hipStream_t s
     DMRGX_CHK(ibuf.alloc((size_t)itot * sizeof(int32_t)));
     double* B = dbuf.as<double>();
     int32_t* I = ibuf.as<int32_t>();
+    hmark("workspace");
 
     // ---- 1. tridiagonalisation -------------------------------------------------------------------------------------------
     // Matrices whose rows fit the LDS of at most all CUs go through the persistent kernel (in rounds of <= #CUs workgroups and
@@ -1208,7 +1215,9 @@ dmrgx_status symeig_batched(const std::vector<SymEigMat>& mats_in, hipStream_t s
             DMRGX_CHK(gran.alloc((size_t)gtot * sizeof(u64)));
             DMRGX_HIP(hipMemsetAsync(gran.p, 0, (size_t)gtot * sizeof(u64), st));     // epochs start at 1: a zeroed granule is "not yet"
             u64* GB = gran.as<u64>();
+            hmark("granules");
             DMRGX_HIP(hipFuncSetAttribute((const void*)trid_coop_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_max));
+            hmark("func attribute");
             for (const Round& r : rounds) {
                 TcArgs ta;
                 ta.status = reinterpret_cast<int32_t*>(GB); ta.nm = (int32_t)r.mats.size(); ta.pad = 0;
@@ -1230,6 +1239,7 @@ dmrgx_status symeig_batched(const std::vector<SymEigMat>& mats_in, hipStream_t s
         }
     } else for (int q = 0; q < nm; ++q) launch_set.push_back(q);
     if (!launch_set.empty()) DMRGX_CHK(trid_by_launches(launch_set));
+    hmark("trid launched");
 
     // ---- 3a. (independent of the eigenvectors) V = (V^T)^T, the Gram blocks, T factors and T V^T ---------------------------------
     std::vector<GProd> prods;
@@ -1352,6 +1362,7 @@ dmrgx_status symeig_batched(const std::vector<SymEigMat>& mats_in, hipStream_t s
         bt_x[(size_t)s] = add_set(xb, xs);
     }
 
+    hmark("tables built");
     // ---- uploads ---------------------------------------------------------------------------------------------------------------
     if (prods.empty()) prods.push_back(GProd{nullptr, nullptr, 0, 0, 0, GPROD_GEMM, 0.0});
     if (groups.empty()) groups.push_back(GGroup{nullptr, 0, 0, 0, 0, 0, 0, 0});
@@ -1362,6 +1373,7 @@ dmrgx_status symeig_batched(const std::vector<SymEigMat>& mats_in, hipStream_t s
     DMRGX_CHK(upload(d_prods, prods, st)); DMRGX_CHK(upload(d_groups, groups, st)); DMRGX_CHK(upload(d_tiles, tiles, st));
     DMRGX_CHK(upload(d_tp, tp, st)); DMRGX_CHK(upload(d_wyb, wyb, st)); DMRGX_CHK(upload(d_dm, dm, st));
     DMRGX_CHK(upload(d_leaves, leaves, st)); DMRGX_CHK(upload(d_merges, merges, st));
+    hmark("tables uploaded");
     // ---- the persistent rounds have had the host's table building and the table uploads to run in: did every workgroup get its partners? ---------------
     if (coop_ran && getenv("DMRGX_TRID_PROF")) {
         long long pr[4];
@@ -1371,6 +1383,7 @@ dmrgx_status symeig_batched(const std::vector<SymEigMat>& mats_in, hipStream_t s
     if (coop_ran) {
         DMRGX_HIP(hipMemcpyAsync(&coop_status, gran.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));      // (a pageable copy: it may block, so it is issued here)
         DMRGX_HIP(hipStreamSynchronize(st));
+        hmark("trid done (sync)");
         if (coop_status != 0) {
             if (!g_coop_disabled) fprintf(stderr, "[dmrgx] persistent tridiagonalisation timed out waiting for a partner workgroup (GPU shared with another "
                                                   "persistent kernel?): using one launch per column from now on\n");
@@ -1480,6 +1493,12 @@ dmrgx_status symeig_batched(const std::vector<SymEigMat>& mats_in, hipStream_t s
 
     // ---- 3b: launches ------------------------------------------------------------------------------------------------------------
     for (int s = 0; s < max_nblk; ++s) { DMRGX_CHK(run_set(bt_w[(size_t)s])); DMRGX_CHK(run_set(bt_x[(size_t)s])); }
+    hmark("all queued");
+    if (host_trace) {
+        fprintf(stderr, "[symeig host] %d matrices, nmax %d:", nm, nmax);
+        for (const auto& hm : hmarks) fprintf(stderr, "  %s %.0f us", hm.first, hm.second);
+        fprintf(stderr, "\n");
+    }
     return DMRGX_OK;
 }
 

@@ -16,7 +16,7 @@ rows.sort()
 idx=[i for i,r in enumerate(rows) if "trid_coop" in r[2] or "trid_step" in r[2]]
 firsts=[i for k,i in enumerate(idx) if k==0 or idx[k-1]!=i-1]
 i0=firsts[int(sys.argv[2])]
-lo=max(0,i0-25); hi=min(len(rows),i0+150)
+lo=max(0,i0-25); hi=min(len(rows),i0+int(__import__("os").environ.get("TL_SPAN","150")))
 t0=rows[lo][0]
 prev=rows[lo][0]
 for s,e,n in rows[lo:hi]:
