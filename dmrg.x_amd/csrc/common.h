@@ -1,5 +1,6 @@
 // Internal helpers shared by the HIP translation units of libdmrgx_hip.so (not part of the ABI).
 #pragma once
+#include <cstring>
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdarg>
@@ -80,8 +81,11 @@ struct DevBuf {
         bytes = n;
         return DMRGX_OK;
     }
-    void release() { if (p) { (void)pool_free(p); p = nullptr; bytes = 0; } }
+    void release() { if (p && owned) (void)pool_free(p); p = nullptr; bytes = 0; owned = true; }
+    // n bytes at `ptr` inside another buffer (a table of a PackedUpload): same accessors, nothing to free; the arena must outlive it
+    void view(void* ptr, size_t n) { release(); p = n ? ptr : nullptr; bytes = n; owned = false; }
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+    bool owned = true;
 };
 
 template <class T>
@@ -90,5 +94,25 @@ dmrgx_status upload(DevBuf& buf, const std::vector<T>& host, hipStream_t st) {
     if (!host.empty()) DMRGX_HIP(h2d_async(buf.p, host.data(), host.size() * sizeof(T), st));
     return DMRGX_OK;
 }
+
+// Several task tables in ONE host -> device copy: every copy is a stream operation of its own (~4 us of blit kernel behind a ~6 us
+// gap at small m, where a step used to issue ~60 of them); the tables of one call go out together and are addressed by offset.
+struct PackedUpload {
+    std::vector<char> host;
+    template <class T> size_t add(const std::vector<T>& v) {
+        const size_t off = (host.size() + 15) & ~(size_t)15;
+        host.resize(off + v.size() * sizeof(T));
+        if (!v.empty()) memcpy(host.data() + off, v.data(), v.size() * sizeof(T));
+        return off;
+    }
+    dmrgx_status upload(DevBuf& buf, hipStream_t st) {
+        DMRGX_CHK(buf.alloc(std::max<size_t>(host.size(), 16)));
+        if (!host.empty()) DMRGX_HIP(h2d_async(buf.p, host.data(), host.size(), st));
+        return DMRGX_OK;
+    }
+    // `dst` becomes a view of the table added at `off` (n elements of T) inside the uploaded arena
+    template <class T> static void view(DevBuf& dst, const DevBuf& arena, size_t off, size_t n) { dst.view(static_cast<char*>(arena.p) + off, n * sizeof(T)); }
+};
+template <class T> inline T* packed_at(const DevBuf& buf, size_t off) { return reinterpret_cast<T*>(static_cast<char*>(buf.p) + off); }
 
 }  // namespace dmrgx

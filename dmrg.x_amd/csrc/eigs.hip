@@ -177,9 +177,10 @@ axpy_normalise_kernel(const double* __restrict__ V, int64_t ldv, int nv, const d
     s2 = s2 > 0.0 ? s2 : 0.0;
     if (blockIdx.x == 0 && threadIdx.x == 0 && beta2_out) *beta2_out = s2;
     const double inv = s2 > 1e-290 ? 1.0 / sqrt(s2) : 0.0;
-    // The second Gram-Schmidt pass is a correction of relative size |c| / |w|: when the first pass already left less than 1e-12 of
-    // the vector inside the basis (the usual case: ~1e-15) the basis is not read again -- the vector is only scaled.  (Grid-uniform.)
-    if (sc <= 1e-24 * cs[nv]) nv = 0;
+    // The second Gram-Schmidt pass is a correction of relative size |c| / |w|: when the first pass already left less than 3e-14 of
+    // the vector inside the basis (the usual case: ~1e-15) the basis is not read again -- the vector is only scaled.  (Grid-uniform.
+    // 1e-12 was too loose: the step-by-step correlator parity of the 4x4 case, asked at 1e-12 absolute, moved by 1.2e-12.)
+    if (sc <= 1e-27 * cs[nv]) nv = 0;
     if (VEC2) {
         const double2* __restrict__ w2 = reinterpret_cast<const double2*>(w);
         double2* __restrict__ d2 = reinterpret_cast<double2*>(dst);

@@ -197,6 +197,7 @@ struct dmrgx_kron_plan {
     int32_t world = 1, rank = 0;
     dmrgx_kron_info info{};
     DevBuf arena;                       // operators + intermediates
+    DevBuf d_tables;                    // one upload holds every table below (the DevBufs are views into it); declared first: destroyed last
     DevBuf d_rprods, d_rgroups;         // relative tables (stage 1 then stage 2, one array)
     // Patched (absolute-pointer) task tables, one set per (x, y) pair seen: a Lanczos solve applies the plan to the same
     // ncv+1 basis vectors cycle after cycle, so after the first cycle no apply has to re-patch (one launch less per step).
@@ -710,17 +711,21 @@ extern "C" dmrgx_status dmrgx_kron_plan_create(const dmrgx_kron_desc* d, void* s
     {   // operator copies, one launch per accumulation round
         int32_t max_round = -1;
         for (auto& c : copies) max_round = std::max(max_round, c.round);
-        DevBuf d_tasks;
-        DMRGX_CHK(upload(d_tasks, copies, st));
+        DevBuf d_tab;                                   // the copy tasks and the tile lists of all rounds in one upload
+        PackedUpload pk;
+        const size_t o_tasks = pk.add(copies);
+        std::vector<std::pair<size_t, size_t>> lists;
         for (int32_t r = 0; r <= max_round; ++r) {
             std::vector<CopyTile> ct;
             for (size_t i = 0; i < copies.size(); ++i) if (copies[i].round == r)
                 for (int32_t ti = 0; ti < (copies[i].nr + 31) / 32; ++ti)
                     for (int32_t tj = 0; tj < (copies[i].nc + 31) / 32; ++tj) ct.push_back(CopyTile{(int32_t)i, ti, tj, 0});
             if (ct.empty()) continue;
-            DevBuf d_ct;
-            DMRGX_CHK(upload(d_ct, ct, st));
-            hipLaunchKernelGGL(cell_copy_kernel, dim3((unsigned)ct.size()), dim3(256), 0, st, d_ct.as<CopyTile>(), d_tasks.as<CopyTask>(), P->arena.as<double>());
+            lists.push_back({pk.add(ct), ct.size()});
+        }
+        DMRGX_CHK(pk.upload(d_tab, st));
+        for (const auto& l : lists) {
+            hipLaunchKernelGGL(cell_copy_kernel, dim3((unsigned)l.second), dim3(256), 0, st, (const CopyTile*)packed_at<CopyTile>(d_tab, l.first), (const CopyTask*)packed_at<CopyTask>(d_tab, o_tasks), P->arena.as<double>());
             DMRGX_HIP(hipGetLastError());
         }
     }
@@ -729,24 +734,28 @@ extern "C" dmrgx_status dmrgx_kron_plan_create(const dmrgx_kron_desc* d, void* s
     P->ntiles1b = (int32_t)B.tiles1b.size(); P->ntiles2b = (int32_t)B.tiles2b.size();
     P->ntiles1t = (int32_t)B.tiles1t.size(); P->ntiles2t = (int32_t)B.tiles2t.size();
     { const char* tm = getenv("DMRGX_TILES"); P->overlap = tm && std::string(tm) == "overlap"; }
-    DMRGX_CHK(upload(P->d_rprods, B.prods, st));
-    DMRGX_CHK(upload(P->d_rgroups, B.groups, st));
-    DMRGX_CHK(upload(P->d_tiles1, B.tiles1, st));
-    DMRGX_CHK(upload(P->d_tiles2, B.tiles2, st));
-    DMRGX_CHK(upload(P->d_tiles1b, B.tiles1b, st));
-    DMRGX_CHK(upload(P->d_tiles2b, B.tiles2b, st));
-    DMRGX_CHK(upload(P->d_tiles1t, B.tiles1t, st));
-    DMRGX_CHK(upload(P->d_tiles2t, B.tiles2t, st));
-    DMRGX_CHK(upload(P->d_red_tasks, B.red_tasks, st));
-    DMRGX_CHK(upload(P->d_red_tiles, B.red_tiles, st));
-    {   // layout conversion table (reference order <-> rank-major stripes)
-        std::vector<LayoutSeg> segs;
+    {   // every table of the plan in one copy; the members are views into P->d_tables
+        std::vector<LayoutSeg> segs;                       // layout conversion table (reference order <-> rank-major stripes)
         for (int32_t k = 0; k < nb; ++k) for (int32_t w = 0; w < W; ++w) {
             if (panel_ld(k, w) <= 0) continue;
             segs.push_back(LayoutSeg{ref_off[k] + cbeg(k, w), panel_off(k, w), nLk(k), panel_ld(k, w), nRk(k), panel_ld(k, w)});
         }
         P->nlayout = (int32_t)segs.size();
-        DMRGX_CHK(upload(P->d_layout, segs, st));
+        PackedUpload pk;
+        const size_t o0 = pk.add(B.prods), o1 = pk.add(B.groups), o2 = pk.add(B.tiles1), o3 = pk.add(B.tiles2), o4 = pk.add(B.tiles1b), o5 = pk.add(B.tiles2b),
+                     o6 = pk.add(B.tiles1t), o7 = pk.add(B.tiles2t), o8 = pk.add(B.red_tasks), o9 = pk.add(B.red_tiles), o10 = pk.add(segs);
+        DMRGX_CHK(pk.upload(P->d_tables, st));
+        PackedUpload::view<std::decay<decltype(B.prods[0])>::type>(P->d_rprods, P->d_tables, o0, B.prods.size());
+        PackedUpload::view<std::decay<decltype(B.groups[0])>::type>(P->d_rgroups, P->d_tables, o1, B.groups.size());
+        PackedUpload::view<GTile>(P->d_tiles1, P->d_tables, o2, B.tiles1.size());
+        PackedUpload::view<GTile>(P->d_tiles2, P->d_tables, o3, B.tiles2.size());
+        PackedUpload::view<GTile>(P->d_tiles1b, P->d_tables, o4, B.tiles1b.size());
+        PackedUpload::view<GTile>(P->d_tiles2b, P->d_tables, o5, B.tiles2b.size());
+        PackedUpload::view<GTile>(P->d_tiles1t, P->d_tables, o6, B.tiles1t.size());
+        PackedUpload::view<GTile>(P->d_tiles2t, P->d_tables, o7, B.tiles2t.size());
+        PackedUpload::view<std::decay<decltype(B.red_tasks[0])>::type>(P->d_red_tasks, P->d_tables, o8, B.red_tasks.size());
+        PackedUpload::view<std::decay<decltype(B.red_tiles[0])>::type>(P->d_red_tiles, P->d_tables, o9, B.red_tiles.size());
+        PackedUpload::view<LayoutSeg>(P->d_layout, P->d_tables, o10, segs.size());
     }
 
     {   // diagonal terms (dmrgx_kron_diag): t = 0: H_L (x) 1, t = 1: 1 (x) H_R, then the shift-0 groups

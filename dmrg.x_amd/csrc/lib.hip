@@ -62,14 +62,13 @@ extern "C" dmrgx_status dmrgx_dgemm_nn(int32_t M, int32_t N, int32_t K, const do
     std::vector<GGroup> groups = {GGroup{C, (int32_t)ldc, M, N, 0, (int32_t)prods.size(), 0, 0}};
     std::vector<GTile> tiles, big;
     ggemm_append_tiles_mixed(big, tiles, 0, M, N);
-    DevBuf dp, dg, dt, db;
     if (prods.empty()) prods.push_back(GProd{nullptr, nullptr, 0, 0, 0, GPROD_GEMM, 0.0});
-    DMRGX_CHK(upload(dp, prods, st));
-    DMRGX_CHK(upload(dg, groups, st));
-    DMRGX_CHK(upload(dt, tiles, st));
-    DMRGX_CHK(upload(db, big, st));
-    DMRGX_CHK(ggemm_launch(db.as<GTile>(), dg.as<GGroup>(), dp.as<GProd>(), (int32_t)big.size(), st, 1));
-    DMRGX_CHK(ggemm_launch(dt.as<GTile>(), dg.as<GGroup>(), dp.as<GProd>(), (int32_t)tiles.size(), st, 0));
+    DevBuf tab;
+    PackedUpload pk;
+    const size_t op = pk.add(prods), og = pk.add(groups), ot = pk.add(tiles), ob = pk.add(big);
+    DMRGX_CHK(pk.upload(tab, st));
+    DMRGX_CHK(ggemm_launch(packed_at<GTile>(tab, ob), packed_at<GGroup>(tab, og), packed_at<GProd>(tab, op), (int32_t)big.size(), st, 1));
+    DMRGX_CHK(ggemm_launch(packed_at<GTile>(tab, ot), packed_at<GGroup>(tab, og), packed_at<GProd>(tab, op), (int32_t)tiles.size(), st, 0));
     return DMRGX_OK;
 }
 
@@ -93,13 +92,12 @@ extern "C" dmrgx_status dmrgx_dgemm_batch(int32_t count, const dmrgx_gemm_task* 
     if (groups.empty()) return DMRGX_OK;
     if (prods.empty()) prods.push_back(GProd{nullptr, nullptr, 0, 0, 0, GPROD_GEMM, 0.0});
     ggemm_schedule(tiles); ggemm_schedule(big, 2);
-    DevBuf dp, dg, dt, db;
-    DMRGX_CHK(upload(dp, prods, st));
-    DMRGX_CHK(upload(dg, groups, st));
-    DMRGX_CHK(upload(dt, tiles, st));
-    DMRGX_CHK(upload(db, big, st));
-    DMRGX_CHK(ggemm_launch(db.as<GTile>(), dg.as<GGroup>(), dp.as<GProd>(), (int32_t)big.size(), st, 1));
-    DMRGX_CHK(ggemm_launch(dt.as<GTile>(), dg.as<GGroup>(), dp.as<GProd>(), (int32_t)tiles.size(), st, 0));
+    DevBuf tab;
+    PackedUpload pk;
+    const size_t op = pk.add(prods), og = pk.add(groups), ot = pk.add(tiles), ob = pk.add(big);
+    DMRGX_CHK(pk.upload(tab, st));
+    DMRGX_CHK(ggemm_launch(packed_at<GTile>(tab, ob), packed_at<GGroup>(tab, og), packed_at<GProd>(tab, op), (int32_t)big.size(), st, 1));
+    DMRGX_CHK(ggemm_launch(packed_at<GTile>(tab, ot), packed_at<GGroup>(tab, og), packed_at<GProd>(tab, op), (int32_t)tiles.size(), st, 0));
     return DMRGX_OK;
 }
 
@@ -239,11 +237,13 @@ extern "C" dmrgx_status dmrgx_dot2d_batch(int32_t count, const dmrgx_dot2d_task*
             pieces.push_back(dmrgx::Dot2dPiece{t.a + (int64_t)r0 * t.lda, t.b + (int64_t)r0 * t.ldb, t.lda, t.ldb, std::min(rows_per, t.nr - r0), t.nc});
     }
     first.push_back((int32_t)pieces.size());
-    DevBuf dp, dpart, douts, dfirst;
+    DevBuf tab, dpart;
     DMRGX_CHK(dpart.alloc(std::max<size_t>(pieces.size(), 1) * sizeof(double)));
-    DMRGX_CHK(upload(dp, pieces, st)); DMRGX_CHK(upload(douts, outs, st)); DMRGX_CHK(upload(dfirst, first, st));
-    if (!pieces.empty()) hipLaunchKernelGGL(dmrgx::dot2d_partial_kernel, dim3((unsigned)pieces.size()), dim3(256), 0, st, dp.as<dmrgx::Dot2dPiece>(), dpart.as<double>());
-    hipLaunchKernelGGL(dmrgx::dot2d_final_kernel, dim3((unsigned)((outs.size() + 255) / 256)), dim3(256), 0, st, (const double*)dpart.as<double>(), douts.as<int32_t>(), dfirst.as<int32_t>(),
+    dmrgx::PackedUpload pk;
+    const size_t opc = pk.add(pieces), oo = pk.add(outs), of = pk.add(first);
+    DMRGX_CHK(pk.upload(tab, st));
+    if (!pieces.empty()) hipLaunchKernelGGL(dmrgx::dot2d_partial_kernel, dim3((unsigned)pieces.size()), dim3(256), 0, st, dmrgx::packed_at<dmrgx::Dot2dPiece>(tab, opc), dpart.as<double>());
+    hipLaunchKernelGGL(dmrgx::dot2d_final_kernel, dim3((unsigned)((outs.size() + 255) / 256)), dim3(256), 0, st, (const double*)dpart.as<double>(), (const int32_t*)dmrgx::packed_at<int32_t>(tab, oo), (const int32_t*)dmrgx::packed_at<int32_t>(tab, of),
                        (int)outs.size(), dev_out);
     DMRGX_HIP(hipGetLastError());
     return DMRGX_OK;

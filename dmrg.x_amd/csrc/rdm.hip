@@ -456,6 +456,7 @@ using namespace dmrgx;
 struct dmrgx_rdm {
     int32_t nblocks = 0;
     std::vector<MatDesc> mats;                 // index 2*k + side
+    DevBuf d_tables;                    // the set-up tables in one upload (d_mats is a view into it)
     DevBuf buf, d_mats, d_perm;
     std::vector<std::vector<double>> eig;      // per matrix: eigenvalues, descending
     std::vector<std::vector<int32_t>> perm;    // per matrix: column of V for the r-th largest eigenvalue
@@ -594,13 +595,51 @@ static dmrgx_status rdm_create_impl(const dmrgx_sectors* left, const dmrgx_secto
     for (int mi = 0; mi < nm; ++mi) if (warm_src[mi] || qmats[mi].n) { const int64_t nn = (int64_t)P->mats[mi].n * P->mats[mi].n; warm_w[mi] = total; total += nn; warm_et[mi] = total; total += nn; }
     DMRGX_CHK(P->buf.alloc((size_t)total * sizeof(double)));
     double* buf = P->buf.as<double>();
-    DevBuf d_pairs, d_tiles, d_doff, d_pstart;
-    DMRGX_CHK(upload(P->d_mats, P->mats, st));
-    DMRGX_CHK(upload(d_pairs, pairs, st));
-    DMRGX_CHK(upload(d_tiles, tiles, st));
-    DMRGX_CHK(upload(d_pstart, pair_start, st));
+    // ---- tables of the set-up (matrix descriptors, Jacobi pair lists, transposition tiles, the Gram GEMMs) in ONE upload ----------
+    DevBuf d_pairs, d_tiles, d_doff, d_pstart;          // views into P->d_tables
     for (auto& v : diag_off) v += diag_base;
-    DMRGX_CHK(upload(d_doff, diag_off, st));
+    std::vector<TrTile> tt;
+    for (int32_t k = 0; k < nblocks; ++k) {
+        const int32_t nl = left->size[block_il[k]], nr = right->size[block_ir[k]];
+        if (!P->selected[2 * k] && !P->selected[2 * k + 1]) continue;
+        for (int ti = 0; ti < (nl + 31) / 32; ++ti) for (int tj = 0; tj < (nr + 31) / 32; ++tj)
+            tt.push_back(TrTile{off[k], psiT_off + off[k], nl, nr, ti, tj});
+    }
+    std::vector<GProd> gprods;
+    std::vector<GGroup> ggroups;
+    std::vector<GTile> gt, gb;
+    for (int32_t k = 0; k < nblocks; ++k) {
+        const int32_t nl = left->size[block_il[k]], nr = right->size[block_ir[k]];
+        const double* Psi = psi_dev + off[k];
+        const double* PsiT = buf + psiT_off + off[k];
+        const MatDesc& mL = P->mats[2 * k];
+        const MatDesc& mR = P->mats[2 * k + 1];
+        if (P->selected[2 * k]) {
+            gprods.push_back(GProd{Psi, PsiT, nr, nl, nr, GPROD_GEMM, 1.0});       // rho_L = Psi Psi^T  (:1733)
+            ggroups.push_back(GGroup{buf + mL.a_off, mL.npad, nl, nl, (int32_t)gprods.size() - 1, (int32_t)gprods.size(), 0, 0});
+            ggemm_append_tiles_mixed(gb, gt, (int32_t)ggroups.size() - 1, nl, nl, (nr + GG_BK - 1) / GG_BK);
+        }
+        if (P->selected[2 * k + 1]) {
+            gprods.push_back(GProd{PsiT, Psi, nl, nr, nl, GPROD_GEMM, 1.0});       // rho_R = Psi^T Psi  (:1734)
+            ggroups.push_back(GGroup{buf + mR.a_off, mR.npad, nr, nr, (int32_t)gprods.size() - 1, (int32_t)gprods.size(), 0, 0});
+            ggemm_append_tiles_mixed(gb, gt, (int32_t)ggroups.size() - 1, nr, nr, (nl + GG_BK - 1) / GG_BK);
+        }
+    }
+    if (gprods.empty()) gprods.push_back(GProd{nullptr, nullptr, 0, 0, 0, GPROD_GEMM, 0.0});
+    if (ggroups.empty()) ggroups.push_back(GGroup{nullptr, 0, 0, 0, 0, 0, 0, 0});
+    ggemm_schedule(gt); ggemm_schedule(gb, 2);
+    size_t o_tt = 0, o_gp = 0, o_gg = 0, o_gt = 0, o_gb = 0;
+    {
+        PackedUpload pk;
+        const size_t o_m = pk.add(P->mats), o_p = pk.add(pairs), o_t = pk.add(tiles), o_ps = pk.add(pair_start), o_d = pk.add(diag_off);
+        o_tt = pk.add(tt); o_gp = pk.add(gprods); o_gg = pk.add(ggroups); o_gt = pk.add(gt); o_gb = pk.add(gb);
+        DMRGX_CHK(pk.upload(P->d_tables, st));
+        PackedUpload::view<MatDesc>(P->d_mats, P->d_tables, o_m, P->mats.size());
+        PackedUpload::view<std::decay<decltype(pairs[0])>::type>(d_pairs, P->d_tables, o_p, pairs.size());
+        PackedUpload::view<std::decay<decltype(tiles[0])>::type>(d_tiles, P->d_tables, o_t, tiles.size());
+        PackedUpload::view<std::decay<decltype(pair_start[0])>::type>(d_pstart, P->d_tables, o_ps, pair_start.size());
+        PackedUpload::view<int64_t>(d_doff, P->d_tables, o_d, diag_off.size());
+    }
     const MatDesc* dm = P->d_mats.as<MatDesc>();
     hipLaunchKernelGGL(rdm_init_kernel, dim3(64, nm), dim3(256), 0, st, dm, buf);
     DMRGX_HIP(hipGetLastError());
@@ -608,45 +647,11 @@ static dmrgx_status rdm_create_impl(const dmrgx_sectors* left, const dmrgx_secto
     stage("layout");
     // ---- Psi^T and the 2*nblocks Gram matrices in one grouped GEMM launch -------------------------------------
     {
-        std::vector<TrTile> tt;
-        for (int32_t k = 0; k < nblocks; ++k) {
-            const int32_t nl = left->size[block_il[k]], nr = right->size[block_ir[k]];
-            if (!P->selected[2 * k] && !P->selected[2 * k + 1]) continue;
-            for (int ti = 0; ti < (nl + 31) / 32; ++ti) for (int tj = 0; tj < (nr + 31) / 32; ++tj)
-                tt.push_back(TrTile{off[k], psiT_off + off[k], nl, nr, ti, tj});
-        }
-        DevBuf d_tt;
-        DMRGX_CHK(upload(d_tt, tt, st));
         // transpose reads psi (caller memory) and writes the arena: pass distinct base pointers
-        if (!tt.empty()) hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)tt.size()), dim3(256), 0, st, d_tt.as<TrTile>(), psi_dev, buf);
+        if (!tt.empty()) hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)tt.size()), dim3(256), 0, st, (const TrTile*)packed_at<TrTile>(P->d_tables, o_tt), psi_dev, buf);
         DMRGX_HIP(hipGetLastError());
-        std::vector<GProd> prods;
-        std::vector<GGroup> groups;
-        std::vector<GTile> gt, gb;
-        for (int32_t k = 0; k < nblocks; ++k) {
-            const int32_t nl = left->size[block_il[k]], nr = right->size[block_ir[k]];
-            const double* Psi = psi_dev + off[k];
-            const double* PsiT = buf + psiT_off + off[k];
-            const MatDesc& mL = P->mats[2 * k];
-            const MatDesc& mR = P->mats[2 * k + 1];
-            if (P->selected[2 * k]) {
-                prods.push_back(GProd{Psi, PsiT, nr, nl, nr, GPROD_GEMM, 1.0});       // rho_L = Psi Psi^T  (:1733)
-                groups.push_back(GGroup{buf + mL.a_off, mL.npad, nl, nl, (int32_t)prods.size() - 1, (int32_t)prods.size(), 0, 0});
-                ggemm_append_tiles_mixed(gb, gt, (int32_t)groups.size() - 1, nl, nl, (nr + GG_BK - 1) / GG_BK);
-            }
-            if (P->selected[2 * k + 1]) {
-                prods.push_back(GProd{PsiT, Psi, nl, nr, nl, GPROD_GEMM, 1.0});       // rho_R = Psi^T Psi  (:1734)
-                groups.push_back(GGroup{buf + mR.a_off, mR.npad, nr, nr, (int32_t)prods.size() - 1, (int32_t)prods.size(), 0, 0});
-                ggemm_append_tiles_mixed(gb, gt, (int32_t)groups.size() - 1, nr, nr, (nl + GG_BK - 1) / GG_BK);
-            }
-        }
-        if (prods.empty()) prods.push_back(GProd{nullptr, nullptr, 0, 0, 0, GPROD_GEMM, 0.0});
-        if (groups.empty()) groups.push_back(GGroup{nullptr, 0, 0, 0, 0, 0, 0, 0});
-        ggemm_schedule(gt); ggemm_schedule(gb, 2);
-        DevBuf dp, dg, dt, db;
-        DMRGX_CHK(upload(dp, prods, st)); DMRGX_CHK(upload(dg, groups, st)); DMRGX_CHK(upload(dt, gt, st)); DMRGX_CHK(upload(db, gb, st));
-        DMRGX_CHK(ggemm_launch(db.as<GTile>(), dg.as<GGroup>(), dp.as<GProd>(), (int32_t)gb.size(), st, 1));
-        DMRGX_CHK(ggemm_launch(dt.as<GTile>(), dg.as<GGroup>(), dp.as<GProd>(), (int32_t)gt.size(), st, 0));
+        DMRGX_CHK(ggemm_launch(packed_at<GTile>(P->d_tables, o_gb), packed_at<GGroup>(P->d_tables, o_gg), packed_at<GProd>(P->d_tables, o_gp), (int32_t)gb.size(), st, 1));
+        DMRGX_CHK(ggemm_launch(packed_at<GTile>(P->d_tables, o_gt), packed_at<GGroup>(P->d_tables, o_gg), packed_at<GProd>(P->d_tables, o_gp), (int32_t)gt.size(), st, 0));
     }
 
     if (const char* dump = getenv("DMRGX_RDM_DUMP")) {      // developer aid: the density matrices of one call, for offline convergence studies
@@ -849,15 +854,16 @@ static dmrgx_status rdm_create_impl(const dmrgx_sectors* left, const dmrgx_secto
         if (prods.empty()) prods.push_back(GProd{nullptr, nullptr, 0, 0, 0, GPROD_GEMM, 0.0});
         if (groups.empty()) groups.push_back(GGroup{nullptr, 0, 0, 0, 0, 0, 0, 0});
         ggemm_schedule(gt); ggemm_schedule(gb, 2);
-        DevBuf dp, dg, dt, db, dc;
-        DMRGX_CHK(upload(dp, prods, st)); DMRGX_CHK(upload(dg, groups, st)); DMRGX_CHK(upload(dt, gt, st)); DMRGX_CHK(upload(db, gb, st));
-        DMRGX_CHK(upload(dc, cn, st));
+        DevBuf dtab;
+        PackedUpload pk;
+        const size_t o_p = pk.add(prods), o_g = pk.add(groups), o_t = pk.add(gt), o_b = pk.add(gb), o_c = pk.add(cn);
+        DMRGX_CHK(pk.upload(dtab, st));
         DMRGX_HIP(zero_async(buf + rq_base, (size_t)dtot * sizeof(double), st));
-        DMRGX_CHK(ggemm_launch(db.as<GTile>(), dg.as<GGroup>(), dp.as<GProd>(), (int32_t)gb.size(), st, 1));
-        DMRGX_CHK(ggemm_launch(dt.as<GTile>(), dg.as<GGroup>(), dp.as<GProd>(), (int32_t)gt.size(), st, 0));
+        DMRGX_CHK(ggemm_launch(packed_at<GTile>(dtab, o_b), packed_at<GGroup>(dtab, o_g), packed_at<GProd>(dtab, o_p), (int32_t)gb.size(), st, 1));
+        DMRGX_CHK(ggemm_launch(packed_at<GTile>(dtab, o_t), packed_at<GGroup>(dtab, o_g), packed_at<GProd>(dtab, o_p), (int32_t)gt.size(), st, 0));
         int maxc = 1;
         for (auto& c : cn) maxc = std::max(maxc, c.ncols);
-        if (!cn.empty()) hipLaunchKernelGGL(colnorm_kernel, dim3((maxc + 63) / 64, (unsigned)cn.size()), dim3(256), 0, st, dc.as<ColNormTask>(), buf, buf);
+        if (!cn.empty()) hipLaunchKernelGGL(colnorm_kernel, dim3((maxc + 63) / 64, (unsigned)cn.size()), dim3(256), 0, st, (const ColNormTask*)packed_at<ColNormTask>(dtab, o_c), buf, buf);
         DMRGX_HIP(hipGetLastError());
         if (!rq.empty()) DMRGX_HIP(hipMemcpyAsync(rq.data(), buf + rq_base, rq.size() * sizeof(double), hipMemcpyDeviceToHost, st));
         DMRGX_HIP(hipStreamSynchronize(st));

@@ -79,16 +79,21 @@ extern "C" dmrgx_status dmrgx_cells_axpy(int32_t n, const dmrgx_axpy_task* tasks
         rnd[i] = rounds[t.dst_base ? t.dst_base : t.dst]++;
         max_round = std::max(max_round, rnd[i]);
     }
-    DevBuf d_tasks;
-    DMRGX_CHK(upload(d_tasks, ht, st));
+    // the task table and the tile lists of every round go out in one copy
+    DevBuf d_tab;
+    PackedUpload pk;
+    const size_t o_tasks = pk.add(ht);
+    std::vector<std::pair<size_t, size_t>> lists;          // (offset, tiles) per non-empty round
     for (int32_t r = 0; r <= max_round; ++r) {
         std::vector<AxTile> tl;
         for (int32_t i = 0; i < n; ++i) if (rnd[i] == r)
             for (int32_t ti = 0; ti < (ht[i].nr + 31) / 32; ++ti) for (int32_t tj = 0; tj < (ht[i].nc + 31) / 32; ++tj) tl.push_back(AxTile{i, ti, tj, 0});
         if (tl.empty()) continue;
-        DevBuf d_tl;
-        DMRGX_CHK(upload(d_tl, tl, st));
-        hipLaunchKernelGGL(cells_axpy_kernel, dim3((unsigned)tl.size()), dim3(256), 0, st, d_tl.as<AxTile>(), d_tasks.as<AxTask>());
+        lists.push_back({pk.add(tl), tl.size()});
+    }
+    DMRGX_CHK(pk.upload(d_tab, st));
+    for (const auto& l : lists) {
+        hipLaunchKernelGGL(cells_axpy_kernel, dim3((unsigned)l.second), dim3(256), 0, st, (const AxTile*)packed_at<AxTile>(d_tab, l.first), (const AxTask*)packed_at<AxTask>(d_tab, o_tasks));
         DMRGX_HIP(hipGetLastError());
     }
     return DMRGX_OK;
@@ -189,22 +194,27 @@ extern "C" dmrgx_status dmrgx_rotate_ops(const dmrgx_sectors* old_sectors, const
     // runs behind A's GEMMs instead of in front of an idle GPU
     ggemm_schedule(tA); ggemm_schedule(tAb, 2);
     const auto h2 = std::chrono::steady_clock::now();
-    DevBuf dp, dg, d1, d2, d3, d4;
-    DMRGX_CHK(upload(dp, prods, st)); DMRGX_CHK(upload(dg, groups, st));
-    DMRGX_CHK(upload(d1, tAb, st)); DMRGX_CHK(upload(d2, tA, st));
+    DevBuf dtabA, dtabB;
+    PackedUpload pkA;
+    const size_t o_p = pkA.add(prods), o_g = pkA.add(groups), o_1 = pkA.add(tAb), o_2 = pkA.add(tA);
+    DMRGX_CHK(pkA.upload(dtabA, st));
+    const GProd* dp = packed_at<GProd>(dtabA, o_p);
+    const GGroup* dg = packed_at<GGroup>(dtabA, o_g);
     const auto h3 = std::chrono::steady_clock::now();
     static const bool trace = getenv("DMRGX_ROT_TRACE") != nullptr;      // developer aid: flops and time of the two stages
     if (trace) fprintf(stderr, "[rotate] host: tables %.3f ms, schedule A %.3f ms, uploads A %.3f ms\n", std::chrono::duration<double, std::milli>(h1 - h0).count(),
                        std::chrono::duration<double, std::milli>(h2 - h1).count(), std::chrono::duration<double, std::milli>(h3 - h2).count());
     hipEvent_t ev[3];
     if (trace) { for (auto& e : ev) DMRGX_HIP(hipEventCreate(&e)); DMRGX_HIP(hipEventRecord(ev[0], st)); }
-    DMRGX_CHK(ggemm_launch(d1.as<GTile>(), dg.as<GGroup>(), dp.as<GProd>(), (int32_t)tAb.size(), st, 1));
-    DMRGX_CHK(ggemm_launch(d2.as<GTile>(), dg.as<GGroup>(), dp.as<GProd>(), (int32_t)tA.size(), st, 0));
+    DMRGX_CHK(ggemm_launch(packed_at<GTile>(dtabA, o_1), dg, dp, (int32_t)tAb.size(), st, 1));
+    DMRGX_CHK(ggemm_launch(packed_at<GTile>(dtabA, o_2), dg, dp, (int32_t)tA.size(), st, 0));
     if (trace) DMRGX_HIP(hipEventRecord(ev[1], st));
     ggemm_schedule(tB); ggemm_schedule(tBb, 2);
-    DMRGX_CHK(upload(d3, tBb, st)); DMRGX_CHK(upload(d4, tB, st));
-    DMRGX_CHK(ggemm_launch(d3.as<GTile>(), dg.as<GGroup>(), dp.as<GProd>(), (int32_t)tBb.size(), st, 1));
-    DMRGX_CHK(ggemm_launch(d4.as<GTile>(), dg.as<GGroup>(), dp.as<GProd>(), (int32_t)tB.size(), st, 0));
+    PackedUpload pkB;
+    const size_t o_3 = pkB.add(tBb), o_4 = pkB.add(tB);
+    DMRGX_CHK(pkB.upload(dtabB, st));
+    DMRGX_CHK(ggemm_launch(packed_at<GTile>(dtabB, o_3), dg, dp, (int32_t)tBb.size(), st, 1));
+    DMRGX_CHK(ggemm_launch(packed_at<GTile>(dtabB, o_4), dg, dp, (int32_t)tB.size(), st, 0));
     if (trace) {
         DMRGX_HIP(hipEventRecord(ev[2], st));
         DMRGX_HIP(hipEventSynchronize(ev[2]));

@@ -1369,10 +1369,19 @@ dmrgx_status symeig_batched(const std::vector<SymEigMat>& mats_in, hipStream_t s
     if (tiles.empty()) tiles.push_back(GTile{-1, 0, 0, 0});
     if (merges.empty()) merges.push_back(DcMerge{0, 0, 0, 0, 0, 0});
     if (wyb.empty()) wyb.push_back(WyBlock{nullptr, nullptr, nullptr, 0, 0, 0, 0});
-    DevBuf d_prods, d_groups, d_tiles, d_tp, d_wyb, d_dm, d_leaves, d_merges;
-    DMRGX_CHK(upload(d_prods, prods, st)); DMRGX_CHK(upload(d_groups, groups, st)); DMRGX_CHK(upload(d_tiles, tiles, st));
-    DMRGX_CHK(upload(d_tp, tp, st)); DMRGX_CHK(upload(d_wyb, wyb, st)); DMRGX_CHK(upload(d_dm, dm, st));
-    DMRGX_CHK(upload(d_leaves, leaves, st)); DMRGX_CHK(upload(d_merges, merges, st));
+    DevBuf d_tab;                                      // all eight tables in one copy
+    PackedUpload pk;
+    const size_t o_prods = pk.add(prods), o_groups = pk.add(groups), o_tiles = pk.add(tiles), o_tp = pk.add(tp), o_wyb = pk.add(wyb), o_dm = pk.add(dm),
+                 o_leaves = pk.add(leaves), o_merges = pk.add(merges);
+    DMRGX_CHK(pk.upload(d_tab, st));
+    const GProd* d_prods = packed_at<GProd>(d_tab, o_prods);
+    const GGroup* d_groups = packed_at<GGroup>(d_tab, o_groups);
+    const GTile* d_tiles = packed_at<GTile>(d_tab, o_tiles);
+    const SqPair* d_tp = packed_at<SqPair>(d_tab, o_tp);
+    const WyBlock* d_wyb = packed_at<WyBlock>(d_tab, o_wyb);
+    const DcMat* d_dm = packed_at<DcMat>(d_tab, o_dm);
+    const DcLeaf* d_leaves = packed_at<DcLeaf>(d_tab, o_leaves);
+    const DcMerge* d_merges = packed_at<DcMerge>(d_tab, o_merges);
     hmark("tables uploaded");
     // ---- the persistent rounds have had the host's table building and the table uploads to run in: did every workgroup get its partners? ---------------
     if (coop_ran && getenv("DMRGX_TRID_PROF")) {
@@ -1440,8 +1449,8 @@ dmrgx_status symeig_batched(const std::vector<SymEigMat>& mats_in, hipStream_t s
     }
 
     auto run_set = [&](const GemmSet& s) -> dmrgx_status {
-        DMRGX_CHK(ggemm_launch(d_tiles.as<GTile>() + s.big_off, d_groups.as<GGroup>(), d_prods.as<GProd>(), s.nbig, st, 1));
-        DMRGX_CHK(ggemm_launch(d_tiles.as<GTile>() + s.small_off, d_groups.as<GGroup>(), d_prods.as<GProd>(), s.nsmall, st, 0));
+        DMRGX_CHK(ggemm_launch(d_tiles + s.big_off, d_groups, d_prods, s.nbig, st, 1));
+        DMRGX_CHK(ggemm_launch(d_tiles + s.small_off, d_groups, d_prods, s.nsmall, st, 0));
         return DMRGX_OK;
     };
 
@@ -1449,10 +1458,10 @@ dmrgx_status symeig_batched(const std::vector<SymEigMat>& mats_in, hipStream_t s
     const bool any_blk = max_nblk > 0;
     if (any_blk) {
         const unsigned t32 = (unsigned)((nmax + 31) / 32);
-        hipLaunchKernelGGL(transpose_sq_kernel, dim3(t32, t32, (unsigned)nm), dim3(256), 0, st, d_tp.as<SqPair>());
+        hipLaunchKernelGGL(transpose_sq_kernel, dim3(t32, t32, (unsigned)nm), dim3(256), 0, st, d_tp);
         DMRGX_HIP(hipGetLastError());
         DMRGX_CHK(run_set(set_gram));
-        hipLaunchKernelGGL(wy_tinv_kernel, dim3((unsigned)wyb.size()), dim3(WY_SUB), 0, st, d_wyb.as<WyBlock>());
+        hipLaunchKernelGGL(wy_tinv_kernel, dim3((unsigned)wyb.size()), dim3(WY_SUB), 0, st, d_wyb);
         DMRGX_HIP(hipGetLastError());
         DMRGX_CHK(run_set(set_t12a));
         DMRGX_CHK(run_set(set_t12b));
@@ -1460,18 +1469,18 @@ dmrgx_status symeig_batched(const std::vector<SymEigMat>& mats_in, hipStream_t s
     }
 
     // ---- 2: launches -------------------------------------------------------------------------------------------------------------
-    const DcMat* ddm = d_dm.as<DcMat>();
+    const DcMat* ddm = d_dm;
     hipLaunchKernelGGL(dc_scale_kernel, dim3((unsigned)nm), dim3(256), 0, st, ddm);
     // (A/B: DMRGX_LEAF=ql runs the one-wave QL leaf instead.  Measured equal: 250 us per call at m = 512 for both, 8.85 ms per
     //  truncation at m = 2048 for both -- the QL chain is ~25 dependent f64 operations per rotation for ~900 rotations plus a serial scan
     //  for the split point per iteration; Jacobi stays the default because it has no failure mode.)
     static const bool leaf_jacobi = !(getenv("DMRGX_LEAF") && std::string(getenv("DMRGX_LEAF")) == "ql");
-    if (leaf_jacobi) hipLaunchKernelGGL(dc_leaf_kernel, dim3((unsigned)leaves.size()), dim3(DC_LEAF_THREADS), 0, st, ddm, d_leaves.as<DcLeaf>());
-    else hipLaunchKernelGGL(dc_leaf_ql_kernel, dim3((unsigned)leaves.size()), dim3(64), 0, st, ddm, d_leaves.as<DcLeaf>());
+    if (leaf_jacobi) hipLaunchKernelGGL(dc_leaf_kernel, dim3((unsigned)leaves.size()), dim3(DC_LEAF_THREADS), 0, st, ddm, d_leaves);
+    else hipLaunchKernelGGL(dc_leaf_ql_kernel, dim3((unsigned)leaves.size()), dim3(64), 0, st, ddm, d_leaves);
     DMRGX_HIP(hipGetLastError());
     for (const Step& s : steps) {
         if (s.nmerge == 0) continue;
-        const DcMerge* mp = d_merges.as<DcMerge>() + s.merge_off;
+        const DcMerge* mp = d_merges + s.merge_off;
         const int nl = s.nlmax;
         const size_t lds_defl = (size_t)nl * (4 * sizeof(double) + 5 * sizeof(int)) + 16;
         const size_t lds_sec = (size_t)nl * 2 * sizeof(double);
