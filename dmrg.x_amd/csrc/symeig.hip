@@ -29,8 +29,16 @@ namespace {
 
 constexpr int TRID_THREADS = 256, TRID_ROWS = 8;      // rows of the trailing matrix per workgroup (two per wave)
 constexpr int TRID_PF = 8;                            // chunks of 64 columns requested per row before they are used
-constexpr int DC_LEAF = 32;                           // largest leaf of the divide-and-conquer tree
-constexpr int DC_LEAF_THREADS = 256;                  // (one wave per leaf measured 2x slower: the sweep is bound by its LDS work, not by its barriers)
+#ifndef DMRGX_DC_LEAF
+#define DMRGX_DC_LEAF 16
+#endif
+constexpr int DC_LEAF = DMRGX_DC_LEAF;                // largest leaf of the divide-and-conquer tree.  Measured (same box; Rdms per step of configs[1] /
+                                                      // truncation of cfg4real): 32: 2.00 / 8.85 ms, 16: 1.84 / 8.60, 8: 1.90 / 8.62 -- a Jacobi leaf of 16 costs a
+                                                      // quarter of one of 32, which is more than the extra merge level takes
+#ifndef DMRGX_DC_LEAF_THREADS
+#define DMRGX_DC_LEAF_THREADS 128
+#endif
+constexpr int DC_LEAF_THREADS = DMRGX_DC_LEAF_THREADS;     // (leaf of 32: one wave measured 2x slower than 256 threads; leaf of 16: 128 threads as fast as 256)
 #ifndef DMRGX_WY_NB
 #define DMRGX_WY_NB 64
 #endif
