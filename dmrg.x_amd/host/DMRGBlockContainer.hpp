@@ -33,6 +33,7 @@
 #include <mutex>
 #include <thread>
 #include "DMRGKron.hpp"
+#include "CorrelatorDealing.hpp"
 
 /** One eigenpair of a reduced-density-matrix block */
 struct Eigen_t
@@ -1487,49 +1488,17 @@ public:
                     need_right[(size_t)nb][(size_t)s] = 1;
                 }
         }
-        /* On W ranks the correlators are dealt over the ranks (round 3): a rank measures only its share, so it carries only the site
-           operators ITS correlators read on the way back to the centre (in round 2 every rank rotated all of them, up to 124
-           correlator-only operators per step at configs[3]); the values are summed over the ranks at the measurement.  Site i of the
-           half-lattice block is rotated N/2 - i times on the way back, so the one- and two-site correlators are cut into W runs of
-           equal carried weight by their lowest site (low sites are dear: rank 0's run is the shortest), and each string (row,
-           column, loop) then goes to the rank whose carried weight it raises the least.  The reference splits this work the other
-           way round, rotating operators on sub-communicators (src/DMRGBlock.cpp:761-773, -rot_nsubcomm). */
+        /* On W ranks the correlators are dealt over the ranks (round 3, CorrelatorDealing.hpp): a rank measures only its share, so it
+           carries only the site operators ITS correlators read on the way back to the centre (in round 2 every rank rotated all of
+           them, up to 124 correlator-only operators per step at configs[3]); the values are summed over the ranks at the measurement. */
         {
             const int W = dmrgx_host::WorldComm() ? dmrgx_host::WorldSize() : 1;
-            corr_owner.assign(measurements.size(), -1);                      /* -1: measured by every rank (one-rank runs) */
-            if (W > 1 && !measurements.empty()) {
-                const PetscInt H = std::max<PetscInt>(N / 2, 1);
-                auto weight = [&](PetscInt i) { return (double)std::max<PetscInt>(H - i, 1); };
-                auto sites_of = [&](const Correlator& c) { std::vector<PetscInt> v; for (const Op& o : c.SysOps) v.push_back(o.idx); for (const Op& o : c.EnvOps) v.push_back(o.idx); return v; };
-                double total = 0; for (PetscInt i = 0; i < H; ++i) total += weight(i);
-                std::vector<int> site_rank((size_t)N, W - 1);
-                { double acc = 0; for (PetscInt i = 0; i < H; ++i) { site_rank[(size_t)i] = std::min(W - 1, (int)(acc * W / total)); acc += weight(i); } }
-                std::vector<std::vector<char>> has((size_t)W, std::vector<char>((size_t)N, 0));
-                std::vector<double> carried((size_t)W, 0.0);
-                auto give = [&](size_t ic, int r, const std::vector<PetscInt>& v) {
-                    corr_owner[ic] = r;
-                    for (PetscInt i : v) if (i >= 0 && i < N && !has[(size_t)r][(size_t)i]) { has[(size_t)r][(size_t)i] = 1; carried[(size_t)r] += weight(i); }
-                };
-                for (size_t ic = 0; ic < measurements.size(); ++ic) {
-                    const std::vector<PetscInt> v = sites_of(measurements[ic]);
-                    if (v.empty()) { corr_owner[ic] = 0; continue; }
-                    if (v.size() > 2) continue;
-                    const PetscInt lo = *std::min_element(v.begin(), v.end());
-                    give(ic, lo >= 0 && lo < N ? site_rank[(size_t)lo] : 0, v);
-                }
-                for (size_t ic = 0; ic < measurements.size(); ++ic) {
-                    if (corr_owner[ic] >= 0) continue;
-                    const std::vector<PetscInt> v = sites_of(measurements[ic]);
-                    int best = 0; double best_cost = 0;
-                    for (int r = 0; r < W; ++r) {
-                        double c = carried[(size_t)r];
-                        std::vector<char> seen((size_t)N, 0);
-                        for (PetscInt i : v) if (i >= 0 && i < N && !has[(size_t)r][(size_t)i] && !seen[(size_t)i]) { seen[(size_t)i] = 1; c += weight(i); }
-                        if (r == 0 || c < best_cost) { best = r; best_cost = c; }
-                    }
-                    give(ic, best, v);
-                }
+            std::vector<std::vector<int64_t>> sites(measurements.size());
+            for (size_t ic = 0; ic < measurements.size(); ++ic) {
+                for (const Op& o : measurements[ic].SysOps) sites[ic].push_back((int64_t)o.idx);
+                for (const Op& o : measurements[ic].EnvOps) sites[ic].push_back((int64_t)o.idx);
             }
+            corr_owner = dmrgx_host::DealCorrelators(sites, (int64_t)N, W);      /* -1: measured by every rank (one-rank runs) */
         }
         const int me_rank = dmrgx_host::WorldComm() ? dmrgx_host::WorldRank() : 0;
         corr_sites.assign((size_t)N, 0);

@@ -9,6 +9,7 @@
 #include "DMRGBlock.hpp"
 #include "Hamiltonians.hpp"
 #include "DMRGKron.hpp"
+#include "CorrelatorDealing.hpp"
 
 static void dump_mat(const char* tag, PetscInt site, const Mat& m)
 {
@@ -133,6 +134,18 @@ int main()
             PetscInt s = 0, e = 0; PetscBool flg = PETSC_FALSE;
             ierr = blocks[name].Magnetization.OpBlockToGlobalRange(blk, shift, s, e, flg);
             printf("rc %d %lld %lld %d\n", ierr, LLD(s), LLD(e), (int)flg);
+        } else if (cmd == "deal") {              /* deal N W ncorr, then per correlator: k site_1 .. site_k  ->  owners and carried weights */
+            int64_t N; int W; size_t nc;
+            is >> N >> W >> nc;
+            std::vector<std::vector<int64_t>> sites(nc);
+            for (auto& v : sites) { size_t k; is >> k; v.resize(k); for (auto& x : v) is >> x; }
+            std::vector<double> carried;
+            const std::vector<int> owner = dmrgx_host::DealCorrelators(sites, N, W, &carried);
+            printf("owners");
+            for (int o : owner) printf(" %d", o);
+            printf("\ncarried");
+            for (double c : carried) printf(" %.17g", c);
+            printf("\n");
         } else printf("unknown %s\n", cmd.c_str());
         fflush(stdout);
     }

@@ -208,3 +208,42 @@ def test_engine_block_shallow_copy_semantics():
     assert parse_dump(out[:end + 1]) == parse_dump(first)                        # the copy shows the same operators
     nn = [ln for ln in out if ln.startswith("nnz ")]
     assert int(nn[0].split()[1]) > 0 and int(nn[1].split()[1]) <= 0             # ... and its Destroy() emptied the original's
+
+
+def test_correlators_are_dealt_over_the_ranks_by_carried_weight():
+    """Multi-rank runs deal the correlators over the ranks (host/CorrelatorDealing.hpp): every correlator has exactly one owner,
+    a one-rank run keeps them all (-1), the one- and two-site correlators go to their lowest site's run, and the carried weight --
+    sum over a rank's sites of the times each is rotated on the way back, N/2 - i for site i -- is balanced: on the driver's
+    correlator table of the 20x8 cylinder (magnetisations, three bond correlators per nearest-neighbour pair mapped into the
+    half-lattice block, one row string, two columns, one loop) no rank of 8 carries more than 34 % of what one rank carries alone
+    (pairs reach Ly sites ahead and a string drags sites of the whole block along: 2.5 x redundancy in all), and the ranks are level."""
+    Lx, Ly = 20, 8
+    N = Lx * Ly
+    H = N // 2
+    local = lambda i: i if i < H else N - 1 - i          # (the right half is measured on the reflected block)
+    corr = [[i] for i in range(H)]
+    for x in range(Lx):
+        for y in range(Ly):
+            i = x * Ly + y
+            for j in ([i + Ly] if x + 1 < Lx else []) + [x * Ly + (y + 1) % Ly]:
+                corr += [[local(i), local(j)]] * 3
+    corr.append([local(x * Ly + 1) for x in range(Lx)])                         # row string
+    corr.append([local(1 * Ly + y) for y in range(Ly)])
+    corr.append([local((Lx - 2) * Ly + y) for y in range(Ly)])
+    loop = [1 * Ly + y for y in range(1, Ly - 2)] + [x * Ly + Ly - 2 for x in range(1, Lx - 2)] + [(Lx - 2) * Ly + y for y in range(Ly - 2, 1, -1)] + [x * Ly + 1 for x in range(Lx - 2, 1, -1)]
+    corr.append([local(i) for i in loop])
+    line = lambda W: "deal %d %d %d " % (N, W, len(corr)) + " ".join("%d %s" % (len(c), " ".join(map(str, c))) for c in corr)
+    out = tool([line(1), line(2), line(8)])
+    owners = [list(map(int, l.split()[1:])) for l in out if l.startswith("owners")]
+    carried = [list(map(float, l.split()[1:])) for l in out if l.startswith("carried")]
+    assert len(owners) == 3 and all(len(o) == len(corr) for o in owners)
+    assert set(owners[0]) == {-1}
+    weight = lambda sites: sum(max(H - i, 1) for i in set(sites))
+    alone = weight([i for c in corr for i in c])
+    for W, own, car in ((2, owners[1], carried[1]), (8, owners[2], carried[2])):
+        assert set(own) == set(range(W))                                           # every rank measures something
+        for r in range(W):                                                         # the tool's figure is the weight of the rank's site set
+            assert abs(car[r] - weight([i for c, o in zip(corr, own) if o == r for i in c])) < 1e-9
+        short = [(min(c), o) for c, o in zip(corr, own) if len(c) <= 2]
+        assert all(o1 <= o2 for (l1, o1), (l2, o2) in zip(sorted(short), sorted(short)[1:]))      # runs of lowest sites, in order
+        assert max(car) <= (0.72 if W == 2 else 0.34) * alone and max(car) <= 1.1 * min(car), (W, car, alone)
