@@ -107,7 +107,11 @@ struct PackedUpload {
     }
     dmrgx_status upload(DevBuf& buf, hipStream_t st) {
         DMRGX_CHK(buf.alloc(std::max<size_t>(host.size(), 16)));
-        if (!host.empty()) DMRGX_HIP(h2d_async(buf.p, host.data(), host.size(), st));
+        // (in pieces the pinned ring stages -- 4 MiB: a larger copy would leave pageable memory synchronously; the plan tables of an
+        //  m = 4096 step are ~6 MB together)
+        constexpr size_t piece = (size_t)4 << 20;
+        for (size_t off = 0; off < host.size(); off += piece)
+            DMRGX_HIP(h2d_async(static_cast<char*>(buf.p) + off, host.data() + off, std::min(piece, host.size() - off), st));
         return DMRGX_OK;
     }
     // `dst` becomes a view of the table added at `off` (n elements of T) inside the uploaded arena
