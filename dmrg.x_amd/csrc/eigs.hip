@@ -244,26 +244,39 @@ basis_rotate_kernel(const double* __restrict__ V, int64_t ldv, int m, const doub
 // Writes t; partial[b] = sum_e r[e]^2.
 __global__ void __launch_bounds__(DOT_THREADS)
 ritz_precond_kernel(const double* __restrict__ V, const double* __restrict__ W, int64_t ldv, int nv, const double* __restrict__ y, double theta,
-                    const double* __restrict__ D, double floor_, double* __restrict__ t, int64_t n, double* __restrict__ partial)
+                    const double* __restrict__ D, double floor_, double* __restrict__ t, int64_t n, double* __restrict__ partial, double* __restrict__ t2)
 {
+    // t2 != null (Olsen's variant, DMRGX_GD_OLSEN=1): also t2 = u / (theta - D) and the partial sums of u.t and u.t2 (rows 1 and 2 of
+    // `partial`), from which olsen_combine_kernel forms t - (u.t / u.t2) t2 -- the correction that keeps (H - theta)^-1-like steps off u
     __shared__ double ys[MAX_NCV];
-    __shared__ double red[DOT_THREADS / 64];
+    __shared__ double red[3][DOT_THREADS / 64];
     if (threadIdx.x < nv) ys[threadIdx.x] = y[threadIdx.x];
     __syncthreads();
-    double nrm = 0.0;
+    double nrm = 0.0, a = 0.0, b = 0.0;
     for (int64_t e = (int64_t)blockIdx.x * DOT_THREADS + threadIdx.x; e < n; e += (int64_t)gridDim.x * DOT_THREADS) {
         double u = 0.0, hu = 0.0;
         for (int i = 0; i < nv; ++i) { u += ys[i] * V[(int64_t)i * ldv + e]; hu += ys[i] * W[(int64_t)i * ldv + e]; }
         const double r = hu - theta * u;
         double den = theta - D[e];
         if (fabs(den) < floor_) den = den < 0.0 ? -floor_ : floor_;
-        t[e] = r / den;
+        const double te = r / den;
+        t[e] = te;
         nrm += r * r;
+        if (t2) { const double t2e = u / den; t2[e] = t2e; a += u * te; b += u * t2e; }
     }
     nrm = wave_sum(nrm);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = nrm;
+    if (t2) { a = wave_sum(a); b = wave_sum(b); }
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = nrm; red[1][threadIdx.x >> 6] = a; red[2][threadIdx.x >> 6] = b; }
     __syncthreads();
-    if (threadIdx.x == 0) { double s2 = 0.0; for (int k = 0; k < DOT_THREADS / 64; ++k) s2 += red[k]; partial[blockIdx.x] = s2; }
+    if (threadIdx.x < 3 && (threadIdx.x == 0 || t2)) { double s2 = 0.0; for (int k = 0; k < DOT_THREADS / 64; ++k) s2 += red[threadIdx.x][k]; partial[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] = s2; }
+}
+
+// t -= (sc[1] / sc[2]) t2   (sc: the reduced sums of ritz_precond_kernel)
+__global__ void __launch_bounds__(DOT_THREADS)
+olsen_combine_kernel(double* __restrict__ t, const double* __restrict__ t2, int64_t n, const double* __restrict__ sc)
+{
+    const double bb = sc[2], eps = bb != 0.0 ? sc[1] / bb : 0.0;
+    for (int64_t e = (int64_t)blockIdx.x * DOT_THREADS + threadIdx.x; e < n; e += (int64_t)gridDim.x * DOT_THREADS) t[e] -= eps * t2[e];
 }
 
 // counter-based uniform(-1,1) start vector (splitmix64 of seed + global index)
@@ -579,7 +592,7 @@ static dmrgx_status eigs_davidson(dmrgx_kron_plan* plan, const dmrgx_eigs_opts* 
         fprintf(stderr, "[eigs gd] setup %-12s t = %.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
     };
     mark("enter");
-    DevBuf dV, dW, dT, dX, dD, dTmp, dPartial, dScal, dY;
+    DevBuf dV, dW, dT, dT2, dX, dD, dTmp, dPartial, dScal, dY;
     DMRGX_CHK(dV.alloc((size_t)(m + 1) * n * sizeof(double)));
     DMRGX_CHK(dW.alloc((size_t)(m + 1) * n * sizeof(double)));
     DMRGX_CHK(dT.alloc((size_t)n * sizeof(double)));
@@ -706,12 +719,15 @@ static dmrgx_status eigs_davidson(dmrgx_kron_plan* plan, const dmrgx_eigs_opts* 
         for (int i = 0; i < mm; ++i) ydev[(size_t)i] = Y[(size_t)i * mm + 0];
         DMRGX_HIP(h2d_async(dY.p, ydev.data(), ydev.size() * sizeof(double), st));
         const double floor_ = floor_rel * std::max(1.0, std::fabs(lambda)) * 1e-2 + 1e-12;
+        static const bool olsen = getenv("DMRGX_GD_OLSEN") && atoi(getenv("DMRGX_GD_OLSEN")) != 0;
+        if (olsen && !dT2.p) DMRGX_CHK(dT2.alloc((size_t)n * sizeof(double)));
         hipLaunchKernelGGL(ritz_precond_kernel, dim3(nblk), dim3(DOT_THREADS), 0, st, (const double*)V, (const double*)W, n, mm, (const double*)dY.as<double>(), lambda,
-                           (const double*)dD.as<double>(), floor_, t, n, dPartial.as<double>());
+                           (const double*)dD.as<double>(), floor_, t, n, dPartial.as<double>(), olsen ? dT2.as<double>() : (double*)nullptr);
         DMRGX_HIP(hipGetLastError());
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(DOT_THREADS), 0, st, dPartial.as<double>(), nrm, 1, nblk);
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(olsen ? 3 : 1), dim3(DOT_THREADS), 0, st, dPartial.as<double>(), nrm, olsen ? 3 : 1, nblk);
         DMRGX_HIP(hipGetLastError());
-        DMRGX_CHK(allreduce(nrm, 1));
+        DMRGX_CHK(allreduce(nrm, olsen ? 3 : 1));
+        if (olsen) { hipLaunchKernelGGL(olsen_combine_kernel, dim3(1024), dim3(DOT_THREADS), 0, st, t, (const double*)dT2.as<double>(), n, (const double*)nrm); DMRGX_HIP(hipGetLastError()); }
         DMRGX_HIP(hipMemcpyAsync(h_r2, nrm, sizeof(double), hipMemcpyDeviceToHost, st));
         DMRGX_HIP(hipEventRecord(ev_r2, st));
         // queued behind the read-back, before the host looks at it: the restart (when the basis is full) and the next direction
