@@ -25,7 +25,7 @@ constexpr int SYMEIG_MAX_N = 3072;     // the merge kernels keep O(n) vectors of
 // Enqueue the eigendecomposition of every matrix on `st` (asynchronous; workspace comes from the stream-ordered pool).
 dmrgx_status symeig_batched(const std::vector<SymEigMat>& mats, hipStream_t st);
 
-// The tridiagonalisation normally runs as ONE persistent launch with the matrices resident in registers across most CUs of the
+// The tridiagonalisation normally runs as ONE persistent launch with the matrices resident in the LDS of most CUs of the
 // chip; processes that share a GPU with other ranks (the host-staged rehearsal communicator) switch it off and use one launch per
 // column (also selected by DMRGX_TRID=launch, and automatically after a bounded-spin timeout).
 void symeig_set_persistent(bool on);
