@@ -1190,21 +1190,38 @@ dmrgx_status symeig_batched(const std::vector<SymEigMat>& mats_in, hipStream_t s
         std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return M[a].n > M[b].n; });
         struct Round { std::vector<int> mats, G; int wgs = 0; };
         std::vector<Round> rounds;
-        // Workgroups per matrix: at least what LDS capacity asks for; when that leaves CUs idle (small m: a dozen small matrices on 256
-        // CUs) the rows are spread further, down to `rows_target` rows per workgroup -- the column step is a latency chain in which
-        // a workgroup's own row pass (rows / 8 per wave) is one link, and more workgroups cost the all-gather almost nothing.
-        static const int rows_target = [] { const char* e = getenv("DMRGX_TRID_ROWS"); const int v = e ? atoi(e) : 16; return v < 1 ? 1 : v; }();
+        // Workgroups per matrix: at least what LDS capacity asks for.  CUs that this leaves idle go, one at a time, to the matrix with the
+        // longest estimated chain -- n columns x (a fixed part + the workgroup's own row pass, which is proportional to rows per workgroup
+        // x row length) -- down to `rows_floor` rows per workgroup: the launch lasts as long as its longest chain, a workgroup's row pass
+        // is one link of every column of it, and among few workgroups more partners cost the all-gather almost nothing.  (Small m: a dozen
+        // matrices of n <= 300 on 256 CUs go from 75 to 8-16 rows per workgroup: 888 -> 672 us per call at m = 512.)
+        static const int rows_floor = [] { const char* e = getenv("DMRGX_TRID_ROWS"); const int v = e ? atoi(e) : 8; return v < 1 ? 1 : v; }();
         std::vector<int> Gmin(nm, 0), Gof(nm, 0);
         {
-            int64_t sum_min = 0, sum_want = 0;
+            int64_t used = 0;
             for (int q = 0; q < nm; ++q) {
                 const int64_t n = M[q].n, nv = (n + 1) & ~(int64_t)1, cap = (dyn_max / 8 - TC_VECS * nv) / nv;      // rows of this matrix one workgroup can hold
                 Gmin[q] = cap >= 1 ? (int)((n + cap - 1) / cap) : ncu + 1;
-                Gof[q] = std::max<int>(Gmin[q], (int)((n + rows_target - 1) / rows_target));
-                if (Gmin[q] <= ncu) { sum_min += Gmin[q]; sum_want += std::min(Gof[q], ncu); }
+                Gof[q] = Gmin[q];
+                if (Gmin[q] <= ncu) used += Gmin[q];
             }
-            const double f = sum_want <= ncu ? 1.0 : (sum_min >= ncu ? 0.0 : double(ncu - sum_min) / double(sum_want - sum_min));
-            for (int q = 0; q < nm; ++q) if (Gmin[q] <= ncu) Gof[q] = Gmin[q] + (int)(f * (std::min(Gof[q], ncu) - Gmin[q]));
+            // estimated chain [us]: per column 2.7 fixed (exchange, vector work, barriers) + 1.35 for 18 rows of 1037 columns (measured, m = 2048)
+            auto chain = [&](int q) { const double n = M[q].n, rows = std::ceil(n / Gof[q]); return n * (2.7 + 1.35 * (rows / 18.0) * (n / 1037.0)); };
+            // Only when the largest matrix is itself small: at m = 2048 (n up to 1037, G = 58 by capacity) more workgroups made the call
+            // SLOWER on the same box -- 8.49 ms per truncation with none, 8.60 with the spare CUs on the small matrices, 8.62 with them on
+            // the largest -- more partners lengthen the exchange there by more than the shorter row pass saves.
+            if (used <= ncu && nmax <= 400) {          // (m = 1024, n up to ~520: no difference either way)
+                for (int64_t spare = ncu - used; spare > 0; --spare) {
+                    int best = -1; double tbest = 0;
+                    for (int q = 0; q < nm; ++q) {
+                        if (Gmin[q] > ncu || (M[q].n + Gof[q] - 1) / Gof[q] <= rows_floor) continue;
+                        const double t = chain(q);
+                        if (best < 0 || t > tbest) { best = q; tbest = t; }
+                    }
+                    if (best < 0) break;
+                    ++Gof[best];
+                }
+            }
         }
         for (int q : order) {
             const int G = Gof[q];
