@@ -30,13 +30,13 @@ struct GGroup {         // one output matrix, tiled BM x BN
     int32_t accumulate;             // 0: C = result, 1: C += result
 };
 
-struct GTile { int32_t group, tm, tn, pad; };
+struct GTile { int32_t group, tm, tn, pad; };   // pad: host, before ggemm_schedule: cost in k-steps; device: first GEMM product of the group
 
 constexpr int GG_BM = 64, GG_BN = 64, GG_BK = 16, GG_THREADS = 256;
 
-// Enqueue the tiles [0, ntiles) described by device tables.  big != 0: every tile is a 128 x 128 macro tile
+// Enqueue the scheduled tile list [0, ntiles) described by device tables.  big != 0: every tile is a 128 x 128 macro tile
 // (coordinates still in 64-units), else 64 x 64.
-dmrgx_status ggemm_launch(const GTile* d_tiles, const GGroup* d_groups, const GProd* d_prods, int32_t ntiles, hipStream_t st, int big = 0);   // big: GG_SHAPE_*
+dmrgx_status ggemm_launch(const GTile* d_tiles, const GGroup* d_groups, const GProd* d_prods, int32_t ntiles, hipStream_t st, int big = 0);
 
 // Host-side helper: append the tiles of group `g` (M x N) to a tile list in 8 x 8 clusters (tiles of a cluster share
 // A row-panels and B column-panels; the scheduler keeps a cluster on one XCD so they meet in its L2); `cost` (k-steps of
@@ -51,7 +51,7 @@ inline void ggemm_append_tiles(std::vector<GTile>& tiles, int32_t g, int32_t M, 
                 for (int32_t tn = bn; tn < std::min(TN, bn + GG_CLUSTER); ++tn) tiles.push_back(GTile{g, tm, tn, cost});
 }
 
-// DMRGX_TILES=64 (environment) disables the 128 x 128 kernel, DMRGX_TILES=mixed enables it for the superblock plan.
+// DMRGX_TILES=mixed routes the 128-aligned cores of the superblock plan's groups to the 128 x 128 kernel (measurement knob).
 bool ggemm_use_big_tiles();
 inline void ggemm_append_tiles_mixed(std::vector<GTile>& big, std::vector<GTile>& small, int32_t g, int32_t M, int32_t N, int32_t cost = 1, bool allow_big = true) {
     const int32_t mb = allow_big ? (M / 128) * 2 : 0, nb = allow_big ? (N / 128) * 2 : 0;   // core extent in 64-units
@@ -67,34 +67,23 @@ inline void ggemm_append_tiles_mixed(std::vector<GTile>& big, std::vector<GTile>
                     if (tm >= mb || tn >= nb) small.push_back(GTile{g, tm, tn, cost});
 }
 
-// Tiling with 96-row "tall" tiles (the superblock plan): a ragged row remainder of at most 32 rows does not get a tile of its own
-// (a sliver tile walks its whole K for a few valid rows and costs as much as a full tile) but is absorbed by the last full tile row,
-// which becomes one row of 96 x 64 tiles (ggemm_kernel<3,2,2,2>, shape GG_SHAPE_TALL; coordinates stay in 64-units).  128 x 128 core
-// tiles never cover the tall row.
-enum : int { GG_SHAPE_64 = 0, GG_SHAPE_128 = 1, GG_SHAPE_TALL = 2 };
-inline void ggemm_append_tiles_tall(std::vector<GTile>& big, std::vector<GTile>& small, std::vector<GTile>& tall, int32_t g, int32_t M, int32_t N, int32_t cost = 1, bool allow_big = true) {
-    const int32_t TM = (M + GG_BM - 1) / GG_BM, TN = (N + GG_BN - 1) / GG_BN, r = M % GG_BM;
-    const bool absorb = r > 0 && r <= 32 && TM >= 2;
-    const int32_t tall_tm = absorb ? TM - 2 : TM;                            // first tile row that is not tiled 64 x 64
-    int32_t mb = allow_big ? (M / 128) * 2 : 0;
-    if (mb > tall_tm) mb = (tall_tm / 2) * 2;
-    const int32_t nb = allow_big ? (N / 128) * 2 : 0;
-    for (int32_t bm = 0; bm < mb; bm += 2 * GG_CLUSTER)
-        for (int32_t bn = 0; bn < nb; bn += 2 * GG_CLUSTER)
-            for (int32_t tm = bm; tm < std::min(mb, bm + 2 * GG_CLUSTER); tm += 2)
-                for (int32_t tn = bn; tn < std::min(nb, bn + 2 * GG_CLUSTER); tn += 2) big.push_back(GTile{g, tm, tn, 4 * cost});
-    for (int32_t bm = 0; bm < tall_tm; bm += GG_CLUSTER)
-        for (int32_t bn = 0; bn < TN; bn += GG_CLUSTER)
-            for (int32_t tm = bm; tm < std::min(tall_tm, bm + GG_CLUSTER); ++tm)
-                for (int32_t tn = bn; tn < std::min(TN, bn + GG_CLUSTER); ++tn)
-                    if (tm >= mb || tn >= nb) small.push_back(GTile{g, tm, tn, cost});
-    if (absorb) for (int32_t tn = 0; tn < TN; ++tn) tall.push_back(GTile{g, tall_tm, tn, cost + cost / 2});
-}
-
 // XCD-aware, cost-balanced launch order.  Blocks b, b+8, b+16.. run on one XCD (each XCD has its own L2), so the
 // list is rebuilt as 8 interleaved per-XCD lists: clusters of tiles that share an A row-panel (same group and
 // tile row) stay on one XCD for L2 reuse, clusters are dealt longest-first to the least-loaded XCD (LPT), and each
 // XCD runs its longest clusters first so the tail is made of short tiles.  Lists are padded with group = -1.
-void ggemm_schedule(std::vector<GTile>& tiles, int unit = 1);   // unit = 2 for lists of 128 x 128 tiles
+//
+// Since round 4 the launch keeps `ggemm_slots` RESIDENT workgroups (every workgroup slot of the chip) and workgroup w walks the
+// entries w, w + slots, w + 2 slots, ... of the scheduled list: the tiles of an XCD are dealt, in cluster order, to the
+// workgroup of that XCD with the least work so far.  On the device GTile::pad is the index of the group's first GEMM product
+// -- -1 if it has none -- (on the host, before scheduling, the tile's cost in k-steps), which is why the scheduler needs the groups.
+// EVERY list handed to ggemm_launch must have gone through ggemm_schedule.
+int ggemm_slots(int unit = 1);
+void ggemm_schedule_core(std::vector<GTile>& tiles, const std::vector<int32_t>& first_gemm_product_of_group, int unit);
+template <class GroupVec>
+inline void ggemm_schedule(std::vector<GTile>& tiles, const GroupVec& groups, int unit = 1) {   // unit = 2 for lists of 128 x 128 tiles
+    std::vector<int32_t> p0(groups.size());
+    for (size_t i = 0; i < groups.size(); ++i) p0[i] = groups[i].prod_begin + groups[i].n_axpy < groups[i].prod_end ? groups[i].prod_begin + groups[i].n_axpy : -1;
+    ggemm_schedule_core(tiles, p0, unit);
+}
 
 }  // namespace dmrgx

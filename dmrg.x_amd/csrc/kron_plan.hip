@@ -205,8 +205,8 @@ struct dmrgx_kron_plan {
     std::vector<std::unique_ptr<Patched>> patched;
     size_t patched_next = 0;            // round-robin victim once PATCHED_MAX sets exist
     static constexpr size_t PATCHED_MAX = 24;
-    DevBuf d_tiles1, d_tiles2, d_tiles1b, d_tiles2b, d_tiles1t, d_tiles2t;
-    int32_t nprods = 0, ngroups = 0, ntiles1 = 0, ntiles2 = 0, ntiles1b = 0, ntiles2b = 0, ntiles1t = 0, ntiles2t = 0;
+    DevBuf d_tiles1, d_tiles2, d_tiles1b, d_tiles2b;
+    int32_t nprods = 0, ngroups = 0, ntiles1 = 0, ntiles2 = 0, ntiles1b = 0, ntiles2b = 0;
     DevBuf d_layout;
     int32_t nlayout = 0;
     DevBuf d_red_tasks, d_red_tiles;    // split-K fix-up tables
@@ -215,15 +215,10 @@ struct dmrgx_kron_plan {
     std::vector<DiagSeg> diag_segs;     // this rank's panels of every KronBlock
     int32_t diag_terms = 0, diag_rounds = 0;
     int64_t diag_NL = 0, diag_NR = 0;
-    // DMRGX_TILES=overlap: the 128 x 128 launch of a stage on the caller's stream and its 64 x 64 launch on a second stream, joined by
-    // events before the next stage (the two write disjoint tiles; one launch's tail fills with the other's workgroups)
-    bool overlap = false;
-    hipStream_t aux = nullptr;
-    hipEvent_t ev_j[4] = {nullptr, nullptr, nullptr, nullptr};
     bool timing = false;                // per-stage HIP-event timing (dmrgx_kron_plan_timing)
     std::vector<hipEvent_t> ev;         // 3 events per recorded apply
     size_t ev_used = 0;
-    ~dmrgx_kron_plan() { for (hipEvent_t e : ev) (void)hipEventDestroy(e); for (hipEvent_t e : ev_j) if (e) (void)hipEventDestroy(e); if (aux) (void)hipStreamDestroy(aux); }
+    ~dmrgx_kron_plan() { for (hipEvent_t e : ev) (void)hipEventDestroy(e); }
 };
 
 namespace {
@@ -257,17 +252,11 @@ dmrgx_status normalise_op(const dmrgx_secop* op, const dmrgx_sectors& sec, const
 struct Builder {
     std::vector<RelProd> prods;
     std::vector<RelGroup> groups;
-    std::vector<GTile> tiles1, tiles2, tiles1b, tiles2b, tiles1t, tiles2t;   // 64x64, 128x128 and 96x64 ("tall") lists per stage
+    std::vector<GTile> tiles1, tiles2, tiles1b, tiles2b;   // 64x64 and 128x128 lists per stage
     std::vector<int32_t> stage2_groups;
     double flops_alg = 0, flops_exec = 0, flops_alg_big = 0;
     bool big = ggemm_use_big_tiles();
-    // 96-row tiles that absorb a ragged row remainder <= 32 (DMRGX_TALL=1).  Measured and left off: on cfg4real the plan loses 864 + 1000
-    // sliver tiles but runs at 52.5 instead of 53.8 TF/s (64 x 64 plan) / 52.2 instead of 53.4 (mixed) -- inside one launch a sliver
-    // tile is an MFMA-light workgroup riding beside three full ones on its CU, cheaper than the extra launch of 132-register tiles
-    bool tall = getenv("DMRGX_TALL") && atoi(getenv("DMRGX_TALL")) == 1;
-    void append_tiles(std::vector<GTile>& b, std::vector<GTile>& s64, std::vector<GTile>& t, int32_t g, int32_t M, int32_t N, int32_t cost) {
-        if (tall) ggemm_append_tiles_tall(b, s64, t, g, M, N, cost, big); else ggemm_append_tiles_mixed(b, s64, g, M, N, cost, big);
-    }
+    void append_tiles(std::vector<GTile>& b, std::vector<GTile>& s64, int32_t g, int32_t M, int32_t N, int32_t cost) { ggemm_append_tiles_mixed(b, s64, g, M, N, cost, big); }
     int32_t max_split = 1;
 
     int32_t ksteps(int32_t g) const {      // cost of one tile of group g in k-steps of the GEMM stream
@@ -325,7 +314,7 @@ struct Builder {
                 cuts.erase(std::unique(cuts.begin(), cuts.end()), cuts.end());
             }
             const int32_t S = (int32_t)cuts.size();
-            if (S == 1) { append_tiles(tiles2b, tiles2, tiles2t, g, groups[g].M, groups[g].N, cost); continue; }
+            if (S == 1) { append_tiles(tiles2b, tiles2, g, groups[g].M, groups[g].N, cost); continue; }
             max_split = std::max(max_split, S);
             const int64_t mn = (int64_t)groups[g].M * groups[g].N;
             red_tasks.push_back(RedTask{groups[g].c_off, slab_base + slab_elems, groups[g].ldc, groups[g].M, groups[g].N, S - 1});
@@ -356,7 +345,7 @@ struct Builder {
                 const int32_t ne = (int32_t)prods.size();
                 if (sidx == 0) {
                     groups[g].prod_begin = nb; groups[g].prod_end = ne; groups[g].n_axpy = n_axpy_seg;
-                    append_tiles(tiles2b, tiles2, tiles2t, g, groups[g].M, groups[g].N, (hi - lo) + n_axpy_seg);
+                    append_tiles(tiles2b, tiles2, g, groups[g].M, groups[g].N, (hi - lo) + n_axpy_seg);
                 } else {
                     RelGroup ng2 = groups[g];
                     ng2.c_base = BASE_ARENA;
@@ -364,7 +353,7 @@ struct Builder {
                     ng2.ldc = ng2.N;
                     ng2.prod_begin = nb; ng2.prod_end = ne; ng2.n_axpy = n_axpy_seg; ng2.accumulate = 0;
                     groups.push_back(ng2);
-                    append_tiles(tiles2b, tiles2, tiles2t, (int32_t)groups.size() - 1, ng2.M, ng2.N, (hi - lo) + n_axpy_seg);
+                    append_tiles(tiles2b, tiles2, (int32_t)groups.size() - 1, ng2.M, ng2.N, (hi - lo) + n_axpy_seg);
                 }
                 lo = hi;
             }
@@ -400,7 +389,7 @@ struct Builder {
                 if (big) flops_alg_big += 2.0 * (double)((G.M / 128) * 128) * (double)((G.N / 128) * 128) * prods[p].K;
             }
         }
-        if (stage == 1) append_tiles(tiles1b, tiles1, tiles1t, g, G.M, G.N, ksteps(g));
+        if (stage == 1) append_tiles(tiles1b, tiles1, g, G.M, G.N, ksteps(g));
         else stage2_groups.push_back(g);
     }
 };
@@ -679,12 +668,10 @@ extern "C" dmrgx_status dmrgx_kron_plan_create(const dmrgx_kron_desc* d, void* s
     const int64_t slab_base = arena_ops + arena_T;
     B.finalize_stage2(slab_base);
     const int64_t arena_slabs = B.slab_elems;
-    ggemm_schedule(B.tiles1);
-    ggemm_schedule(B.tiles2);
-    ggemm_schedule(B.tiles1b, 2);
-    ggemm_schedule(B.tiles2b, 2);
-    ggemm_schedule(B.tiles1t);
-    ggemm_schedule(B.tiles2t);
+    ggemm_schedule(B.tiles1, B.groups);
+    ggemm_schedule(B.tiles2, B.groups);
+    ggemm_schedule(B.tiles1b, B.groups, 2);
+    ggemm_schedule(B.tiles2b, B.groups, 2);
     if (const char* dump = getenv("DMRGX_PLAN_DUMP")) {   // developer aid: scheduled tile lists, one line per tile
         if (FILE* f = fopen(dump, "w")) {
             auto put = [&](const char* name, const std::vector<GTile>& tl) {
@@ -692,10 +679,10 @@ extern "C" dmrgx_status dmrgx_kron_plan_create(const dmrgx_kron_desc* d, void* s
                     const GTile& t = tl[i];
                     if (t.group < 0) { fprintf(f, "%s %zu -1 0 0 0 0 0 0\n", name, i); continue; }
                     const RelGroup& G2 = B.groups[t.group];
-                    fprintf(f, "%s %zu %d %d %d %d %d %d %d\n", name, i, t.group, t.tm, t.tn, G2.M, G2.N, t.pad, G2.prod_end - G2.prod_begin);
+                    fprintf(f, "%s %zu %d %d %d %d %d %d %d\n", name, i, t.group, t.tm, t.tn, G2.M, G2.N, B.ksteps(t.group), G2.prod_end - G2.prod_begin);
                 }
             };
-            put("s1", B.tiles1); put("s2", B.tiles2); put("s1b", B.tiles1b); put("s2b", B.tiles2b); put("s1t", B.tiles1t); put("s2t", B.tiles2t);
+            put("s1", B.tiles1); put("s2", B.tiles2); put("s1b", B.tiles1b); put("s2b", B.tiles2b);
             fclose(f);
         }
     }
@@ -732,8 +719,6 @@ extern "C" dmrgx_status dmrgx_kron_plan_create(const dmrgx_kron_desc* d, void* s
     P->nprods = (int32_t)B.prods.size(); P->ngroups = (int32_t)B.groups.size();
     P->ntiles1 = (int32_t)B.tiles1.size(); P->ntiles2 = (int32_t)B.tiles2.size();
     P->ntiles1b = (int32_t)B.tiles1b.size(); P->ntiles2b = (int32_t)B.tiles2b.size();
-    P->ntiles1t = (int32_t)B.tiles1t.size(); P->ntiles2t = (int32_t)B.tiles2t.size();
-    { const char* tm = getenv("DMRGX_TILES"); P->overlap = tm && std::string(tm) == "overlap"; }
     {   // every table of the plan in one copy; the members are views into P->d_tables
         std::vector<LayoutSeg> segs;                       // layout conversion table (reference order <-> rank-major stripes)
         for (int32_t k = 0; k < nb; ++k) for (int32_t w = 0; w < W; ++w) {
@@ -743,7 +728,7 @@ extern "C" dmrgx_status dmrgx_kron_plan_create(const dmrgx_kron_desc* d, void* s
         P->nlayout = (int32_t)segs.size();
         PackedUpload pk;
         const size_t o0 = pk.add(B.prods), o1 = pk.add(B.groups), o2 = pk.add(B.tiles1), o3 = pk.add(B.tiles2), o4 = pk.add(B.tiles1b), o5 = pk.add(B.tiles2b),
-                     o6 = pk.add(B.tiles1t), o7 = pk.add(B.tiles2t), o8 = pk.add(B.red_tasks), o9 = pk.add(B.red_tiles), o10 = pk.add(segs);
+                     o8 = pk.add(B.red_tasks), o9 = pk.add(B.red_tiles), o10 = pk.add(segs);
         DMRGX_CHK(pk.upload(P->d_tables, st));
         PackedUpload::view<std::decay<decltype(B.prods[0])>::type>(P->d_rprods, P->d_tables, o0, B.prods.size());
         PackedUpload::view<std::decay<decltype(B.groups[0])>::type>(P->d_rgroups, P->d_tables, o1, B.groups.size());
@@ -751,8 +736,6 @@ extern "C" dmrgx_status dmrgx_kron_plan_create(const dmrgx_kron_desc* d, void* s
         PackedUpload::view<GTile>(P->d_tiles2, P->d_tables, o3, B.tiles2.size());
         PackedUpload::view<GTile>(P->d_tiles1b, P->d_tables, o4, B.tiles1b.size());
         PackedUpload::view<GTile>(P->d_tiles2b, P->d_tables, o5, B.tiles2b.size());
-        PackedUpload::view<GTile>(P->d_tiles1t, P->d_tables, o6, B.tiles1t.size());
-        PackedUpload::view<GTile>(P->d_tiles2t, P->d_tables, o7, B.tiles2t.size());
         PackedUpload::view<std::decay<decltype(B.red_tasks[0])>::type>(P->d_red_tasks, P->d_tables, o8, B.red_tasks.size());
         PackedUpload::view<std::decay<decltype(B.red_tiles[0])>::type>(P->d_red_tiles, P->d_tables, o9, B.red_tiles.size());
         PackedUpload::view<LayoutSeg>(P->d_layout, P->d_tables, o10, segs.size());
@@ -817,7 +800,7 @@ extern "C" dmrgx_status dmrgx_kron_plan_create(const dmrgx_kron_desc* d, void* s
     cellbytes(PHL); cellbytes(PHRT);
     I.bytes_alg = opbytes + 8.0 * ((double)N + (double)seg_off[me][nb]);
     I.bytes_workspace = 16.0 * (double)arena_T + 16.0 * (double)B.slab_elems;
-    I.n_groups = (int32_t)G.size(); I.n_tiles_stage1 = P->ntiles1 + P->ntiles1b + P->ntiles1t; I.n_tiles_stage2 = P->ntiles2 + P->ntiles2b + P->ntiles2t;
+    I.n_groups = (int32_t)G.size(); I.n_tiles_stage1 = P->ntiles1 + P->ntiles1b; I.n_tiles_stage2 = P->ntiles2 + P->ntiles2b;
     I.n_tiles_big = P->ntiles1b + P->ntiles2b; I.flops_alg_big = B.flops_alg_big;
     (void)n_groups_stage1;
     *out = guard.release();
@@ -865,45 +848,15 @@ extern "C" dmrgx_status dmrgx_kron_apply(dmrgx_kron_plan* P, const double* x_ful
         e = &P->ev[P->ev_used];
         P->ev_used += 5;
     }
-    if (P->overlap && P->ntiles1b > 0 && P->ntiles2b > 0) {
-        if (!P->aux) {
-            DMRGX_HIP(hipStreamCreateWithFlags(&P->aux, hipStreamNonBlocking));
-            for (auto& x : P->ev_j) DMRGX_HIP(hipEventCreateWithFlags(&x, hipEventDisableTiming));
-        }
-        if (e) DMRGX_HIP(hipEventRecord(e[0], st));
-        DMRGX_HIP(hipEventRecord(P->ev_j[0], st));                       // everything queued so far (x, the patched tables) ...
-        DMRGX_HIP(hipStreamWaitEvent(P->aux, P->ev_j[0], 0));            // ... precedes the second stream's work
-        DMRGX_CHK(ggemm_launch(P->d_tiles1b.as<GTile>(), T->groups.as<GGroup>(), T->prods.as<GProd>(), P->ntiles1b, st, 1));
-        DMRGX_CHK(ggemm_launch(P->d_tiles1.as<GTile>(), T->groups.as<GGroup>(), T->prods.as<GProd>(), P->ntiles1, P->aux, 0));
-        DMRGX_CHK(ggemm_launch(P->d_tiles1t.as<GTile>(), T->groups.as<GGroup>(), T->prods.as<GProd>(), P->ntiles1t, P->aux, GG_SHAPE_TALL));
-        DMRGX_HIP(hipEventRecord(P->ev_j[1], P->aux));
-        DMRGX_HIP(hipEventRecord(P->ev_j[2], st));
-        DMRGX_HIP(hipStreamWaitEvent(st, P->ev_j[1], 0));                // stage 2 reads every T tile of stage 1
-        DMRGX_HIP(hipStreamWaitEvent(P->aux, P->ev_j[2], 0));
-        if (e) { DMRGX_HIP(hipEventRecord(e[1], st)); DMRGX_HIP(hipEventRecord(e[2], st)); }
-        DMRGX_CHK(ggemm_launch(P->d_tiles2b.as<GTile>(), T->groups.as<GGroup>(), T->prods.as<GProd>(), P->ntiles2b, st, 1));
-        DMRGX_CHK(ggemm_launch(P->d_tiles2.as<GTile>(), T->groups.as<GGroup>(), T->prods.as<GProd>(), P->ntiles2, P->aux, 0));
-        DMRGX_CHK(ggemm_launch(P->d_tiles2t.as<GTile>(), T->groups.as<GGroup>(), T->prods.as<GProd>(), P->ntiles2t, P->aux, GG_SHAPE_TALL));
-        DMRGX_HIP(hipEventRecord(P->ev_j[3], P->aux));
-        DMRGX_HIP(hipStreamWaitEvent(st, P->ev_j[3], 0));
-        if (e) { DMRGX_HIP(hipEventRecord(e[3], st)); DMRGX_HIP(hipEventRecord(e[4], st)); }
-        if (P->n_red_tiles > 0) {
-            hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)P->n_red_tiles), dim3(256), 0, st, P->d_red_tiles.as<RedTile>(), P->d_red_tasks.as<RedTask>(), y_local, P->arena.as<double>());
-            DMRGX_HIP(hipGetLastError());
-        }
-        return DMRGX_OK;
-    }
     // four launches: {stage 1, stage 2} x {128x128 core tiles, 64x64 remainder tiles}, each bracketed by events
     if (e) DMRGX_HIP(hipEventRecord(e[0], st));
     DMRGX_CHK(ggemm_launch(P->d_tiles1b.as<GTile>(), T->groups.as<GGroup>(), T->prods.as<GProd>(), P->ntiles1b, st, 1));
     if (e) DMRGX_HIP(hipEventRecord(e[1], st));
     DMRGX_CHK(ggemm_launch(P->d_tiles1.as<GTile>(), T->groups.as<GGroup>(), T->prods.as<GProd>(), P->ntiles1, st, 0));
-    DMRGX_CHK(ggemm_launch(P->d_tiles1t.as<GTile>(), T->groups.as<GGroup>(), T->prods.as<GProd>(), P->ntiles1t, st, GG_SHAPE_TALL));      // (timed with the 64 x 64 launch)
     if (e) DMRGX_HIP(hipEventRecord(e[2], st));
     DMRGX_CHK(ggemm_launch(P->d_tiles2b.as<GTile>(), T->groups.as<GGroup>(), T->prods.as<GProd>(), P->ntiles2b, st, 1));
     if (e) DMRGX_HIP(hipEventRecord(e[3], st));
     DMRGX_CHK(ggemm_launch(P->d_tiles2.as<GTile>(), T->groups.as<GGroup>(), T->prods.as<GProd>(), P->ntiles2, st, 0));
-    DMRGX_CHK(ggemm_launch(P->d_tiles2t.as<GTile>(), T->groups.as<GGroup>(), T->prods.as<GProd>(), P->ntiles2t, st, GG_SHAPE_TALL));
     if (e) DMRGX_HIP(hipEventRecord(e[4], st));
     if (P->n_red_tiles > 0) {
         hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)P->n_red_tiles), dim3(256), 0, st, P->d_red_tiles.as<RedTile>(), P->d_red_tasks.as<RedTask>(), y_local, P->arena.as<double>());

@@ -61,7 +61,8 @@ extern "C" dmrgx_status dmrgx_dgemm_nn(int32_t M, int32_t N, int32_t K, const do
     if (K > 0) prods.push_back(GProd{A, B, (int32_t)lda, (int32_t)ldb, K, GPROD_GEMM, 1.0});
     std::vector<GGroup> groups = {GGroup{C, (int32_t)ldc, M, N, 0, (int32_t)prods.size(), 0, 0}};
     std::vector<GTile> tiles, big;
-    ggemm_append_tiles_mixed(big, tiles, 0, M, N);
+    ggemm_append_tiles_mixed(big, tiles, 0, M, N, (K + GG_BK - 1) / GG_BK);
+    ggemm_schedule(tiles, groups); ggemm_schedule(big, groups, 2);
     if (prods.empty()) prods.push_back(GProd{nullptr, nullptr, 0, 0, 0, GPROD_GEMM, 0.0});
     DevBuf tab;
     PackedUpload pk;
@@ -91,7 +92,7 @@ extern "C" dmrgx_status dmrgx_dgemm_batch(int32_t count, const dmrgx_gemm_task* 
     }
     if (groups.empty()) return DMRGX_OK;
     if (prods.empty()) prods.push_back(GProd{nullptr, nullptr, 0, 0, 0, GPROD_GEMM, 0.0});
-    ggemm_schedule(tiles); ggemm_schedule(big, 2);
+    ggemm_schedule(tiles, groups); ggemm_schedule(big, groups, 2);
     DevBuf tab;
     PackedUpload pk;
     const size_t op = pk.add(prods), og = pk.add(groups), ot = pk.add(tiles), ob = pk.add(big);

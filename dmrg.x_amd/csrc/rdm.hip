@@ -627,7 +627,7 @@ static dmrgx_status rdm_create_impl(const dmrgx_sectors* left, const dmrgx_secto
     }
     if (gprods.empty()) gprods.push_back(GProd{nullptr, nullptr, 0, 0, 0, GPROD_GEMM, 0.0});
     if (ggroups.empty()) ggroups.push_back(GGroup{nullptr, 0, 0, 0, 0, 0, 0, 0});
-    ggemm_schedule(gt); ggemm_schedule(gb, 2);
+    ggemm_schedule(gt, ggroups); ggemm_schedule(gb, ggroups, 2);
     size_t o_tt = 0, o_gp = 0, o_gg = 0, o_gt = 0, o_gb = 0;
     {
         PackedUpload pk;
@@ -749,7 +749,7 @@ static dmrgx_status rdm_create_impl(const dmrgx_sectors* left, const dmrgx_secto
             DMRGX_CHK(upload(d_tt, tt, st));
             hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)tt.size()), dim3(256), 0, st, d_tt.as<TrTile>(), (const double*)buf, buf);
             DMRGX_HIP(hipGetLastError());
-            ggemm_schedule(t1); ggemm_schedule(t1b, 2); ggemm_schedule(t2); ggemm_schedule(t2b, 2);
+            ggemm_schedule(t1, g1); ggemm_schedule(t1b, g1, 2); ggemm_schedule(t2, g2); ggemm_schedule(t2b, g2, 2);
             DMRGX_CHK(upload(dp1, p1, st)); DMRGX_CHK(upload(dg1, g1, st)); DMRGX_CHK(upload(dt1, t1, st)); DMRGX_CHK(upload(db1, t1b, st));
             DMRGX_CHK(upload(dp2, p2, st)); DMRGX_CHK(upload(dg2, g2, st)); DMRGX_CHK(upload(dt2, t2, st)); DMRGX_CHK(upload(db2, t2b, st));
             DMRGX_CHK(ggemm_launch(db1.as<GTile>(), dg1.as<GGroup>(), dp1.as<GProd>(), (int32_t)t1b.size(), st, 1));
@@ -853,7 +853,7 @@ static dmrgx_status rdm_create_impl(const dmrgx_sectors* left, const dmrgx_secto
         }
         if (prods.empty()) prods.push_back(GProd{nullptr, nullptr, 0, 0, 0, GPROD_GEMM, 0.0});
         if (groups.empty()) groups.push_back(GGroup{nullptr, 0, 0, 0, 0, 0, 0, 0});
-        ggemm_schedule(gt); ggemm_schedule(gb, 2);
+        ggemm_schedule(gt, groups); ggemm_schedule(gb, groups, 2);
         DevBuf dtab;
         PackedUpload pk;
         const size_t o_p = pk.add(prods), o_g = pk.add(groups), o_t = pk.add(gt), o_b = pk.add(gb), o_c = pk.add(cn);

@@ -192,7 +192,7 @@ extern "C" dmrgx_status dmrgx_rotate_ops(const dmrgx_sectors* old_sectors, const
     const auto h1 = std::chrono::steady_clock::now();
     // stage A goes to the device before stage B's tile lists are scheduled: the host work of B (a sort over ~10^4 tiles) then
     // runs behind A's GEMMs instead of in front of an idle GPU
-    ggemm_schedule(tA); ggemm_schedule(tAb, 2);
+    ggemm_schedule(tA, groups); ggemm_schedule(tAb, groups, 2);
     const auto h2 = std::chrono::steady_clock::now();
     DevBuf dtabA, dtabB;
     PackedUpload pkA;
@@ -209,7 +209,7 @@ extern "C" dmrgx_status dmrgx_rotate_ops(const dmrgx_sectors* old_sectors, const
     DMRGX_CHK(ggemm_launch(packed_at<GTile>(dtabA, o_1), dg, dp, (int32_t)tAb.size(), st, 1));
     DMRGX_CHK(ggemm_launch(packed_at<GTile>(dtabA, o_2), dg, dp, (int32_t)tA.size(), st, 0));
     if (trace) DMRGX_HIP(hipEventRecord(ev[1], st));
-    ggemm_schedule(tB); ggemm_schedule(tBb, 2);
+    ggemm_schedule(tB, groups); ggemm_schedule(tBb, groups, 2);
     PackedUpload pkB;
     const size_t o_3 = pkB.add(tBb), o_4 = pkB.add(tB);
     DMRGX_CHK(pkB.upload(dtabB, st));

@@ -1272,7 +1272,7 @@ dmrgx_status symeig_batched(const std::vector<SymEigMat>& mats_in, hipStream_t s
     std::vector<GTile> tiles;                         // all tile lists, one after the other
     auto add_set = [&](std::vector<GTile>& big, std::vector<GTile>& small) {
         GemmSet s;
-        ggemm_schedule(big, 2); ggemm_schedule(small);
+        ggemm_schedule(big, groups, 2); ggemm_schedule(small, groups);
         s.big_off = tiles.size(); s.nbig = (int32_t)big.size(); tiles.insert(tiles.end(), big.begin(), big.end());
         s.small_off = tiles.size(); s.nsmall = (int32_t)small.size(); tiles.insert(tiles.end(), small.begin(), small.end());
         return s;
