@@ -260,6 +260,16 @@ def sweep_legs_multi(ranks, rehearsal):
     return out
 
 
+def kernel_source_hash():
+    """Identifies the build a PMC measurement belongs to: the sources of the dominant kernel and of the plan that feeds it."""
+    import hashlib
+    h = hashlib.sha256()
+    root = os.path.dirname(os.path.abspath(__file__))
+    for f in ("dmrg.x_amd/csrc/ggemm.hip", "dmrg.x_amd/csrc/ggemm.h", "dmrg.x_amd/csrc/kron_plan.hip"):
+        h.update(open(os.path.join(root, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def launch_ranks(n):
     """`python bench.py --gpus N` as a plain command: start the N rank processes ourselves (what torch.distributed.run would
     do: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT), relay rank 0's JSON line, exit with the worst return code.
@@ -358,9 +368,9 @@ def main():
     # 128-aligned cores to the 128x128 one.  Two launches of it per MatMult (stage 1, stage 2).
     launches = 2 * napp
     if info.n_tiles_big > 0:
-        kernel, avg_ms, flops_per_launch = "dmrgx::ggemm_kernel<4,2,2,4>", (ms4[0] + ms4[2]) / max(launches, 1), info.flops_alg_big / 2.0
+        kernel, avg_ms, flops_per_launch = "dmrgx::ggemm_kernel_128", (ms4[0] + ms4[2]) / max(launches, 1), info.flops_alg_big / 2.0
     else:
-        kernel, avg_ms, flops_per_launch = "dmrgx::ggemm_kernel<2,2,2,2>", (ms4[1] + ms4[3]) / max(launches, 1), info.flops_alg / 2.0
+        kernel, avg_ms, flops_per_launch = "dmrgx::ggemm_kernel_64", (ms4[1] + ms4[3]) / max(launches, 1), info.flops_alg / 2.0
     achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
     gemm_all = info.flops_alg / max((ms1 + ms2) / max(napp, 1) * 1e-3, 1e-12) / 1e12     # all four GEMM launches together
 
@@ -399,12 +409,20 @@ def main():
                      "tiles_stage1": info.n_tiles_stage1, "tiles_stage2": info.n_tiles_stage2,
                      "hbm_frac_of_peak": (info.bytes_alg + info.bytes_workspace) / max((ms1 + ms2) / max(napp, 1) * 1e-3, 1e-12) / (HBM_PEAK_TBS * 1e12)},
     }
+    # PMC-measured fabric traffic of the same command (rocprofv3 --pmc passes, tools/profile.sh -> tools/make_traffic_json.py).  It
+    # is a committed measurement, not something this run measures: it is only quoted if it was taken on THIS kernel and plan
+    # builder (hash of their sources recorded beside it), and the line says at which commit it was measured.
     traffic_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "traffic.json")
-    if os.path.exists(traffic_file):          # PMC-measured L2-miss traffic of the same command (rocprofv3 passes, tools/profile.sh)
+    if os.path.exists(traffic_file):
         t = json.load(open(traffic_file)).get(f"{args.workload}@{world}")
         if t and t.get("kernel") == kernel:
-            out["roofline"]["traffic"] = t["bytes_per_launch"]
-            out["roofline"]["traffic_source"] = t["source"]
+            if t.get("source_hash") == kernel_source_hash():
+                out["roofline"]["traffic"] = t["bytes_per_launch"]
+                out["roofline"]["traffic_source"] = t["source"]
+                out["roofline"]["traffic_measured_at_commit"] = t.get("measured_at_commit")
+            else:
+                out["roofline"]["traffic_source"] = ("profiles/traffic.json was measured on other kernel / plan sources (hash %s, running %s): not quoted; "
+                                                     "regenerate with tools/profile.sh + tools/make_traffic_json.py" % (t.get("source_hash"), kernel_source_hash()))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # two CPU statements of the same MatMult on this host: the factored, operator-merged form -- the same
         # algorithm as the HIP plan, so value / cpu_baseline.value is hardware against hardware -- and beside it the literal

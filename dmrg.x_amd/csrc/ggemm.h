@@ -41,8 +41,7 @@ dmrgx_status ggemm_launch(const GTile* d_tiles, const GGroup* d_groups, const GP
 // Host-side helper: append the tiles of group `g` (M x N) to a tile list in 8 x 8 clusters (tiles of a cluster share
 // A row-panels and B column-panels; the scheduler keeps a cluster on one XCD so they meet in its L2); `cost` (k-steps of
 // the group's product list) is stored in GTile::pad for the scheduler.
-int ggemm_cluster();   // cluster edge in tiles (default 8; DMRGX_CLUSTER overrides, developer aid)
-#define GG_CLUSTER (::dmrgx::ggemm_cluster())
+constexpr int GG_CLUSTER = 8;   // cluster edge in tiles (4 and 16 measured within 1-2 %, rounds 2 and 4)
 inline void ggemm_append_tiles(std::vector<GTile>& tiles, int32_t g, int32_t M, int32_t N, int32_t cost = 1) {
     const int32_t TM = (M + GG_BM - 1) / GG_BM, TN = (N + GG_BN - 1) / GG_BN;
     for (int32_t bm = 0; bm < TM; bm += GG_CLUSTER)
@@ -51,8 +50,6 @@ inline void ggemm_append_tiles(std::vector<GTile>& tiles, int32_t g, int32_t M, 
                 for (int32_t tn = bn; tn < std::min(TN, bn + GG_CLUSTER); ++tn) tiles.push_back(GTile{g, tm, tn, cost});
 }
 
-// DMRGX_TILES=mixed routes the 128-aligned cores of the superblock plan's groups to the 128 x 128 kernel (measurement knob).
-bool ggemm_use_big_tiles();
 inline void ggemm_append_tiles_mixed(std::vector<GTile>& big, std::vector<GTile>& small, int32_t g, int32_t M, int32_t N, int32_t cost = 1, bool allow_big = true) {
     const int32_t mb = allow_big ? (M / 128) * 2 : 0, nb = allow_big ? (N / 128) * 2 : 0;   // core extent in 64-units
     for (int32_t bm = 0; bm < mb; bm += 2 * GG_CLUSTER)

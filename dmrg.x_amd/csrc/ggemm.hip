@@ -29,10 +29,12 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 #define GG_TRACE_PARAM , unsigned long long* __restrict__ trace
 #define GG_STAMP(I) { if (trace && threadIdx.x == 0) trace[(size_t)t * 8 + (I)] = __builtin_amdgcn_s_memrealtime(); }
 #define GG_STAMP_ID() { if (trace && threadIdx.x == 0) { unsigned hw, xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); trace[(size_t)t * 8 + 7] = ((unsigned long long)xcc << 32) | hw; } }
+#define GG_TRACE_FWD , trace
 #define GG_CLK0() unsigned long long clk0_ = __builtin_amdgcn_s_memtime();
 #define GG_CLK1() { if (trace && threadIdx.x == 0) trace[(size_t)t * 8 + 6] = __builtin_amdgcn_s_memtime() - clk0_; }   /* shader cycles of the k-step stream */
 #else
 #define GG_TRACE_PARAM
+#define GG_TRACE_FWD
 #define GG_STAMP(I)
 #define GG_STAMP_ID()
 #define GG_CLK0()
@@ -69,27 +71,35 @@ __device__ __forceinline__ GProd kload(kprod_ptr p, int i)
 // ds_read_b64: within a 32-lane pass the addresses i*18 + {k, k+1}, i < 16, cover every 8-byte bank pair once; an odd
 // stride always collides for one (i, i') pair, measured 20 % conflict cycles at 17), B rows BN+16 doubles apart.
 
-// Workgroup -> tiles: a launch has G = min(ntiles, slots of the chip) RESIDENT workgroups; workgroup w walks the list entries
-// w, w + G, w + 2G, ... (its own tile list, laid out by the host: ggemm_schedule) until the first entry with group < 0.  Blocks
-// b, b+8, b+16, ... -- the workgroups the dispatcher deals to one XCD -- own that XCD's cost-balanced, locality-clustered lists.
+// Workgroup -> tiles: a launch has G = min(ntiles, workgroup slots of the chip) RESIDENT workgroups.  The scheduled list is eight
+// interleaved per-XCD queues (entry i belongs to XCD i & 7: blocks b, b+8, b+16, ... are the workgroups the dispatcher deals to one
+// XCD; ggemm_schedule balances the queues and keeps a cluster's tiles next to each other); workgroup b starts on entry b and then
+// claims the further entries of its XCD's queue, in order, with an atomic counter.
 //
 // Why resident workgroups (round 4; tools/tile_trace.sh on cfg4real, profiles/r04_tile_trace_before.txt): with one workgroup per
 // tile a stage-1 launch kept 3.60 of 4 workgroup slots per CU occupied (7.5 % of the slot time lay between the end of one
-// workgroup and the start of the next on the same CU: same-length tiles of a cluster end together and the dispatcher refills the
-// slots one after the other, median 1.8 us, p90 16.6 us) and a resident workgroup spent 13.6 % of its time outside the k-step
-// stream (descriptor chain 1.2 us, first operands 1.6 us, scaled copies 2.4 us, stores 3.0 us per 52 us tile), so only 3.12
-// workgroups per CU were feeding the MFMA pipe; the k-step itself runs at the pipe's limit (1.95 us for a full tile with four
-// streams on the CU).  A resident workgroup (a) is never re-dispatched, (b) has the next tile's descriptors in SGPRs a whole
-// tile ahead, and (c) issues the next tile's first operand loads in the LAST k-step of the current tile, so that the switch
-// costs the epilogue only.
-
+// workgroup and the start of the next on the same CU: the dispatcher refills slots in order, median 1.8 us, p90 16.6 us) and a
+// resident workgroup spent 13.6 % of its time outside the k-step stream (descriptor chain 1.2 us, first operands 1.6 us, scaled
+// copies 2.4 us, stores 3.0 us per 52 us tile), so only 3.12 workgroups per CU were feeding the MFMA pipe.  A resident workgroup
+// (a) is never re-dispatched, (b) claims its next tile while its loader has already left the current one (the last two k-steps
+// hide the atomic), (c) fetches the next tile's first two k-steps beside the current tile's output stores.  What the measurements
+// on the way taught (profiles/r04_tile_trace_*.txt, DESIGN.md K1 "Round 4"):
+//   * the claim must be LATE.  Claimed at the start of the current tile (a whole tile ahead), the tiles of an 8 x 8 cluster started
+//     over 77-120 us instead of 30 us, i.e. at different positions of the shared panels, and the L2 hit rate fell from 82 % to 66 %
+//     (FETCH_SIZE 2.1 x): the in-order dispatcher of the old scheme had kept them together for free;
+//   * spilled registers thrash the L2: 27 spilled dwords are 7 KB per wave, 3.5 MB per XCD -- the size of its L2.  This kernel
+//     spills nothing (see the staging registers and GG_LANES);
+//   * the chip holds ~2.05 GHz under this load: cycles saved in the stream come back partly as a lower clock.
+//
 // TR x TC v_mfma_f64_16x16x4 accumulators per wave, WR x WC waves per workgroup: tile (16 TR WR) x (16 TC WC).
 //   <2,2,2,2>:  64 x  64 tile, 256 threads, 4 workgroups per CU -- ragged remainders and small sectors
 //   <4,2,2,4>: 128 x 128 tile, 512 threads, 2 workgroups per CU -- same 4 waves per SIMD, half the L2->LDS bytes
 //                                                                 per flop, 64 accumulator registers per wave
-template <int TR, int TC, int WR, int WC>
-__global__ void __launch_bounds__(64 * WR * WC, 4)
-ggemm_kernel(const GTile* __restrict__ tiles_, const GGroup* __restrict__ groups_, const GProd* __restrict__ prods_, int ntiles, int* __restrict__ ctr GG_TRACE_PARAM)
+//   DEEP: the loader runs two k-steps ahead through hand-managed staging registers (see GG_GLOAD_D); else one k-step ahead through
+//         ordinary variables (the 128 x 128 shape has no 32 registers to spare for a second staging set)
+template <int TR, int TC, int WR, int WC, bool DEEP>
+__device__ __forceinline__ void
+ggemm_body(const GTile* __restrict__ tiles_, const GGroup* __restrict__ groups_, const GProd* __restrict__ prods_, int ntiles, int* __restrict__ ctr GG_TRACE_PARAM)
 {
     const ktile_ptr tiles = (ktile_ptr)tiles_;
     const kgroup_ptr groups = (kgroup_ptr)groups_;
@@ -103,15 +113,18 @@ ggemm_kernel(const GTile* __restrict__ tiles_, const GGroup* __restrict__ groups
     constexpr int BROWS = THREADS / BN;  // B rows covered per pass
     constexpr int NB = BK / BROWS;       // B elements per thread per k-step
     constexpr bool RELAYOUT = (TR == 2 && TC == 2 && WR == 2 && WC == 2);   // thin edge tiles: blocks dealt over all four waves
-    __shared__ double As[2][BM * AS_LD];
-    __shared__ double Bs[2][BK * BS_LD];
+    // LDS is DYNAMIC (size passed at launch: ggemm_lds_bytes): with a static size the compiler sees that LDS holds the kernel to
+    // four waves per SIMD anyway and hands the register allocator all 128 registers, staging registers included
+    extern __shared__ double gg_smem[];
+    double (*As)[BM * AS_LD] = (double (*)[BM * AS_LD])gg_smem;
+    double (*Bs)[BK * BS_LD] = (double (*)[BK * BS_LD])(gg_smem + 2 * BM * AS_LD);
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index in an SGPR
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index in an SGPR
     // Work distribution: the list is eight interleaved per-XCD queues (entry i belongs to XCD i & 7; the host balances the queues).
     // Workgroup b starts on entry b and then claims the further entries of its XCD's queue, in order, with an atomic counter
     // (ctr[0..7], all zero at launch and reset by the last workgroup to leave; ctr[8] counts the leavers).  The claim for the NEXT
     // tile is issued at the start of the current one and read after its k-step stream, so its latency is never waited for.
-    __shared__ int sh_next;
+    int& sh_next = *(int*)(gg_smem + 2 * BM * AS_LD + 2 * BK * BS_LD);
     const int G = gridDim.x;
     const bool dyn = ntiles > G;                   // (else every entry has its own workgroup)
     const int xcd = blockIdx.x & 7, qbase = G >> 3;
@@ -123,9 +136,6 @@ ggemm_kernel(const GTile* __restrict__ tiles_, const GGroup* __restrict__ groups
     }
     GGroup g = kload(groups, tl.group);
     const GTile tl_none = GTile{-1, 0, 0, 0};
-#ifdef DMRGX_STAGGER
-    if (dyn) for (int i = ((blockIdx.x >> 3) & 63) * DMRGX_STAGGER; i > 0; --i) __builtin_amdgcn_s_sleep(8);   // experiment: ~250 ns per step
-#endif
     // Per-lane constants.  Only the two LDS store bases (and, per tile, the two fragment bases) are kept in registers across the
     // k-step stream; everything else that depends on the lane is recomputed where it is used from an OPAQUE copy of the thread
     // index (GG_LANES): left visible, the compiler computed some twenty such values once, ran out of registers and kept them in
@@ -146,12 +156,19 @@ ggemm_kernel(const GTile* __restrict__ tiles_, const GGroup* __restrict__ groups
     // Loader state: the tile whose operands are being fetched.  It runs one k-step ahead of the multiplication and therefore
     // moves on to the NEXT tile during the last k-step of the current one.
     int lm0, ln0, lmrem, lnrem;
-    unsigned aoff[NA], boff[NB];                   // per-thread byte offsets inside the current product's panels
-    double ra[NA], rb[NB];
-    const double *cA = nullptr, *cB = nullptr;     // current product, wave-uniform -> SGPRs
+    // Two staging register sets: the loader runs TWO k-steps ahead of the multiplication (set j & 1 holds k-step j between its
+    // loads and its store into LDS buffer j & 1).  One step ahead -- rounds 1-3 -- a tile whose operands come from beyond the L2
+    // (the first tile of a cluster to touch a panel: about one tile in six, tools/tile_trace.sh) waits for every one of its loads:
+    // its k-steps took 5 300-6 000 cycles instead of 3 600.  The loads and their waits are written by hand (asm loads, counted
+    // s_waitcnt vmcnt): the compiler waits for vmcnt(0) on loads that are in flight across a loop back edge.
+    double rc_a[NA], rc_b[NB];                     // (!DEEP) the one staging set
+    const double *cA = nullptr, *cB = nullptr;     // loader's current product, wave-uniform -> SGPRs
     int clda = 0, cldb = 0, cK = 0;
-    int kz = 0;                                    // K edge of the k-step in the registers: > 0 columns below kz, < 0 columns from -kz on are zeroed
-    bool pre = false;                              // first k-step of tile `tl` already fetched (registers -> LDS buffer 0 below)
+    int lp = 0, lk = 0, lpend = 0;                 // loader position: product, k offset of the next k-step to fetch, end of the tile's products
+    bool lmore = false;                            // a k-step is left to fetch at (lp, lk)
+    int kz[2] = {0, 0};                            // K edge of the k-step in a register set: > 0 columns below kz, < 0 columns from -kz on are zeroed
+    int npre = 0;                                  // k-steps of tile `tl` already fetched into the register sets (beside the previous tile's epilogue)
+    int vm_after = 0;                              // vector-memory operations issued after the loads of register set 0 (for its counted wait)
 
 // Operand pointers come out of the task table, so the compiler would treat them as generic and emit flat_load
 // (+ lgkmcnt waits that serialise against LDS); they are global by construction -> explicit address space, and the
@@ -181,27 +198,113 @@ ggemm_kernel(const GTile* __restrict__ tiles_, const GGroup* __restrict__ groups
         _Pragma("unroll") for (int s = 0; s < NB; ++s) boff[s] = ((unsigned)min(b_k + BROWS * s, kc_) * (unsigned)cldb + (unsigned)bcol) * 8u; \
     }
 #define GG_PRODUCT(P) { const GProd pr_ = kload(prods, P); GG_PRODUCT_SET(pr_); }
-#define GG_GLOAD(KK0)                                                                         \
+// DEEP staging registers: v96 .. v127 belong to the hand-written statements below and to nothing else.  The 64 x 64 kernel is compiled
+// for five waves per SIMD, so the compiler allocates v0 .. v95 only; the statements name the staging registers literally and list
+// them as clobbers (which is also what makes the kernel's register count 128).  No C++ value ever lives in them: between an asm
+// load and the asm wait a compiler would consider such a value arrived and might copy it (live-range split, loop-head phi) while it is
+// still in flight.  tools/check_staging_regs.py scans the ISA of every build: only asm statements may touch v96 .. v127.
+#define GG_RA_0_0 "v[96:97]"
+#define GG_CA_0_0 "v96", "v97"
+#define GG_RA_0_1 "v[98:99]"
+#define GG_CA_0_1 "v98", "v99"
+#define GG_RA_0_2 "v[100:101]"
+#define GG_CA_0_2 "v100", "v101"
+#define GG_RA_0_3 "v[102:103]"
+#define GG_CA_0_3 "v102", "v103"
+#define GG_RB_0_0 "v[104:105]"
+#define GG_CB_0_0 "v104", "v105"
+#define GG_RB_0_1 "v[106:107]"
+#define GG_CB_0_1 "v106", "v107"
+#define GG_RB_0_2 "v[108:109]"
+#define GG_CB_0_2 "v108", "v109"
+#define GG_RB_0_3 "v[110:111]"
+#define GG_CB_0_3 "v110", "v111"
+#define GG_RA_1_0 "v[112:113]"
+#define GG_CA_1_0 "v112", "v113"
+#define GG_RA_1_1 "v[114:115]"
+#define GG_CA_1_1 "v114", "v115"
+#define GG_RA_1_2 "v[116:117]"
+#define GG_CA_1_2 "v116", "v117"
+#define GG_RA_1_3 "v[118:119]"
+#define GG_CA_1_3 "v118", "v119"
+#define GG_RB_1_0 "v[120:121]"
+#define GG_CB_1_0 "v120", "v121"
+#define GG_RB_1_1 "v[122:123]"
+#define GG_CB_1_1 "v122", "v123"
+#define GG_RB_1_2 "v[124:125]"
+#define GG_CB_1_2 "v124", "v125"
+#define GG_RB_1_3 "v[126:127]"
+#define GG_CB_1_3 "v126", "v127"
+#define GG_ZT_0_0 "v_cndmask_b32_e64 v96, v96, 0, %0\n\tv_cndmask_b32_e64 v97, v97, 0, %0"
+#define GG_ZT_0_1 "v_cndmask_b32_e64 v98, v98, 0, %0\n\tv_cndmask_b32_e64 v99, v99, 0, %0"
+#define GG_ZT_0_2 "v_cndmask_b32_e64 v100, v100, 0, %0\n\tv_cndmask_b32_e64 v101, v101, 0, %0"
+#define GG_ZT_0_3 "v_cndmask_b32_e64 v102, v102, 0, %0\n\tv_cndmask_b32_e64 v103, v103, 0, %0"
+#define GG_ZT_1_0 "v_cndmask_b32_e64 v112, v112, 0, %0\n\tv_cndmask_b32_e64 v113, v113, 0, %0"
+#define GG_ZT_1_1 "v_cndmask_b32_e64 v114, v114, 0, %0\n\tv_cndmask_b32_e64 v115, v115, 0, %0"
+#define GG_ZT_1_2 "v_cndmask_b32_e64 v116, v116, 0, %0\n\tv_cndmask_b32_e64 v117, v117, 0, %0"
+#define GG_ZT_1_3 "v_cndmask_b32_e64 v118, v118, 0, %0\n\tv_cndmask_b32_e64 v119, v119, 0, %0"
+#define GG_LD1(OP, SET, S, OFFV, BASE, BREG) asm volatile("global_load_dwordx2 " GG_R##OP##_##SET##_##S ", %0, %1" : : "v"(OFFV), BREG(BASE) : "memory", GG_C##OP##_##SET##_##S)
+#define GG_ST1(OP, SET, S, ADDR, OFFS) asm volatile("ds_write_b64 %0, " GG_R##OP##_##SET##_##S " offset:%1" : : "v"(ADDR), "i"(OFFS) : "memory")
+#define GG_Z1(SET, S) asm volatile(GG_ZT_##SET##_##S : : "s"(zm_) : GG_CA_##SET##_##S)
+// position of the loader after the k-step at (lp, lk)
+#define GG_LOADER_NEXT()                                                                      \
     {                                                                                         \
-        const int klast_ = cK - 1 - (KK0);                                                    \
-        const int back_ = (klast_ < BK - 1 && cK >= BK) ? BK - 1 - klast_ : 0;                \
-        kz = klast_ < BK - 1 ? (cK >= BK ? back_ : -(klast_ + 1)) : 0;                        \
-        gbptr A_ = (gbptr)(cA + (size_t)lm0 * clda + ((KK0) - back_));                        \
-        gbptr B_ = (gbptr)(cB + (size_t)((KK0) - back_) * cldb + ln0);                        \
-        _Pragma("unroll") for (int s = 0; s < NA; ++s) ra[s] = *(gptr)(A_ + aoff[s]);         \
-        _Pragma("unroll") for (int s = 0; s < NB; ++s) rb[s] = *(gptr)(B_ + boff[s]);         \
+        lk += BK;                                                                             \
+        if (lk >= cK) { ++lp; lk = 0; if (lp < lpend) GG_PRODUCT(lp); }                       \
+        lmore = lp < lpend;                                                                   \
     }
-#define GG_LSTORE(BUF)                                                                        \
+#define GG_LOADER_BASES()                                                                     \
+        const int klast_ = cK - 1 - lk;                                                       \
+        const int back_ = (klast_ < BK - 1 && cK >= BK) ? BK - 1 - klast_ : 0;                \
+        const int kz_ = klast_ < BK - 1 ? (cK >= BK ? back_ : -(klast_ + 1)) : 0;             \
+        gbptr A_ = (gbptr)(cA + (size_t)lm0 * clda + (lk - back_));                           \
+        gbptr B_ = (gbptr)(cB + (size_t)(lk - back_) * cldb + ln0);
+// (DEEP) fetch the k-step at the loader's position into register set SET (8 asm loads, nothing waits), then move the loader on
+#define GG_GLOAD_D(SET)                                                                       \
     {                                                                                         \
-        if (kz != 0) {                                                                        \
+        static_assert(!DEEP || (NA == 4 && NB == 4), "staging register table");               \
+        GG_LOADER_BASES();                                                                    \
+        kz[SET] = kz_;                                                                        \
+        GG_LD1(A, SET, 0, aoff[0], A_, "{s[96:97]}"); GG_LD1(A, SET, 1, aoff[1 % NA], A_, "{s[96:97]}");   \
+        GG_LD1(A, SET, 2, aoff[2 % NA], A_, "{s[96:97]}"); GG_LD1(A, SET, 3, aoff[3 % NA], A_, "{s[96:97]}");   \
+        GG_LD1(B, SET, 0, boff[0], B_, "{s[98:99]}"); GG_LD1(B, SET, 1, boff[1 % NB], B_, "{s[98:99]}");   \
+        GG_LD1(B, SET, 2, boff[2 % NB], B_, "{s[98:99]}"); GG_LD1(B, SET, 3, boff[3 % NB], B_, "{s[98:99]}");   \
+        GG_LOADER_NEXT();                                                                     \
+    }
+// all but the N youngest vector-memory operations of the wave have completed
+#define GG_VMWAIT(N) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory")
+#define GG_LSTORE_D(BUF, SET)                                                                 \
+    {                                                                                         \
+        if (kz[SET] != 0) {                                                                   \
             GG_LANES();                                                                       \
-            const bool z_ = kz > 0 ? a_k < kz : a_k >= -kz;                                   \
-            _Pragma("unroll") for (int s = 0; s < NA; ++s) ra[s] = z_ ? 0.0 : ra[s];          \
+            const unsigned long long zm_ = __builtin_amdgcn_ballot_w64(kz[SET] > 0 ? a_k < kz[SET] : a_k >= -kz[SET]);   \
+            GG_Z1(SET, 0); GG_Z1(SET, 1); GG_Z1(SET, 2); GG_Z1(SET, 3);                       \
+        }                                                                                     \
+        GG_ST1(A, SET, 0, st_a, 8 * ((BUF) * BM * AS_LD + AROWS * 0 * AS_LD)); GG_ST1(A, SET, 1, st_a, 8 * ((BUF) * BM * AS_LD + AROWS * 1 * AS_LD)); \
+        GG_ST1(A, SET, 2, st_a, 8 * ((BUF) * BM * AS_LD + AROWS * 2 * AS_LD)); GG_ST1(A, SET, 3, st_a, 8 * ((BUF) * BM * AS_LD + AROWS * 3 * AS_LD)); \
+        GG_ST1(B, SET, 0, st_b, 8 * ((BUF) * BK * BS_LD + BROWS * 0 * BS_LD)); GG_ST1(B, SET, 1, st_b, 8 * ((BUF) * BK * BS_LD + BROWS * 1 * BS_LD)); \
+        GG_ST1(B, SET, 2, st_b, 8 * ((BUF) * BK * BS_LD + BROWS * 2 * BS_LD)); GG_ST1(B, SET, 3, st_b, 8 * ((BUF) * BK * BS_LD + BROWS * 3 * BS_LD)); \
+    }
+// (!DEEP) the same through ordinary variables: one set, the compiler places the waits
+#define GG_GLOAD_C()                                                                          \
+    {                                                                                         \
+        GG_LOADER_BASES();                                                                    \
+        kz[0] = kz_;                                                                          \
+        _Pragma("unroll") for (int s = 0; s < NA; ++s) rc_a[s] = *(gptr)(A_ + aoff[s]);       \
+        _Pragma("unroll") for (int s = 0; s < NB; ++s) rc_b[s] = *(gptr)(B_ + boff[s]);       \
+        GG_LOADER_NEXT();                                                                     \
+    }
+#define GG_LSTORE_C(BUF)                                                                      \
+    {                                                                                         \
+        if (kz[0] != 0) {                                                                     \
+            GG_LANES();                                                                       \
+            const bool z_ = kz[0] > 0 ? a_k < kz[0] : a_k >= -kz[0];                          \
+            _Pragma("unroll") for (int s = 0; s < NA; ++s) rc_a[s] = z_ ? 0.0 : rc_a[s];      \
         }                                                                                     \
         _Pragma("unroll") for (int s = 0; s < NA; ++s)                                        \
-            asm volatile("ds_write_b64 %0, %1 offset:%2" : : "v"(st_a), "v"(ra[s]), "i"(8 * ((BUF) * BM * AS_LD + AROWS * s * AS_LD)) : "memory"); \
+            asm volatile("ds_write_b64 %0, %1 offset:%2" : : "v"(st_a), "v"(rc_a[s]), "i"(8 * ((BUF) * BM * AS_LD + AROWS * s * AS_LD)) : "memory"); \
         _Pragma("unroll") for (int s = 0; s < NB; ++s)                                        \
-            asm volatile("ds_write_b64 %0, %1 offset:%2" : : "v"(st_b), "v"(rb[s]), "i"(8 * ((BUF) * BK * BS_LD + BROWS * s * BS_LD)) : "memory"); \
+            asm volatile("ds_write_b64 %0, %1 offset:%2" : : "v"(st_b), "v"(rc_b[s]), "i"(8 * ((BUF) * BK * BS_LD + BROWS * s * BS_LD)) : "memory"); \
     }
 
 // MFMA fragments come from LDS through explicit ds_read_b64 with immediate offsets off two per-tile base registers
@@ -239,18 +342,26 @@ ggemm_kernel(const GTile* __restrict__ tiles_, const GGroup* __restrict__ groups
 //   k-group 3: nothing but MFMAs
 // Every fragment read of buffer BUF is issued and waited for before the barrier, so a fast wave that goes on to
 // refill BUF one step later cannot overtake a reader.  sched_barrier pins the order against the compiler's scheduler.
-#define GG_STEP(BUF, GUARD)                                                                   \
+// The claim of the workgroup's next tile: one returning atomic add by lane 0 of wave 0, under a WAVE-UNIFORM branch and with the
+// exec mask set by hand (a divergent `if (tid == 0)` inside the k-step loop makes the compiler treat the loader's scalar state as
+// divergent).  The value lands in lane 0 of `claim`; nothing waits for it here.
+#define GG_CLAIM()                                                                            \
+    asm volatile("s_mov_b64 s[94:95], exec\n\ts_mov_b64 exec, 1\n\tglobal_atomic_add %0, %1, %2, %3 sc0\n\ts_mov_b64 exec, s[94:95]" \
+                 : "=&v"(claim) : "v"(0u), "v"(1u), "{s[92:93]}"(ctr + xcd) : "memory", "s94", "s95")
+// (DEEP) k-step j on LDS buffer BUF = j & 1.  On entry register set BUF is free (k-step j was stored from it), set OTH = BUF ^ 1 holds
+// k-step j + 1 if there is one (`have1`), the loader stands at k-step j + 2.
+#define GG_STEP_D(BUF, OTH, GUARD)                                                            \
     {                                                                                         \
         constexpr int NM = TR * TC;                                                           \
         GG_FRAG_WAIT(0);                                                                      \
         GG_MFMA(0, GUARD, 0, 1);                                                              \
-        int pn = p, kn = k0 + BK;                                                             \
-        if (kn >= cK) { pn = p + 1; kn = 0; }                                                 \
-        const bool have_next = pn < pend;                                                     \
-        if (have_next && pn != p) GG_PRODUCT(pn);                                             \
+        const bool ld_ = lmore;                                                               \
         __builtin_amdgcn_sched_barrier(0);                                                    \
         GG_MFMA(0, GUARD, 1, 2);                                                              \
-        if (have_next) GG_GLOAD(kn);                                                          \
+        if (ld_) {                                                                            \
+            GG_GLOAD_D(BUF);                                                                  \
+            if (dyn && !lmore && wave == 0) GG_CLAIM();   /* the loader has left the tile: its last two k-steps hide the claim */ \
+        }                                                                                     \
         __builtin_amdgcn_sched_barrier(0);                                                    \
         GG_MFMA(0, GUARD, 2, NM - 1);                                                         \
         GG_FRAG(1, BUF, 4);                                                                   \
@@ -261,17 +372,55 @@ ggemm_kernel(const GTile* __restrict__ tiles_, const GGroup* __restrict__ groups
         GG_MFMA(1, GUARD, NM - 1, NM);                                                        \
         GG_FRAG_WAIT(0);                                                                      \
         GG_MFMA(0, GUARD, 0, 1);                                                              \
-        if (have_next) GG_LSTORE((BUF) ^ 1);                                                  \
+        if (have1) {                                                                          \
+            if (ld_ && lmore) { GG_VMWAIT(NA + NB); } else { GG_VMWAIT(0); }   /* (a claim, if issued, is waited for too) */ \
+            GG_LSTORE_D(OTH, OTH);                                                            \
+        }                                                                                     \
         __builtin_amdgcn_sched_barrier(0);                                                    \
         GG_MFMA(0, GUARD, 1, NM - 1);                                                         \
         GG_FRAG(1, BUF, 12);                                                                  \
         GG_MFMA(0, GUARD, NM - 1, NM);                                                        \
         GG_FRAG_WAIT(1);                                                                      \
         __syncthreads();                                                                      \
-        if (have_next) GG_FRAG(0, (BUF) ^ 1, 0);                                              \
+        if (have1) GG_FRAG(0, OTH, 0);                                                        \
         __builtin_amdgcn_sched_barrier(0);                                                    \
         GG_MFMA(1, GUARD, 0, NM);                                                             \
-        p = pn; k0 = kn; have = have_next;                                                    \
+        have = have1; have1 = ld_;                                                            \
+    }
+// (!DEEP) the loader one k-step ahead: k-step j + 1 is fetched in k-group 0 and stored in k-group 2 of k-step j
+#define GG_STEP_C(BUF, OTH, GUARD)                                                            \
+    {                                                                                         \
+        constexpr int NM = TR * TC;                                                           \
+        GG_FRAG_WAIT(0);                                                                      \
+        GG_MFMA(0, GUARD, 0, 1);                                                              \
+        const bool ld_ = lmore;                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        GG_MFMA(0, GUARD, 1, 2);                                                              \
+        if (ld_) {                                                                            \
+            GG_GLOAD_C();                                                                     \
+            if (dyn && !lmore && wave == 0) GG_CLAIM();                                       \
+        }                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        GG_MFMA(0, GUARD, 2, NM - 1);                                                         \
+        GG_FRAG(1, BUF, 4);                                                                   \
+        GG_MFMA(0, GUARD, NM - 1, NM);                                                        \
+        GG_FRAG_WAIT(1);                                                                      \
+        GG_MFMA(1, GUARD, 0, NM - 1);                                                         \
+        GG_FRAG(0, BUF, 8);                                                                   \
+        GG_MFMA(1, GUARD, NM - 1, NM);                                                        \
+        GG_FRAG_WAIT(0);                                                                      \
+        GG_MFMA(0, GUARD, 0, 1);                                                              \
+        if (ld_) GG_LSTORE_C(OTH);                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        GG_MFMA(0, GUARD, 1, NM - 1);                                                         \
+        GG_FRAG(1, BUF, 12);                                                                  \
+        GG_MFMA(0, GUARD, NM - 1, NM);                                                        \
+        GG_FRAG_WAIT(1);                                                                      \
+        __syncthreads();                                                                      \
+        if (ld_) GG_FRAG(0, OTH, 0);                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        GG_MFMA(1, GUARD, 0, NM);                                                             \
+        have = ld_;                                                                           \
     }
 // The k-step stream, instantiated twice: interior waves run it with every MFMA unconditional; waves on a ragged tile
 // edge run a copy whose MFMAs are guarded by wave-uniform block bounds (blocks outside the output are never multiplied).
@@ -279,13 +428,16 @@ ggemm_kernel(const GTile* __restrict__ tiles_, const GGroup* __restrict__ groups
 // per-k-step choice makes the compiler merge the accumulators with v_mov copies that wait on the MFMA results.)
 #define GG_STREAM(GUARD)                                                                      \
     while (have) {                                                                            \
-        GG_STEP(0, GUARD);                                                                    \
+        if (DEEP) { GG_STEP_D(0, 1, GUARD); } else { GG_STEP_C(0, 1, GUARD); }                \
         if (!have) break;                                                                     \
-        GG_STEP(1, GUARD);                                                                    \
+        if (DEEP) { GG_STEP_D(1, 0, GUARD); } else { GG_STEP_C(1, 0, GUARD); }                \
     }
 
     for (;;) {
         GG_STAMP(0);
+        // per-thread byte offsets inside the loader's current product's panels: variables of ONE tile iteration (set before the stream
+        // for this tile's loader, overwritten after it for the next tile's first loads), so that nothing is carried round the loop
+        unsigned aoff[NA], boff[NB];
         // ---- the tile being multiplied --------------------------------------------------------------------------
         const int m0 = tl.tm * GG_BM, n0 = tl.tn * GG_BN;            // tile coordinates are in 64-units for both shapes
         const int mrem = min(BM, g.M - m0), nrem = min(BN, g.N - n0);
@@ -306,7 +458,6 @@ ggemm_kernel(const GTile* __restrict__ tiles_, const GGroup* __restrict__ groups
             // multiplied, so ragged sector sizes cost MFMA time at 16-granularity, not at tile granularity (wave-uniform).
             tr_eff = min(TR, max(0, (mrem - wrow + 15) >> 4)); tc_eff = min(TC, max(0, (nrem - wcol + 15) >> 4));
         }
-        const bool wave_full = (tr_eff == TR) && (tc_eff == TC);
         unsigned lds_a, lds_b;
         {
             int tf = tid;
@@ -330,17 +481,39 @@ ggemm_kernel(const GTile* __restrict__ tiles_, const GGroup* __restrict__ groups
         // base advances in SGPRs, and the LDS buffer index is a compile-time constant (loop unrolled by two) so that all LDS
         // addresses are loop invariants.
         const int pend = g.prod_end;
-        int p = tl.pad >= 0 ? tl.pad : pend;       // GTile::pad: the group's first GEMM product, -1 if it has none
-        int k0 = 0;
-        bool have = p < pend;
-        if (!pre && have) {                        // first tile of the workgroup (or the tile before had no GEMM product)
+        const int p0 = tl.pad >= 0 ? tl.pad : pend;      // GTile::pad: the group's first GEMM product, -1 if it has none
+        if (npre == 0 && p0 < pend) {              // first tile of the workgroup (or the tile before had no GEMM product): fetch its first k-step(s)
             GG_LOADER_TILE(tl, g);
-            GG_PRODUCT(p);
+            lp = p0; lk = 0; lpend = pend;
+            GG_PRODUCT(lp);
             GG_STAMP(1);
-            GG_GLOAD(0);
+            vm_after = 0;
+            if (DEEP) { GG_GLOAD_D(0); npre = 1; if (lmore) { GG_GLOAD_D(1); npre = 2; vm_after = NA + NB; } }
+            else { GG_GLOAD_C(); npre = 1; }
+        } else if (lmore) {
+            GG_PRODUCT(lp);                        // (first k-steps fetched beside the previous epilogue: the offsets of the loader's product again)
+        } else {
+#pragma unroll
+            for (int s = 0; s < NA; ++s) aoff[s] = 0u;
+#pragma unroll
+            for (int s = 0; s < NB; ++s) boff[s] = 0u;
         }
-        if (have) GG_LSTORE(0);                    // (pre: the registers were filled beside the previous tile's epilogue)
-        pre = false;
+        bool have = npre >= 1, have1 = npre >= 2;
+        (void)have1;
+        if (have) {
+            if (DEEP) {
+                // register set 0 -> LDS buffer 0, after a wait that leaves the younger operations in flight: the loads of set 1 and, if
+                // the sets were filled beside the previous tile's epilogue, its output stores
+                if (vm_after == NA + NB) { GG_VMWAIT(NA + NB); }
+                else if (vm_after == NA + NB + TR * TC * 4) { GG_VMWAIT(NA + NB + TR * TC * 4); }
+                else if (vm_after == TR * TC * 4) { GG_VMWAIT(TR * TC * 4); }
+                else { GG_VMWAIT(0); }
+                GG_LSTORE_D(0, 0);
+            } else GG_LSTORE_C(0);
+        }
+        npre = 0;
+        unsigned claim = 0xffffffffu;              // (lane 0 of wave 0) counter value claimed for the next tile
+        if (dyn && have && !lmore && wave == 0) GG_CLAIM();      // (a tile so short that the stream below never fetches)
         __syncthreads();
         GG_STAMP(2);
         GG_CLK0();
@@ -361,14 +534,16 @@ gmask = __builtin_amdgcn_readfirstlane(gmask);
         // the staging registers hold nothing that is needed any more (the next tile's loads below set all of them; so does the
         // prologue of a tile that starts cold) -- said explicitly, because they are carried round the tile loop
 #pragma unroll
-        for (int s = 0; s < NA; ++s) asm volatile("" : "=v"(ra[s]));
+        for (int s = 0; s < NA; ++s) asm volatile("" : "=v"(rc_a[s]));
 #pragma unroll
-        for (int s = 0; s < NB; ++s) asm volatile("" : "=v"(rb[s]));
+        for (int s = 0; s < NB; ++s) asm volatile("" : "=v"(rc_b[s]));
         // this workgroup's next tile (claimed at the start of this one) and its descriptors: group and first product both depend
         // on the tile record only (GTile::pad = its first GEMM product); they travel while the scaled copies below are added
         int t_n = ntiles;
         if (dyn) {
-            if (tid == 0) sh_next = atomicAdd(&ctr[xcd], 1);
+            // (the claim was issued by an asm statement: the compiler does not know that `claim` may still be in flight)
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(claim) : : "memory");
+            if (tid == 0) sh_next = claim != 0xffffffffu ? (int)claim : (int)atomicAdd(&ctr[xcd], 1);      // (claimed before the end of the stream)
             __syncthreads();
             t_n = xcd + 8 * (__builtin_amdgcn_readfirstlane(sh_next) + qbase);      // entries below qbase are the starting tiles
         }
@@ -392,47 +567,105 @@ gmask = __builtin_amdgcn_readfirstlane(gmask);
         int tq = tid;
         asm volatile("" : "+v"(tq));
         const int el15 = tq & 15, el4 = (tq >> 4) & 3;
-        // (the loader's offset registers are carried round the tile loop; their old contents are dead here -- every path sets them
-        //  again before they are used -- which the compiler cannot see: overwritten with a lane-dependent dummy, they are not kept
-        //  alive, i.e. in scratch, through the scaled copies)
-#pragma unroll
-        for (int s = 0; s < NA; ++s) aoff[s] = (unsigned)tq;
-#pragma unroll
-        for (int s = 0; s < NB; ++s) boff[s] = (unsigned)tq;
         const int erow = wrow + el4, ecol = wcol + el15;               // lane's first row / column inside the tile
         int q = g.prod_begin;
         const int axpy_end = q + g.n_axpy;
         const bool full_tile = mrem == BM && nrem == BN;
-        if (TR * TC <= 4 && full_tile && q < axpy_end) {
+        if (DEEP && full_tile && q < axpy_end) {
             // full tile: row (mi, r) of the lane is a wave-uniform stride away from its first row, so the sixteen loads of a product
-            // share ONE lane offset (plus an immediate for the second block column) off sixteen scalar bases
-            double v[TR][TC][4];
-            GProd pa = kload(prods, q);
-#define GG_SLOAD(MI, PR)                                                                      \
+            // share ONE lane offset (plus an immediate for the second block column) off eight scalar bases.  The sixteen values land
+            // in the STAGING registers (v96 .. v127, idle between two streams; statements by hand as for the operands): as a C++ array
+            // they were 32 of the compiler's 96 registers and pushed the accumulators' neighbours into scratch.
+#define GG_SREG_0 "v[96:97]"
+#define GG_SCLB_0 "v96", "v97"
+#define GG_SREG_1 "v[98:99]"
+#define GG_SCLB_1 "v98", "v99"
+#define GG_SREG_2 "v[100:101]"
+#define GG_SCLB_2 "v100", "v101"
+#define GG_SREG_3 "v[102:103]"
+#define GG_SCLB_3 "v102", "v103"
+#define GG_SREG_4 "v[104:105]"
+#define GG_SCLB_4 "v104", "v105"
+#define GG_SREG_5 "v[106:107]"
+#define GG_SCLB_5 "v106", "v107"
+#define GG_SREG_6 "v[108:109]"
+#define GG_SCLB_6 "v108", "v109"
+#define GG_SREG_7 "v[110:111]"
+#define GG_SCLB_7 "v110", "v111"
+#define GG_SREG_8 "v[112:113]"
+#define GG_SCLB_8 "v112", "v113"
+#define GG_SREG_9 "v[114:115]"
+#define GG_SCLB_9 "v114", "v115"
+#define GG_SREG_10 "v[116:117]"
+#define GG_SCLB_10 "v116", "v117"
+#define GG_SREG_11 "v[118:119]"
+#define GG_SCLB_11 "v118", "v119"
+#define GG_SREG_12 "v[120:121]"
+#define GG_SCLB_12 "v120", "v121"
+#define GG_SREG_13 "v[122:123]"
+#define GG_SCLB_13 "v122", "v123"
+#define GG_SREG_14 "v[124:125]"
+#define GG_SCLB_14 "v124", "v125"
+#define GG_SREG_15 "v[126:127]"
+#define GG_SCLB_15 "v126", "v127"
+#define GG_SLD(U, OFFV, BASE, IMM) asm volatile("global_load_dwordx2 " GG_SREG_##U ", %0, %1 offset:" #IMM : : "v"(OFFV), "{s[96:97]}"(BASE) : "memory", GG_SCLB_##U)
+#define GG_SFMA(U, EL, AL) { double t_ = EL; asm volatile("v_fma_f64 %0, %1, " GG_SREG_##U ", %0" : "+v"(t_) : "s"(AL)); EL = t_; }
+#define GG_SLOAD0(PR)                                                                         \
             {                                                                                 \
                 const unsigned lo_ = ((unsigned)erow * (unsigned)(PR).ldb + (unsigned)ecol) * 8u;   \
-                _Pragma("unroll") for (int r = 0; r < 4; ++r) {                               \
-                    gbptr S_ = (gbptr)((PR).B + (size_t)(m0 + (MI) * 16 + 4 * r) * (PR).ldb + n0);   \
-                    _Pragma("unroll") for (int ni = 0; ni < TC; ++ni) v[MI][ni][r] = *(gptr)(S_ + lo_ + ni * 128); \
-                }                                                                             \
+                { gbptr S_ = (gbptr)((PR).B + (size_t)(m0 + 0 + 4 * 0) * (PR).ldb + n0); GG_SLD(0, lo_, S_, 0); GG_SLD(1, lo_, S_, 128); } \
+                { gbptr S_ = (gbptr)((PR).B + (size_t)(m0 + 0 + 4 * 1) * (PR).ldb + n0); GG_SLD(2, lo_, S_, 0); GG_SLD(3, lo_, S_, 128); } \
+                { gbptr S_ = (gbptr)((PR).B + (size_t)(m0 + 0 + 4 * 2) * (PR).ldb + n0); GG_SLD(4, lo_, S_, 0); GG_SLD(5, lo_, S_, 128); } \
+                { gbptr S_ = (gbptr)((PR).B + (size_t)(m0 + 0 + 4 * 3) * (PR).ldb + n0); GG_SLD(6, lo_, S_, 0); GG_SLD(7, lo_, S_, 128); } \
             }
-#pragma unroll
-            for (int mi = 0; mi < TR; ++mi) GG_SLOAD(mi, pa);
+#define GG_SLOAD1(PR)                                                                         \
+            {                                                                                 \
+                const unsigned lo_ = ((unsigned)erow * (unsigned)(PR).ldb + (unsigned)ecol) * 8u;   \
+                { gbptr S_ = (gbptr)((PR).B + (size_t)(m0 + 16 + 4 * 0) * (PR).ldb + n0); GG_SLD(8, lo_, S_, 0); GG_SLD(9, lo_, S_, 128); } \
+                { gbptr S_ = (gbptr)((PR).B + (size_t)(m0 + 16 + 4 * 1) * (PR).ldb + n0); GG_SLD(10, lo_, S_, 0); GG_SLD(11, lo_, S_, 128); } \
+                { gbptr S_ = (gbptr)((PR).B + (size_t)(m0 + 16 + 4 * 2) * (PR).ldb + n0); GG_SLD(12, lo_, S_, 0); GG_SLD(13, lo_, S_, 128); } \
+                { gbptr S_ = (gbptr)((PR).B + (size_t)(m0 + 16 + 4 * 3) * (PR).ldb + n0); GG_SLD(14, lo_, S_, 0); GG_SLD(15, lo_, S_, 128); } \
+            }
+#define GG_SFMA0(AL)                                                                          \
+            {                                                                                 \
+                GG_SFMA(0, acc[0][0][0], AL); \
+                GG_SFMA(1, acc[0][1][0], AL); \
+                GG_SFMA(2, acc[0][0][1], AL); \
+                GG_SFMA(3, acc[0][1][1], AL); \
+                GG_SFMA(4, acc[0][0][2], AL); \
+                GG_SFMA(5, acc[0][1][2], AL); \
+                GG_SFMA(6, acc[0][0][3], AL); \
+                GG_SFMA(7, acc[0][1][3], AL); \
+            }
+#define GG_SFMA1(AL)                                                                          \
+            {                                                                                 \
+                GG_SFMA(8, acc[1][0][0], AL); \
+                GG_SFMA(9, acc[1][1][0], AL); \
+                GG_SFMA(10, acc[1][0][1], AL); \
+                GG_SFMA(11, acc[1][1][1], AL); \
+                GG_SFMA(12, acc[1][0][2], AL); \
+                GG_SFMA(13, acc[1][1][2], AL); \
+                GG_SFMA(14, acc[1][0][3], AL); \
+                GG_SFMA(15, acc[1][1][3], AL); \
+            }
+            static_assert(!DEEP || (TR == 2 && TC == 2), "scaled-copy register table");
+            GProd pa = kload(prods, q);
+            GG_SLOAD0(pa); GG_SLOAD1(pa);
             for (; q < axpy_end; ++q) {
                 const bool more = q + 1 < axpy_end;
                 const GProd pb = more ? kload(prods, q + 1) : pa;
-#pragma unroll
-                for (int mi = 0; mi < TR; ++mi) {
-#pragma unroll
-                    for (int ni = 0; ni < TC; ++ni)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) acc[mi][ni][r] += pa.alpha * v[mi][ni][r];
-                    if (more) GG_SLOAD(mi, pb);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+                const double al = pa.alpha;
+                GG_VMWAIT(8);                       // block row 0 of product q has landed (block row 1: the 8 younger loads)
+                GG_SFMA0(al);
+                if (more) { GG_SLOAD0(pb); GG_VMWAIT(8); } else { GG_VMWAIT(0); }
+                GG_SFMA1(al);
+                if (more) GG_SLOAD1(pb);
                 pa = pb;
             }
-#undef GG_SLOAD
+#undef GG_SLOAD0
+#undef GG_SLOAD1
+#undef GG_SFMA0
+#undef GG_SFMA1
         }
         for (; q < axpy_end; ++q) {
             const GProd pr = kload(prods, q);
@@ -450,11 +683,13 @@ gmask = __builtin_amdgcn_readfirstlane(gmask);
         GG_STAMP(4);
 
         // ---- the next tile's first operands are fetched beside this tile's output stores ------------------------
+        vm_after = 0;
         if (nx && tl_n.pad >= 0) {
             GG_LOADER_TILE(tl_n, g_n);
+            lp = tl_n.pad; lk = 0; lpend = g_n.prod_end;
             GG_PRODUCT_SET(pr_n);
-            GG_GLOAD(0);
-            pre = true;
+            if (DEEP) { GG_GLOAD_D(0); npre = 1; if (lmore) { GG_GLOAD_D(1); npre = 2; vm_after = NA + NB; } }
+            else { GG_GLOAD_C(); npre = 1; }
         }
 
         // ---- epilogue ---------------------------------------------------------------------------------------
@@ -468,7 +703,9 @@ gmask = __builtin_amdgcn_readfirstlane(gmask);
 #pragma unroll
                     for (int ni = 0; ni < TC; ++ni) *(gwptr)(C + lo + ni * 128) = acc[mi][ni][r];
                 }
+            vm_after += TR * TC * 4;
         } else {
+            vm_after = -1;                        // (an unknown number of stores / loads: the next tile waits for all of them)
             char __attribute__((address_space(1)))* C = (char __attribute__((address_space(1)))*)(g.C + (size_t)m0 * g.ldc + n0);
 #pragma unroll
             for (int mi = 0; mi < TR; ++mi)
@@ -500,21 +737,26 @@ gmask = __builtin_amdgcn_readfirstlane(gmask);
 #undef GG_PRODUCT
 #undef GG_PRODUCT_SET
 #undef GG_LOADER_TILE
-#undef GG_GLOAD
-#undef GG_LSTORE
+#undef GG_GLOAD_D
+#undef GG_GLOAD_C
+#undef GG_LSTORE_D
+#undef GG_LSTORE_C
 }
 
-int ggemm_cluster()
+// (waves_per_eu(5, 5) is how the compiler is held to v0 .. v95 -- 512 / 5 rounded down to the allocation granule; with the staging
+//  registers named by the asm statements the kernel's register count is 128 and four waves per SIMD are resident, as intended.  clang's
+//  amdgpu_num_vgpr attribute is ignored by this toolchain.)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5)))
+ggemm_kernel_64(const GTile* __restrict__ tiles, const GGroup* __restrict__ groups, const GProd* __restrict__ prods, int ntiles, int* __restrict__ ctr GG_TRACE_PARAM)
 {
-    static const int c = [] { const char* e = getenv("DMRGX_CLUSTER"); const int v = e ? atoi(e) : 8; return v >= 1 && v <= 16 ? v : 8; }();
-    return c;
+    ggemm_body<2, 2, 2, 2, true>(tiles, groups, prods, ntiles, ctr GG_TRACE_FWD);
+}
+__global__ void __launch_bounds__(512, 4)
+ggemm_kernel_128(const GTile* __restrict__ tiles, const GGroup* __restrict__ groups, const GProd* __restrict__ prods, int ntiles, int* __restrict__ ctr GG_TRACE_PARAM)
+{
+    ggemm_body<4, 2, 2, 4, false>(tiles, groups, prods, ntiles, ctr GG_TRACE_FWD);
 }
 
-bool ggemm_use_big_tiles()
-{
-    const char* e = getenv("DMRGX_TILES");
-    return e && std::string(e) == "mixed";
-}
 
 // Resident workgroups of one launch: every workgroup slot of the chip (4 per CU for the 64 x 64 kernel, 2 for the 128 x 128 one).
 int ggemm_slots(int unit)
@@ -525,8 +767,7 @@ int ggemm_slots(int unit)
         (void)hipGetLastError();
         return (n / 8) * 8 > 0 ? (n / 8) * 8 : 8;
     }();
-    static const int per_cu = [] { const char* e = getenv("DMRGX_SLOTS"); const int v = e ? atoi(e) : 4; return v >= 1 && v <= 4 ? v : 4; }();   // experiment knob
-    return (unit == 2 ? (per_cu + 1) / 2 : per_cu) * cus;
+    return (unit == 2 ? 2 : 4) * cus;
 }
 
 // Cost of a tile in units of a full tile's k-step, for the balance of the per-workgroup lists (tools/tile_trace.sh, cfg4real: a full
@@ -612,8 +853,9 @@ dmrgx_status ggemm_launch(const GTile* d_tiles, const GGroup* d_groups, const GP
     });
     DMRGX_HIP(ring_err);
     int* ctr = ring + 16 * (next.fetch_add(1) % 256u);
-    if (big) hipLaunchKernelGGL((ggemm_kernel<4, 2, 2, 4>), dim3(grid), dim3(512), 0, st, d_tiles, d_groups, d_prods, ntiles, ctr GG_TRACE_ARG);
-    else hipLaunchKernelGGL((ggemm_kernel<2, 2, 2, 2>), dim3(grid), dim3(256), 0, st, d_tiles, d_groups, d_prods, ntiles, ctr GG_TRACE_ARG);
+    constexpr size_t lds64 = (2 * 64 * (GG_BK + 2) + 2 * GG_BK * (64 + 16)) * sizeof(double) + 16, lds128 = (2 * 128 * (GG_BK + 2) + 2 * GG_BK * (128 + 16)) * sizeof(double) + 16;
+    if (big) hipLaunchKernelGGL(ggemm_kernel_128, dim3(grid), dim3(512), lds128, st, d_tiles, d_groups, d_prods, ntiles, ctr GG_TRACE_ARG);
+    else hipLaunchKernelGGL(ggemm_kernel_64, dim3(grid), dim3(256), lds64, st, d_tiles, d_groups, d_prods, ntiles, ctr GG_TRACE_ARG);
     DMRGX_HIP(hipGetLastError());
     return DMRGX_OK;
 }

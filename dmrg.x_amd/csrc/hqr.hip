@@ -252,102 +252,6 @@ hqr_panel_regs_kernel(const HqrMat* __restrict__ mats, double* __restrict__ buf,
     else hqr_panel_regs_body<16>(m, buf, r0, vsm, red, Tm, sred, piv);
 }
 
-constexpr int TR_THREADS = 512, TR_WAVES = TR_THREADS / 64, TR_COLS = 64, TR_UNROLL = 8;
-
-__global__ void __launch_bounds__(TR_THREADS)
-hqr_trailing_kernel(const HqrMat* __restrict__ mats, double* __restrict__ buf, const double* __restrict__ vt, int r0)
-{
-    __shared__ double racc[TR_WAVES][16][TR_COLS];
-    __shared__ double Ts[32 * 32];
-    const HqrMat m = mats[blockIdx.y];
-    if (r0 >= m.n) return;
-    const int n = m.n, nrem = n - r0, pw = min(32, nrem), ldb = 2 * n;
-    const int nA = (n - r0 - pw + TR_COLS - 1) / TR_COLS, nI = (n + TR_COLS - 1) / TR_COLS;
-    const int t = blockIdx.x;
-    if (t >= nA + nI) return;
-    int col0, cend;
-    if (t < nA) { col0 = r0 + pw + t * TR_COLS; cend = n; }
-    else { col0 = n + (t - nA) * TR_COLS; cend = 2 * n; }
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const bool valid = col0 + lane < cend;
-    double* C = buf + m.b_off + (int64_t)r0 * ldb + (valid ? col0 + lane : col0);
-    const double keep = valid ? 1.0 : 0.0;
-    const double* V = vt + m.v_off;
-    for (int e = threadIdx.x; e < 32 * 32; e += TR_THREADS) Ts[e] = vt[m.t_off + e];
-
-    double acc[32];
-#pragma unroll
-    for (int k = 0; k < 32; ++k) acc[k] = 0.0;
-    int i = wave;
-    for (; i + (TR_UNROLL - 1) * TR_WAVES < nrem; i += TR_UNROLL * TR_WAVES) {
-        double cv[TR_UNROLL];
-#pragma unroll
-        for (int u = 0; u < TR_UNROLL; ++u) cv[u] = C[(int64_t)(i + u * TR_WAVES) * ldb] * keep;
-#pragma unroll
-        for (int u = 0; u < TR_UNROLL; ++u) {
-            const double* vr = V + (int64_t)(i + u * TR_WAVES) * 32;
-#pragma unroll
-            for (int k = 0; k < 32; ++k) acc[k] += vr[k] * cv[u];
-            asm volatile("" ::: "memory");          // one reflector row (64 SGPRs) at a time: hoisting all of them spills
-        }
-    }
-    for (; i < nrem; i += TR_WAVES) {
-        const double cv = C[(int64_t)i * ldb] * keep;
-        const double* vr = V + (int64_t)i * 32;
-#pragma unroll
-        for (int k = 0; k < 32; ++k) acc[k] += vr[k] * cv;
-    }
-    // ---- W0 = sum over the eight waves (two halves of 16 reflectors through 64 KB of LDS), then W = T^T W0 in place (as a solve)
-    double w[32];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        __syncthreads();
-#pragma unroll
-        for (int kk = 0; kk < 16; ++kk) racc[wave][kk][lane] = acc[16 * h + kk];
-        __syncthreads();
-#pragma unroll
-        for (int kk = 0; kk < 16; ++kk) {
-            double s = 0.0;
-#pragma unroll
-            for (int q = 0; q < TR_WAVES; ++q) s += racc[q][kk][lane];
-            w[16 * h + kk] = s;
-        }
-    }
-    // W = T^T W0 with T^-1 = S' (unit... S' = strict upper part of S + diag(1/tau)), i.e. forward substitution in registers:
-    // w_k = tau_k (w0_k - sum_{l<k} z_l[k] w_l); the right-looking form keeps the 32 - k updates of a step independent
-#pragma unroll
-    for (int k = 0; k < 32; ++k) {
-        w[k] *= Ts[k * 32 + k];
-#pragma unroll
-        for (int l = k + 1; l < 32; ++l) w[l] -= Ts[k * 32 + l] * w[k];
-    }
-    // ---- C -= V W
-    i = wave;
-    for (; i + (TR_UNROLL - 1) * TR_WAVES < nrem; i += TR_UNROLL * TR_WAVES) {
-        double cv[TR_UNROLL];
-#pragma unroll
-        for (int u = 0; u < TR_UNROLL; ++u) cv[u] = C[(int64_t)(i + u * TR_WAVES) * ldb];
-#pragma unroll
-        for (int u = 0; u < TR_UNROLL; ++u) {
-            const double* vr = V + (int64_t)(i + u * TR_WAVES) * 32;
-            double s = 0.0;
-#pragma unroll
-            for (int k = 0; k < 32; ++k) s += vr[k] * w[k];
-            cv[u] -= s;
-            asm volatile("" ::: "memory");
-        }
-#pragma unroll
-        for (int u = 0; u < TR_UNROLL; ++u) if (valid) C[(int64_t)(i + u * TR_WAVES) * ldb] = cv[u];
-    }
-    for (; i < nrem; i += TR_WAVES) {
-        const double cv = C[(int64_t)i * ldb];
-        const double* vr = V + (int64_t)i * 32;
-        double s = 0.0;
-#pragma unroll
-        for (int k = 0; k < 32; ++k) s += vr[k] * w[k];
-        if (valid) C[(int64_t)i * ldb] = cv - s;
-    }
-}
 
 
 // The same update on the MFMA pipe (v_mfma_f64_16x16x4): one workgroup per TM_COLS columns, eight waves.
@@ -475,15 +379,13 @@ dmrgx_status hqr_batched(const std::vector<HqrMat>& mats, const HqrMat* d_mats, 
     if (nm == 0) return DMRGX_OK;
     for (int r0 = 0; r0 < max_n; r0 += 32) {
         const int nrem = max_n - r0, pw = std::min(32, nrem);
-        static const bool valu_update = getenv("DMRGX_HQR_VALU") != nullptr;      // developer aid: the plain-FMA block-reflector update
-        const int strip = valu_update ? TR_COLS : TM_COLS;
+        const int strip = TM_COLS;
         const unsigned tiles = (unsigned)((max_n - r0 - pw + strip - 1) / strip + (max_n + strip - 1) / strip);
         bool regs = false, longp = false;                    // panels of up to HR_MAX_ROWS rows (registers) / longer ones
         for (const HqrMat& m : mats) { const int r = m.n - r0; if (r > HR_MAX_ROWS) longp = true; else if (r > 0) regs = true; }
         if (longp) hipLaunchKernelGGL(hqr_panel_kernel, dim3(nm), dim3(HQ_THREADS), 0, st, d_mats, buf, r0);
         if (regs) hipLaunchKernelGGL(hqr_panel_regs_kernel, dim3(nm), dim3(HR_THREADS), 0, st, d_mats, buf, r0);
-        if (valu_update) hipLaunchKernelGGL(hqr_trailing_kernel, dim3(tiles, nm), dim3(TR_THREADS), 0, st, d_mats, buf, (const double*)buf, r0);
-        else hipLaunchKernelGGL(hqr_trailing_mfma_kernel, dim3(tiles, nm), dim3(TM_THREADS), 0, st, d_mats, buf, (const double*)buf, r0);
+        hipLaunchKernelGGL(hqr_trailing_mfma_kernel, dim3(tiles, nm), dim3(TM_THREADS), 0, st, d_mats, buf, (const double*)buf, r0);
         DMRGX_HIP(hipGetLastError());
     }
     return DMRGX_OK;

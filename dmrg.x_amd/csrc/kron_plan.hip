@@ -255,7 +255,7 @@ struct Builder {
     std::vector<GTile> tiles1, tiles2, tiles1b, tiles2b;   // 64x64 and 128x128 lists per stage
     std::vector<int32_t> stage2_groups;
     double flops_alg = 0, flops_exec = 0, flops_alg_big = 0;
-    bool big = ggemm_use_big_tiles();
+    static constexpr bool big = false;      // 128 x 128 tiles for the 128-aligned cores + 64 x 64 remainders in launches of their own measured equal to 64 x 64 alone (rounds 2-4)
     void append_tiles(std::vector<GTile>& b, std::vector<GTile>& s64, int32_t g, int32_t M, int32_t N, int32_t cost) { ggemm_append_tiles_mixed(b, s64, g, M, N, cost, big); }
     int32_t max_split = 1;
 
@@ -280,14 +280,12 @@ struct Builder {
             const RelGroup& G = groups[g];
             total += (double)ksteps(g) * ((G.M + GG_BM - 1) / GG_BM) * ((G.N + GG_BN - 1) / GG_BN);
         }
-        static const double units = getenv("DMRGX_SPLIT_UNITS") ? atof(getenv("DMRGX_SPLIT_UNITS")) : 8192.0;
+        constexpr double units = 8192.0;      // (4 k - 32 k units, a floor of 8 - 32 k-steps and a tapered last segment all measured within +-1 %: round 2)
         // Shortest segment worth its 32 KB slab: 16 k-steps when the launch has work for every workgroup slot anyway; a small
         // superblock (m <= 512: a few thousand tile-k-steps in all) is latency-bound by its longest segment instead, so the
         // floor drops until about 1024 units exist (4 k-steps at least).
-        static const double min_seg_env = getenv("DMRGX_SPLIT_MIN") ? atof(getenv("DMRGX_SPLIT_MIN")) : 0.0;
-        const double min_seg = min_seg_env > 0.0 ? min_seg_env : std::min(16.0, std::max(4.0, total / 1024.0));
+        const double min_seg = std::min(16.0, std::max(4.0, total / 1024.0));
         const double seg_target = std::max(total / units, min_seg);
-        static const int taper = getenv("DMRGX_SPLIT_TAPER") ? atoi(getenv("DMRGX_SPLIT_TAPER")) : 0;
         const size_t ng = stage2_groups.size();
         for (size_t gi = 0; gi < ng; ++gi) {
             const int32_t g = stage2_groups[gi];
@@ -296,9 +294,8 @@ struct Builder {
             int32_t gcost = 0;
             for (int32_t p = gemm_begin; p < gemm_end; ++p) gcost += (prods[p].K + GG_BK - 1) / GG_BK;
             // Cut points of the group's GEMM stream, in k-steps: equal segments of ~seg_target.  Cuts may fall inside a
-            // product: a product is just (pointers, K), so it is split at a multiple of GG_BK.  (DMRGX_SPLIT_TAPER=1
-            // additionally cuts the last segment into 1/2, 1/4, 1/4 so that every XCD finishes on short units; measured
-            // neutral to slightly negative at cfg3-cfg5, off by default.)
+            // product: a product is just (pointers, K), so it is split at a multiple of GG_BK.  (Cutting the last
+            // segment further into 1/2, 1/4, 1/4 so that every XCD finishes on short units measured neutral to slightly negative.)
             std::vector<int32_t> cuts;
             {
                 int32_t S = (int32_t)std::min<double>(64.0, std::max(1.0, std::floor(gcost / seg_target + 0.5)));
@@ -306,10 +303,6 @@ struct Builder {
                 if (gcost < 2) S = 1;
                 S = std::min(S, gcost);
                 for (int32_t i = 1; i < S; ++i) cuts.push_back((int32_t)(((int64_t)gcost * i) / S));
-                if (taper && S > 1) {
-                    const int32_t lo = cuts.back(), r = gcost - lo;
-                    if (r >= 16) { cuts.push_back(lo + r / 2); cuts.push_back(lo + r / 2 + r / 4); }
-                }
                 cuts.push_back(gcost);
                 cuts.erase(std::unique(cuts.begin(), cuts.end()), cuts.end());
             }
@@ -460,7 +453,6 @@ extern "C" dmrgx_status dmrgx_kron_plan_create(const dmrgx_kron_desc* d, void* s
     // reference builds at src/DMRGKron.cpp:955-960), a covered left operator A_i the group  A_i (x) (sum_t a_t B_t).  Merging on
     // one side only costs min(#left, #right) groups; at a cut in the middle of a column of the J1-J2 cylinder that is 9-10 sites
     // per operator type against a cover of 8 (Koenig: maximum matching, alternating paths from the unmatched left vertices).
-    static const bool one_sided = getenv("DMRGX_MERGE_ONE_SIDED") != nullptr;      // developer aid: the round-1 rule
     std::vector<char> coverL(d->n_left_ops, 0), coverR(d->n_right_ops, 0);
     {
         std::vector<std::vector<int32_t>> adj(d->n_left_ops);
@@ -491,11 +483,6 @@ extern "C" dmrgx_status dmrgx_kron_plan_create(const dmrgx_kron_desc* d, void* s
         }
         for (int32_t l : usedL) coverL[l] = !zL[l];
         for (int32_t r : usedR) coverR[r] = zR[r];
-        if (one_sided) {
-            const bool key_right = usedR.size() <= usedL.size();
-            for (int32_t l : usedL) coverL[l] = !key_right;
-            for (int32_t r : usedR) coverR[r] = key_right;
-        }
     }
     struct Group { int32_t sA, sB; std::vector<PCell> left, rightT; };   // rightT: cells of Bhat^T
     std::vector<Group> G;

@@ -570,10 +570,8 @@ static dmrgx_status rdm_create_impl(const dmrgx_sectors* left, const dmrgx_secto
     const int64_t w_base = total; total += 2 * N;            // W = Psi^T V_L (n_R x n_L) and Psi V_R (n_L x n_R) per block
     const int64_t ew_base = total; total += use_dc ? dtot : 0;   // eigenvalues as the direct solver returns them (ascending)
     // warm start: per matrix with a previous eigenbasis E (rows), W = E A and E^T (n x n each)
-    // QR preconditioner (default on; DMRGX_RDM_QR=0 restores the plain / caller-warm-started solver for comparison): its
-    // basis replaces the caller's v0_rows, which then only remain a hint
-    static const bool want_qr = !(getenv("DMRGX_RDM_QR") && atoi(getenv("DMRGX_RDM_QR")) == 0);
-    const bool use_qr = want_qr && !use_dc;
+    // QR preconditioner of the Jacobi path: its basis replaces the caller's v0_rows, which then only remain a hint
+    const bool use_qr = !use_dc;
     std::vector<const double*> warm_src(nm, nullptr);
     std::vector<HqrMat> qmats(nm, HqrMat{0, 0, 0, 0, 0});
     std::vector<int64_t> qe_off(nm, 0), qperm_off(nm, 0);
@@ -652,29 +650,6 @@ static dmrgx_status rdm_create_impl(const dmrgx_sectors* left, const dmrgx_secto
         DMRGX_HIP(hipGetLastError());
         DMRGX_CHK(ggemm_launch(packed_at<GTile>(P->d_tables, o_gb), packed_at<GGroup>(P->d_tables, o_gg), packed_at<GProd>(P->d_tables, o_gp), (int32_t)gb.size(), st, 1));
         DMRGX_CHK(ggemm_launch(packed_at<GTile>(P->d_tables, o_gt), packed_at<GGroup>(P->d_tables, o_gg), packed_at<GProd>(P->d_tables, o_gp), (int32_t)gt.size(), st, 0));
-    }
-
-    if (const char* dump = getenv("DMRGX_RDM_DUMP")) {      // developer aid: the density matrices of one call, for offline convergence studies
-        static int call = 0;
-        const char* which = getenv("DMRGX_RDM_DUMP_CALL");
-        if (call++ == (which ? atoi(which) : 0)) {
-            if (FILE* f = fopen(dump, "wb")) {
-                const int minn = getenv("DMRGX_RDM_DUMP_MINN") ? atoi(getenv("DMRGX_RDM_DUMP_MINN")) : 0;
-                int32_t hdr = 0;
-                for (int mi = 0; mi < nm; ++mi) hdr += P->mats[mi].n >= minn;
-                fwrite(&hdr, 4, 1, f);
-                for (int mi = 0; mi < nm; ++mi) {
-                    const MatDesc& m = P->mats[mi];
-                    if (m.n < minn) continue;
-                    std::vector<double> h((size_t)m.npad * m.npad);
-                    if (!h.empty()) DMRGX_HIP(hipMemcpy(h.data(), buf + m.a_off, h.size() * sizeof(double), hipMemcpyDeviceToHost));
-                    int32_t d[2] = {m.n, m.npad};
-                    fwrite(d, 4, 2, f);
-                    fwrite(h.data(), sizeof(double), h.size(), f);
-                }
-                fclose(f);
-            }
-        }
     }
 
     stage("gram");
@@ -803,8 +778,7 @@ static dmrgx_status rdm_create_impl(const dmrgx_sectors* left, const dmrgx_secto
             }
             // apply round r (A_cur -> A_next, V in place) and, beside it, solve the sub-problems of the round after it
             const int r_next = (r + 1 == rounds) ? 0 : r + 1;
-            static const bool cross_visits = !(getenv("DMRGX_JACOBI_CROSS") && atoi(getenv("DMRGX_JACOBI_CROSS")) == 0);   // developer aid: =0: every visit is a full cyclic sweep
-            const int cross_next = (cross_visits && r_next != 0) ? 1 : 0;      // the pairs inside a block: once per sweep, in its first round
+            const int cross_next = r_next != 0 ? 1 : 0;      // the pairs inside a block: once per sweep, in its first round
             hipLaunchKernelGGL(jacobi_round_kernel, dim3((unsigned)(pairs.size() + tiles.size())), dim3(SUB_THREADS), 0, st, dm, d_pairs.as<PairRef>(), (int)pairs.size(), buf, flip,
                                (const double*)rcur, (const double*)dcur, r, 1, rnext, dnext, r_next, cross_next, d_tiles.as<UpdTask>(), d_pstart.as<int32_t>());
             DMRGX_HIP(hipGetLastError());

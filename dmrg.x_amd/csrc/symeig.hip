@@ -272,7 +272,8 @@ struct TcMat {
     u64 *ybuf, *rowbuf;                               // 2 (parity) x n x 2 granules each
     int32_t n, lda, ldv, G, wg0, pad;
 };
-struct TcArgs { TcMat m[TRID_MAXM]; int32_t* status; long long* prof; int32_t nm, pad; };      // prof: developer aid (phase clocks of one workgroup), else null
+struct TcArgs { TcMat m[TRID_MAXM]; int32_t* status; long long* prof; int32_t nm, fault; };      // prof: developer aid (phase clocks of one workgroup), else null;
+                                                                                                // fault: test hook, one workgroup withholds one publication
 
 __device__ __forceinline__ void put_f64(u64* g, unsigned epoch, double v)
 {
@@ -313,6 +314,14 @@ trid_coop_kernel(const TcArgs args)
     double* svj = shc + 3 * (size_t)nv;
     double* rows = shc + TC_VECS * (size_t)nv;          // row t of this workgroup = row g + G t of the matrix
     const int cnt = g < n ? (n - g + G - 1) / G : 0;
+    // Who runs how long.  A workgroup publishes for as long as it owns a row below the pivot: rows i > j contribute y_j[i], and row j + 1
+    // is published by its owner.  The owner of row n - 1 (`glast`) therefore publishes in every column, every other workgroup needs its
+    // granule of every column, and it can never fall two columns behind unnoticed -- so it is the one that writes d, e, tau and V^T; a
+    // workgroup whose last row has become the pivot (or that has no row at all) LEAVES: it would only consume, nobody would wait for it,
+    // and a lagging pure consumer finds its double-buffered slots overwritten by epochs j + 2 / j + 3 and spins to the time-out
+    // (round 3 had workgroup 0 do the bookkeeping to the end).
+    const int glast = (n - 1) % G, ilast = cnt > 0 ? g + G * (cnt - 1) : -1;
+    if (cnt == 0) return;
     for (int t = 0; t < cnt; ++t) {
         const double* src = m.A + (int64_t)(g + G * t) * m.lda;
         for (int k = tid; k < nv; k += TC_THREADS) rows[(size_t)t * nv + k] = k < n ? src[k] : 0.0;
@@ -325,12 +334,13 @@ trid_coop_kernel(const TcArgs args)
     const bool prof = args.prof && mi == 0 && g == (G > 1 ? 1 : 0) && tid == 0;
     long long pt[4] = {0, 0, 0, 0}, pc = 0;
     for (int j = 0; j < n; ++j) {
+        if (g != glast && j >= ilast) return;                         // (uniform per workgroup) nothing left to publish: see above
         if (prof) pc = wall_clock64();
         { double* t = svp; svp = svj; svj = t; }                      // svp = v_{j-1}
         const u64* rb = m.rowbuf + (size_t)(j & 1) * 2 * n;              // row j, epoch j+1
         const u64* yb = m.ybuf + (size_t)((j + 1) & 1) * 2 * n;          // y_{j-1}, epoch j
         double s = 0.0;
-        bool ok = true;
+        bool ok = true, lap = false;
         // every granule this thread needs is requested before the first tag is looked at (TC_KB columns x 4 loads in flight), and only
         // the columns that were not there yet are asked for again
         for (int k0 = j + tid; k0 < n; k0 += TC_THREADS * TC_KB) {
@@ -352,7 +362,14 @@ trid_coop_kernel(const TcArgs args)
                     if (!(pending >> c & 1)) continue;
                     const unsigned er = (unsigned)(j + 1), ey = (unsigned)j;
                     bool ready = (unsigned)(x[c][0] >> 32) == er && (unsigned)(x[c][1] >> 32) == er;
-                    if (j > 0) ready = ready && (unsigned)(x[c][2] >> 32) == ey && (unsigned)(x[c][3] >> 32) == ey;
+                    // an epoch NEWER than the one waited for is not "not yet": the slot was overwritten, this workgroup has been lapped
+                    // -- a protocol error, reported at once instead of after 0.5 s of spinning
+                    bool lapped = (unsigned)(x[c][0] >> 32) > er || (unsigned)(x[c][1] >> 32) > er;
+                    if (j > 0) {
+                        ready = ready && (unsigned)(x[c][2] >> 32) == ey && (unsigned)(x[c][3] >> 32) == ey;
+                        lapped = lapped || (unsigned)(x[c][2] >> 32) > ey || (unsigned)(x[c][3] >> 32) > ey;
+                    }
+                    if (lapped) { ok = false; lap = true; pending = 0; break; }
                     if (!ready) continue;
                     const int k = k0 + c * TC_THREADS;
                     const double a = __longlong_as_double((long long)((x[c][0] & 0xffffffffull) | (x[c][1] << 32)));
@@ -371,9 +388,9 @@ trid_coop_kernel(const TcArgs args)
         // never repaired and the recurrence amplifies it (found the hard way: adding y.v in granule-arrival order broke Tr T = Tr A).
         for (int k = j + tid; k < n; k += TC_THREADS) s += sw[k] * svp[k];
         if (prof) { const long long c = wall_clock64(); pt[0] += c - pc; pc = c; }
-        if (!ok) sfail = 1;
+        if (!ok) sfail = lap ? 2 : 1;
         s = block_sum1<TC_WAVES>(s, red_s, tid);          // (its barrier also publishes the y and the pivot row the other threads just stored)
-        if (sfail) { if (tid == 0) __hip_atomic_store(args.status, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+        if (sfail) { if (tid == 0) __hip_atomic_store(args.status, sfail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }     // 1: timed out, 2: lapped
         const double coef = 0.5 * tau_p * tau_p * s;
         const double vpj = svp[j], wj = tau_p * sw[j] - coef * vpj;     // w_{j-1}[j], straight from y[j]: no barrier between w and the row update
         double sig = 0.0;
@@ -399,7 +416,7 @@ trid_coop_kernel(const TcArgs args)
         for (int k = j + tid; k < n; k += TC_THREADS) svj[k] = (k <= j || tj == 0.0) ? 0.0 : (k == j + 1 ? 1.0 : svj[k] * scale);     // own columns only
         __syncthreads();
         { double* t = sw; sw = sw_next; sw_next = t; }          // sw = w_{j-1} (the y buffer of this column is the w buffer of the next)
-        if (g == 0) {
+        if (g == glast) {
             double* vt = m.VT + (int64_t)j * m.ldv;
             for (int k = tid; k < n; k += TC_THREADS) vt[k] = k > j ? svj[k] : 0.0;
             if (tid == 0) { m.d[j] = dj; if (j + 1 < n) m.e[j] = beta; m.tau[j] = tj; }
@@ -443,7 +460,8 @@ trid_coop_kernel(const TcArgs args)
                 }
             }
             acc0 = wave_sum_fast(acc0); acc1 = wave_sum_fast(acc1);
-            if (lane == 0) { put_f64(ybn + 2 * (size_t)i0, (unsigned)(j + 1), acc0); if (a1) put_f64(ybn + 2 * (size_t)i1, (unsigned)(j + 1), acc1); }
+            const bool withhold = args.fault && mi == 0 && j == 3 && i0 == n - 1;      // (test hook: the last row's y_3 never arrives -> every partner times out)
+            if (lane == 0 && !withhold) { put_f64(ybn + 2 * (size_t)i0, (unsigned)(j + 1), acc0); if (a1) put_f64(ybn + 2 * (size_t)i1, (unsigned)(j + 1), acc1); }
         }
         if (prof) { const long long c = wall_clock64(); pt[2] += c - pc; pc = c; }
         __syncthreads();
@@ -615,95 +633,8 @@ __global__ void __launch_bounds__(DC_LEAF_THREADS) dc_leaf_kernel(const DcMat* _
     for (int e = tid; e < p * p; e += DC_LEAF_THREADS) { const int i = e / p, c = e % p; Q[(int64_t)(lf.lo + i) * ldq + lf.lo + rnk[c]] = R[i][c]; }
 }
 
-// Leaf, second form (round 3, behind DMRGX_LEAF=ql): implicit-shift QL iteration on the tridiagonal leaf itself, ONE WAVE per leaf and no
-// barrier.  The rotation recurrence (a chain of ~900 dependent plane rotations for a leaf of 32) is computed redundantly by every
-// lane -- uniform values, uniform branches -- and lane k applies each rotation to row k of the eigenvector array in LDS, holding
-// the column it will touch again in a register (one LDS read and one write per rotation and lane).  The Jacobi leaf above spends
-// its time in ~600 workgroup barriers; this one in the latency of the rotation recurrence -- measured the same 250 us.
-__global__ void __launch_bounds__(64) dc_leaf_ql_kernel(const DcMat* __restrict__ mats, const DcLeaf* __restrict__ leaves)
-{
-    constexpr int P = DC_LEAF;
-    __shared__ double Z[P][P + 1];
-    __shared__ double D[P + 1], E[P + 1];
-    const DcLeaf lf = leaves[blockIdx.x];
-    const DcMat m = mats[lf.mat];
-    const int p = lf.hi - lf.lo, k = threadIdx.x;
-    const double inv = 1.0 / m.scale[0];
-    if (k < P) {
-        for (int c = 0; c < P; ++c) Z[k][c] = k == c ? 1.0 : 0.0;
-        double dv = 0.0, ev = 0.0;
-        if (k < p) {
-            dv = m.d[lf.lo + k] * inv;
-            if (k == 0 && lf.lo > 0) dv -= fabs(m.e[lf.lo - 1] * inv);
-            if (k == p - 1 && lf.hi < m.n) dv -= fabs(m.e[lf.hi - 1] * inv);
-            if (k + 1 < p) ev = m.e[lf.lo + k] * inv;
-        }
-        D[k] = dv; E[k] = ev;
-    }
-    if (k == 0) { D[P] = 0.0; E[P] = 0.0; }
-    __syncthreads();                                   // (one wave: orders the initialisation, costs nothing)
-    const bool mine = k < p;
-    bool failed = false;
-    for (int l = 0; l < p; ++l) {
-        for (int iter = 0;; ++iter) {
-            int mm = l;
-            for (; mm < p - 1; ++mm) { const double dd = fabs(D[mm]) + fabs(D[mm + 1]); if (fabs(E[mm]) <= 1.1102230246251565e-16 * dd) break; }
-            if (mm == l) break;
-            if (iter >= 80) { failed = true; break; }
-            double g = (D[l + 1] - D[l]) / (2.0 * E[l]);
-            double r = sqrt(g * g + 1.0);
-            g = D[mm] - D[l] + E[l] / (g + (g >= 0.0 ? r : -r));
-            double s = 1.0, c = 1.0, pp = 0.0;
-            double zhold = mine ? Z[k][mm] : 0.0;              // column i + 1 of this lane's row, carried from rotation to rotation
-            double dhold = D[mm];                              // D[i + 1], likewise (nobody else touches it between two rotations)
-            bool underflow = false;
-            // operands of rotation i are loaded one rotation ahead: the dependent chain is arithmetic only
-            double ei = E[mm - 1], di = D[mm - 1], zi = mine ? Z[k][mm - 1] : 0.0;
-            for (int i = mm - 1; i >= l; --i) {
-                const int in = i > l ? i - 1 : i;
-                const double en = E[in], dn = D[in], zn = mine ? Z[k][in] : 0.0;
-                const double f = s * ei, b = c * ei;
-                const double rr = f * f + g * g;
-                if (rr == 0.0) { E[i + 1] = 0.0; D[i + 1] = dhold - pp; E[mm] = 0.0; underflow = true; if (mine) Z[k][i + 1] = zhold; break; }
-                double rinv = __builtin_amdgcn_rsq(rr);            // 1 / sqrt(rr), refined to full precision (two Newton steps)
-                rinv = rinv * (1.5 - 0.5 * rr * rinv * rinv);
-                rinv = rinv * (1.5 - 0.5 * rr * rinv * rinv);
-                E[i + 1] = rr * rinv;
-                s = f * rinv; c = g * rinv;
-                g = dhold - pp;
-                r = (di - g) * s + 2.0 * c * b;
-                pp = s * r;
-                D[i + 1] = g + pp;
-                g = c * r - b;
-                if (mine) Z[k][i + 1] = s * zi + c * zhold;
-                zhold = c * zi - s * zhold;
-                dhold = di;
-                ei = en; di = dn; zi = zn;
-            }
-            if (underflow) continue;
-            if (mine) Z[k][l] = zhold;
-            D[l] = dhold - pp; E[l] = g; E[mm] = 0.0;
-        }
-        if (failed) break;
-    }
-    // (80 iterations on one eigenvalue do not happen -- LAPACK allows 30 n in total; if they ever do, the spectrum is poisoned so that
-    //  the caller's truncation fails visibly instead of using half-converged vectors)
-    if (failed && k < p) D[k] = __longlong_as_double(0x7ff8000000000000ll);
-    __syncthreads();
-    // ascending order
-    int rk = 0;
-    if (mine) {
-        const double v = D[k];
-        for (int q = 0; q < p; ++q) { const double u = D[q]; rk += (u < v) || (u == v && q < k); }
-        m.dcur[lf.lo + rk] = v;
-    }
-    __shared__ int rnk[P];
-    if (mine) rnk[k] = rk;
-    __syncthreads();
-    double* Q = m.Q[lf.buf];
-    const int ldq = m.ldq[lf.buf];
-    for (int e = k; e < p * p; e += 64) { const int i = e / p, c = e % p; Q[(int64_t)(lf.lo + i) * ldq + lf.lo + rnk[c]] = Z[i][c]; }
-}
+// (A one-wave implicit-QL leaf -- no barrier at all, the rotation recurrence redundantly in every lane -- was measured in round 3 and ran
+//  the same 250 us per call as the Jacobi leaf above; it is not part of the library.)
 
 // Deflation of one merge (LAPACK dlaed2 in this solver's data flow): z from the children's boundary rows, poles ranked by brute-
 // force counting (no sortedness assumed), type-1 (rho |z_i| tiny) and type-2 (two close poles: one Givens rotation moves the
@@ -1195,7 +1126,7 @@ dmrgx_status symeig_batched(const std::vector<SymEigMat>& mats_in, hipStream_t s
         // x row length) -- down to `rows_floor` rows per workgroup: the launch lasts as long as its longest chain, a workgroup's row pass
         // is one link of every column of it, and among few workgroups more partners cost the all-gather almost nothing.  (Small m: a dozen
         // matrices of n <= 300 on 256 CUs go from 75 to 8-16 rows per workgroup: 888 -> 672 us per call at m = 512.)
-        static const int rows_floor = [] { const char* e = getenv("DMRGX_TRID_ROWS"); const int v = e ? atoi(e) : 8; return v < 1 ? 1 : v; }();
+        constexpr int rows_floor = 8;      // (4 and 2 rows per workgroup measured flat, round 3)
         std::vector<int> Gmin(nm, 0), Gof(nm, 0);
         {
             int64_t used = 0;
@@ -1245,7 +1176,11 @@ dmrgx_status symeig_batched(const std::vector<SymEigMat>& mats_in, hipStream_t s
             hmark("func attribute");
             for (const Round& r : rounds) {
                 TcArgs ta;
-                ta.status = reinterpret_cast<int32_t*>(GB); ta.nm = (int32_t)r.mats.size(); ta.pad = 0;
+                ta.status = reinterpret_cast<int32_t*>(GB); ta.nm = (int32_t)r.mats.size();
+                // test hook (tests/test_gpu_kron.py: the time-out -> launch-per-column transition, once): the first persistent round of the process
+                // loses one publication
+                static bool fault_pending = getenv("DMRGX_TRID_FAULT") != nullptr;
+                ta.fault = fault_pending ? 1 : 0; fault_pending = false;
                 ta.prof = getenv("DMRGX_TRID_PROF") ? reinterpret_cast<long long*>(B + ws[r.mats[0]].y) : nullptr;      // (the y scratch of the launch path is idle here)
                 size_t lds = 0;
                 int wg0 = 0;
@@ -1419,57 +1354,11 @@ dmrgx_status symeig_batched(const std::vector<SymEigMat>& mats_in, hipStream_t s
         DMRGX_HIP(hipStreamSynchronize(st));
         hmark("trid done (sync)");
         if (coop_status != 0) {
-            if (!g_coop_disabled) fprintf(stderr, "[dmrgx] persistent tridiagonalisation timed out waiting for a partner workgroup (GPU shared with another "
-                                                  "persistent kernel?): using one launch per column from now on\n");
+            if (!g_coop_disabled) fprintf(stderr, coop_status == 2 ? "[dmrgx] persistent tridiagonalisation: a workgroup was lapped by its partners (protocol error): using one launch per column from now on\n"
+                                                                    : "[dmrgx] persistent tridiagonalisation timed out waiting for a partner workgroup (GPU shared with another "
+                                                                      "persistent kernel?): using one launch per column from now on\n");
             g_coop_disabled = true;
             DMRGX_CHK(trid_by_launches(coop_set));     // A was only read by the persistent kernel
-        }
-        if (const char* dir = getenv("DMRGX_TRID_DUMP")) {      // developer aid: A, d, e of the largest matrix of the second call, for offline checks
-            static int call = 0;
-            if (call++ == 1 && !coop_set.empty()) {
-                const int q = coop_set[0];
-                const int64_t n = M[q].n;
-                std::vector<double> hA((size_t)n * M[q].lda), hd((size_t)2 * n);
-                DMRGX_HIP(hipMemcpy(hA.data(), M[q].A, hA.size() * 8, hipMemcpyDeviceToHost));
-                DMRGX_HIP(hipMemcpy(hd.data(), B + ws[q].d, (size_t)n * 8, hipMemcpyDeviceToHost));
-                DMRGX_HIP(hipMemcpy(hd.data() + n, B + ws[q].e, (size_t)n * 8, hipMemcpyDeviceToHost));
-                const std::string fn = std::string(dir) + "/trid_dump.bin";
-                if (FILE* f = fopen(fn.c_str(), "wb")) {
-                    const int64_t hdr[2] = {n, M[q].lda};
-                    fwrite(hdr, 8, 2, f); fwrite(hA.data(), 8, hA.size(), f); fwrite(hd.data(), 8, hd.size(), f);
-                    fclose(f);
-                }
-            }
-        }
-        if (getenv("DMRGX_TRID_CHECK")) {             // developer aid: the same matrices through the launch-per-column kernel, d / e / tau compared
-            for (int q : coop_set) {
-                const int64_t n = M[q].n;
-                DevBuf a2, w2;
-                DMRGX_CHK(a2.alloc((size_t)n * M[q].lda * sizeof(double)));
-                DMRGX_CHK(w2.alloc((size_t)(n * n + 6 * n) * sizeof(double)));
-                DMRGX_HIP(hipMemcpyAsync(a2.p, M[q].A, (size_t)n * M[q].lda * sizeof(double), hipMemcpyDeviceToDevice, st));
-                double* W2 = w2.as<double>();
-                TridArgs ta;
-                for (int i = 0; i < TRID_MAXM; ++i) ta.m[i] = TridMat{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0};
-                ta.m[0] = TridMat{a2.as<double>(), W2, W2 + n * n, W2 + n * n + 2 * n, W2 + n * n + 3 * n, W2 + n * n + 4 * n, (int32_t)n, M[q].lda, (int32_t)n, 0};
-                const size_t lds = (size_t)3 * n * sizeof(double);
-                DMRGX_CHK(set_dyn_lds(trid_step_kernel, lds));
-                for (int j = 0; j < n; ++j) hipLaunchKernelGGL(trid_step_kernel, dim3((unsigned)((n + TRID_ROWS - 1) / TRID_ROWS), 1), dim3(TRID_THREADS), lds, st, ta, j);
-                std::vector<double> h1((size_t)3 * n), h2((size_t)3 * n);
-                DMRGX_HIP(hipMemcpy(h1.data(), B + ws[q].d, (size_t)n * 8, hipMemcpyDeviceToHost));
-                DMRGX_HIP(hipMemcpy(h1.data() + n, B + ws[q].e, (size_t)n * 8, hipMemcpyDeviceToHost));
-                DMRGX_HIP(hipMemcpy(h1.data() + 2 * n, B + ws[q].tau, (size_t)n * 8, hipMemcpyDeviceToHost));
-                DMRGX_HIP(hipMemcpy(h2.data(), W2 + n * n + 2 * n, (size_t)3 * n * 8, hipMemcpyDeviceToHost));
-                double worst = 0.0; int first = -1;
-                for (int64_t i = 0; i < 3 * n; ++i) {
-                    if (i % n == n - 1 && i / n == 1) continue;      // e[n-1] does not exist
-                    const double df = fabs(h1[(size_t)i] - h2[(size_t)i]);
-                    if (df > worst) worst = df;
-                    if (first < 0 && df > 1e-9) first = (int)i;
-                }
-                fprintf(stderr, "[trid-check] n=%lld max |d,e,tau (persistent) - (launches)| = %.3e%s", (long long)n, worst, first < 0 ? "\n" : "");
-                if (first >= 0) fprintf(stderr, "  first mismatch: %s[%d] %.15g vs %.15g\n", first / n == 0 ? "d" : first / n == 1 ? "e" : "tau", (int)(first % n), h1[(size_t)first], h2[(size_t)first]);
-            }
         }
     }
 
@@ -1496,12 +1385,7 @@ dmrgx_status symeig_batched(const std::vector<SymEigMat>& mats_in, hipStream_t s
     // ---- 2: launches -------------------------------------------------------------------------------------------------------------
     const DcMat* ddm = d_dm;
     hipLaunchKernelGGL(dc_scale_kernel, dim3((unsigned)nm), dim3(256), 0, st, ddm);
-    // (A/B: DMRGX_LEAF=ql runs the one-wave QL leaf instead.  Measured equal: 250 us per call at m = 512 for both, 8.85 ms per
-    //  truncation at m = 2048 for both -- the QL chain is ~25 dependent f64 operations per rotation for ~900 rotations plus a serial scan
-    //  for the split point per iteration; Jacobi stays the default because it has no failure mode.)
-    static const bool leaf_jacobi = !(getenv("DMRGX_LEAF") && std::string(getenv("DMRGX_LEAF")) == "ql");
-    if (leaf_jacobi) hipLaunchKernelGGL(dc_leaf_kernel, dim3((unsigned)leaves.size()), dim3(DC_LEAF_THREADS), 0, st, ddm, d_leaves);
-    else hipLaunchKernelGGL(dc_leaf_ql_kernel, dim3((unsigned)leaves.size()), dim3(64), 0, st, ddm, d_leaves);
+    hipLaunchKernelGGL(dc_leaf_kernel, dim3((unsigned)leaves.size()), dim3(DC_LEAF_THREADS), 0, st, ddm, d_leaves);
     DMRGX_HIP(hipGetLastError());
     for (const Step& s : steps) {
         if (s.nmerge == 0) continue;

@@ -81,7 +81,11 @@ public:
     PetscInt Offsets(const PetscInt& lidx, const PetscInt& ridx) const { const PetscInt i = Map(lidx, ridx); return i >= 0 ? kb_offset[i] : -1; }
     PetscInt NumStates() const { return num_states; }
 
-    PetscErrorCode KronSumSetShellMatrix(const PetscBool& do_shell_in) { do_shell = do_shell_in; return 0; }
+    PetscErrorCode KronSumSetShellMatrix(const PetscBool& do_shell_in)
+    {
+        if (!do_shell_in) SETERRQ(PETSC_COMM_WORLD, PETSC_ERR_SUP, "KronSumSetShellMatrix: only the matrix-free (shell) superblock Hamiltonian is implemented.");
+        do_shell = do_shell_in; return 0;
+    }
     PetscErrorCode KronSumSetRedistribute(const PetscBool& in = PETSC_TRUE) { do_redistribute = in; return 0; }
     PetscErrorCode KronSumSetToleranceFromOptions() { return PetscOptionsGetReal(NULL, NULL, "-ks_tol", &ks_tol, NULL); }
 

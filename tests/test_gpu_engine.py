@@ -210,6 +210,77 @@ def test_headline_lattices_step_by_step_against_the_oracle(tmp_path, name, ranks
     assert trunc > 1e-4                                                       # the truncation was real
 
 
+def test_unsupported_reference_options_are_refused(tmp_path):
+    """Options of the reference's driver that select code this engine does not build are refused with PETSC_ERR_SUP (56), not
+    accepted and ignored: -no_symm (include/DMRGBlockContainer.hpp:243 of the reference refuses it too) and -do_shell 0 (the explicit
+    MATMPIAIJ superblock Hamiltonian, src/DMRGKron.cpp:759-841)."""
+    for opt in (["-do_shell", 0], ["-no_symm", 1]):
+        d = str(tmp_path / opt[0].strip("-")) + "/"
+        os.makedirs(d, exist_ok=True)
+        out = subprocess.run([EXE, *[str(o) for o in ("-Lx", 4, "-Ly", 2, "-mwarmup", 8, "-nsweeps", 1, *opt, "-data_dir", d)]], capture_output=True, text=True, timeout=120)
+        assert out.returncode != 0 and "Unsupported option" in (out.stdout + out.stderr), out.stdout[-500:] + out.stderr[-500:]
+
+
+def test_rdm_warm_start_option_gives_the_same_run(tmp_path):
+    """-rdm_warm_start 1 hands the eigenbases of a block's previous visit to dmrgx_rdm_create_warm as a hint (only the Jacobi path
+    uses it; the direct solver ignores it): energies and truncation errors of a warm-up + two sweeps equal the run without it."""
+    model = ["-Lx", 6, "-Ly", 2, "-J1", 1, "-Jz1", 0.9, "-J2", 0.5, "-Jz2", 0.4, "-qn_sector", 1, "-mwarmup", 12, "-nsweeps", 2, "-H_eps_tol", 1e-12]
+    r0, _, _ = run_engine(tmp_path / "cold", *model, "-rdm_warm_start", 0)
+    r1, _, _ = run_engine(tmp_path / "warm", *model, "-rdm_warm_start", 1)
+    assert len(r0) == len(r1) >= 20
+    for a, b in zip(r0, r1):
+        assert abs(a["GSEnergy"] - b["GSEnergy"]) <= 1e-10 * abs(a["GSEnergy"]), (a["GlobIdx"], a["GSEnergy"], b["GSEnergy"])
+        assert abs(a["TruncErr_Sys"] - b["TruncErr_Sys"]) <= 1e-9 * abs(a["TruncErr_Sys"]) + 1e-13
+
+
+def _medium_golden():
+    return json.load(open(os.path.join(ROOT, "tests", "golden", "engine_medium_m.json")))
+
+
+@pytest.mark.parametrize("name,ranks", [("j1j2_10x4_sz1", 1), ("j1j2_8x4_sz1", 1), ("j1j2_8x4_sz1", 2), ("xxz_8x6_sz1", 1), ("j1j2_6x4_sz1", 1)])
+def test_medium_m_step_by_step_against_the_oracle(tmp_path, name, ranks):
+    """The engine against the CPU oracle's DMRG step by step at m = 24 ... 48, where the code paths of the production sizes run inside
+    the engine: enlarged sectors of 20-35 states are diagonalised by divide and conquer with real merges and deflation
+    (csrc/symeig.hip, leaves of 16), back-transformed through WY blocks, and every GEMM tile spans several 16 x 16 MFMA blocks
+    (the m = 4-8 cases above never leave one leaf / one block).  tests/golden/engine_medium_m.json is made by
+    tests/golden/make_engine_golden_medium_m.py (minutes of single-threaded Python per lattice); its docstring says why the runs warm
+    up small, grow m sweep by sweep and turn round `-min_block` sites before the edge: only then is every m-cut decided by the spectrum
+    and not by round-off.  Up to the first ill-defined cut -- 70-180 steps into a run, in its last sweep -- sizes, energies and both
+    truncation errors agree at 1e-10; across the four runs that is more than 150 steps at m >= 24.  After it, energies agree at the
+    truncation-error scale.  Match: include/DMRGBlockContainer.hpp:1656-2057, src/DMRGBlock.cpp:766-771."""
+    g = _medium_golden()[name]
+    o = g["options"]
+    rows, run, _ = run_engine(tmp_path, "-Lx", o["Lx"], "-Ly", o["Ly"], "-J1", o["J1"], "-Jz1", o["Jz1"], "-J2", o["J2"], "-Jz2", o["Jz2"], "-qn_sector", g["qn_sector"],
+                              "-mwarmup", g["mwarmup"], "-msweeps", ",".join(str(m) for m in g["msweeps"]), "-min_block", g["min_block"], "-H_eps_tol", 1e-13, ranks=ranks)
+    steps = g["steps"]
+    assert len(rows) == len(steps) and run["Ranks"] == ranks
+    first_ill = next((i for i, st in enumerate(steps) if not st["well_defined"]), len(steps))
+    assert first_ill == g["first_ill"] and g["strict_steps_m24"] >= 20
+    assert max(st["max_sector"] for st in steps[:first_ill]) > 16                 # merges of the divide-and-conquer tree happen in the strict part
+    trunc = max(st["TruncErr_Sys"] for st in steps)
+    for i, (r, st) in enumerate(zip(rows, steps)):
+        for key in ("NSites_Sys", "NSites_Env"):
+            assert r[key] == st[key], (i, key)
+        if i <= first_ill:
+            for key in ("NStates_SysEnl", "NStates_EnvEnl", "NumStates_H"):
+                assert r[key] == st[key], (i, key)
+            assert abs(r["GSEnergy"] - st["GSEnergy"]) <= 1e-10 * abs(st["GSEnergy"]), (i, st["m"], r["GSEnergy"], st["GSEnergy"])
+        else:
+            assert abs(r["GSEnergy"] - st["GSEnergy"]) <= 4.0 * trunc * abs(st["GSEnergy"]), (i, r["GSEnergy"], st["GSEnergy"])
+        if i < first_ill:
+            for key in ("NStates_SysRot", "NStates_EnvRot"):
+                assert r[key] == st[key], (i, key)
+            for side in ("TruncErr_Sys", "TruncErr_Env"):
+                assert abs(r[side] - st[side]) <= 1e-10 * abs(st[side]) + 1e-13, (i, st["m"], side, r[side], st[side])
+
+
+def test_medium_m_tables_cover_the_sizes_they_are_for():
+    """(no GPU needed, but kept beside its test) >= 100 strictly compared steps at m >= 24, one run with sectors above 32"""
+    g = _medium_golden()
+    assert sum(c["strict_steps_m24"] for c in g.values()) >= 100
+    assert max(st["max_sector"] for c in g.values() for st in c["steps"][:c["first_ill"]]) > 32
+
+
 def test_baseline_config1_energy_against_the_oracle_at_reduced_m(tmp_path):
     """BASELINE configs[1] (J1-J2 8x4 cylinder, J2 = 0.5) is too large for exact diagonalisation and, at m = 512, for the CPU
     oracle.  In the Sz = 0 sector the +q/-q spectra are degenerate, so the kept subspaces of two implementations may differ by

@@ -31,7 +31,7 @@ int main(int argc, char** argv)
         if (big) ggemm_append_tiles_mixed(tb, tiles, g, M, N, nprod * K / 16); else ggemm_append_tiles(tiles, g, M, N, nprod * K / 16);
     }
     std::vector<GTile>& tl = big ? tb : tiles;
-    ggemm_schedule(tl, big ? 2 : 1);
+    ggemm_schedule(tl, groups, big ? 2 : 1);
     GProd* dp; GGroup* dg; GTile* dt;
     CK(hipMalloc(&dp, prods.size() * sizeof(GProd))); CK(hipMalloc(&dg, groups.size() * sizeof(GGroup))); CK(hipMalloc(&dt, tl.size() * sizeof(GTile)));
     CK(hipMemcpy(dp, prods.data(), prods.size() * sizeof(GProd), hipMemcpyHostToDevice));
