@@ -108,19 +108,24 @@ def engine_run(opts, timeout=300, ranks=1, rehearsal=False):
         else:
             base = dict(os.environ, WORLD_SIZE=str(ranks), HSA_ENABLE_IPC_MODE_LEGACY="0", DMRGX_RDZV_FILE=os.path.join(d, "rdzv"),
                         DMRGX_SHM_NAME="dmrgx_bench_eng_%d" % os.getpid(), DMRGX_COMM="shm" if rehearsal else "rccl")
-            procs = [subprocess.Popen(cmd, env=dict(base, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(ranks)]
+            # every rank writes its output to a file of its own: a pipe that nobody drains while rank 0 is awaited blocks its writer
+            # after 64 KB, the blocked rank stops taking part in the collectives and the whole job hangs
+            logs = [open(os.path.join(d, "rank%d.log" % r), "w") for r in range(ranks)]
+            procs = [subprocess.Popen(cmd, env=dict(base, RANK=str(r), LOCAL_RANK=str(r)), stdout=logs[r], stderr=subprocess.STDOUT) for r in range(ranks)]
             t_end = time.time() + timeout
-            outs, rc = [], 0
+            rc = 0
             for p in procs:
                 try:
-                    o, _ = p.communicate(timeout=max(1.0, t_end - time.time()))
+                    p.wait(timeout=max(1.0, t_end - time.time()))
                 except subprocess.TimeoutExpired:
                     for q in procs:
                         q.kill()                                   # the exact processes started above
                     raise RuntimeError("sweep engine on %d ranks timed out after %d s" % (ranks, timeout))
-                outs.append(o); rc = rc or p.returncode
+                rc = rc or p.returncode
+            for f in logs:
+                f.close()
             if rc != 0:
-                raise RuntimeError("sweep engine on %d ranks failed: %s" % (ranks, "".join(outs)[-1500:]))
+                raise RuntimeError("sweep engine on %d ranks failed: %s" % (ranks, "".join(open(os.path.join(d, "rank%d.log" % r)).read()[-800:] for r in range(ranks))))
         run = json.load(open(os.path.join(d, "DMRGRun.json")))
         # per-sweep totals from the reference-format step tables (DMRGSteps.json: LoopType/LoopIdx, Timings.json: Total, MatMults)
         steps = json.load(open(os.path.join(d, "DMRGSteps.json")))["table"]
@@ -132,6 +137,20 @@ def engine_run(opts, timeout=300, ranks=1, rehearsal=False):
             e = per.setdefault(int(st[2]), {"steps": 0, "seconds": 0.0, "matmults": 0})
             e["steps"] += 1; e["seconds"] += float(tm[1]); e["matmults"] += int(tm[7])
         run["PerSweep"] = [per[k] for k in sorted(per)]
+        # where a step of the last sweep goes on rank 0 (Timings.json: host clock per phase; AllGatherMs / ApplyMs: HIP events on the solver's
+        # stream, dmrgx_eigs_comm_timing -- zero on one rank): the N > 1 line must explain itself
+        hdr = json.load(open(os.path.join(d, "Timings.json")))["headers"]
+        col = {h: i for i, h in enumerate(hdr)}
+        last = max(per) if per else None
+        rows = [tm for st, tm in zip(steps, times) if st[1] == "Sweep" and int(st[2]) == last]
+        if rows:
+            mean = lambda name: sum(float(r[col[name]]) for r in rows) / len(rows)          # noqa: E731
+            run["StepBreakdownMs"] = {
+                "t_step_ms": 1e3 * mean("Total"), "t_solve_ms": 1e3 * mean("Diag"), "t_rdm_ms": 1e3 * mean("Rdms"),
+                "t_allgather_ms": mean("AllGatherMs") if "AllGatherMs" in col else None, "t_apply_ms": mean("ApplyMs") if "ApplyMs" in col else None,
+                # everything every rank does alike between two solves: enlargement, plan build, start vector, rotation of the coupling operators
+                "t_replicated_ms": 1e3 * (mean("Total") - mean("Diag") - mean("Rdms")),
+                "rank": 0, "sweep": last, "steps": len(rows)}
         # -step_profile: algorithmic flops and HIP-event GEMM time of every MatMult of every sweep step (KronStats.json)
         ks = [k for k in json.load(open(os.path.join(d, "KronStats.json"))) if k["LoopType"] == "Sweep" and k["timed_applies"] > 0]
         if ks:
@@ -236,7 +255,8 @@ def sweep_legs_multi(ranks, rehearsal):
     def leg(run, config):
         return {"sites_per_s": run["LastSweepSteps"] / run["LastSweepSeconds"], "config": config, "ranks": run.get("Ranks"),
                 "sweep_steps": run["LastSweepSteps"], "sweep_seconds": run["LastSweepSeconds"], "sweep_matmults": run["LastSweepMatMults"],
-                "matmults_per_s_in_sweep": run["LastSweepMatMults"] / run["LastSweepSeconds"], "gs_energy": run["GSEnergy"], "max_trunc_err": run["MaxTruncErr"]}
+                "matmults_per_s_in_sweep": run["LastSweepMatMults"] / run["LastSweepSeconds"], "gs_energy": run["GSEnergy"], "max_trunc_err": run["MaxTruncErr"],
+                "step_breakdown_ms": run.get("StepBreakdownMs")}
     j1j2 = ["-J1", 1, "-Jz1", 1, "-J2", 0.5, "-Jz2", 0.5]
     if rehearsal:
         big = ["-Lx", 6, "-Ly", 4, "-mwarmup", 48, *j1j2, "-nsweeps", 1]
@@ -279,14 +299,26 @@ def launch_ranks(n):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    base = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    # DMRGX_BENCH_LAUNCHER=1: the engine legs are run by THIS process once every rank has exited and released its GPU (a rank 0 that
+    # starts them itself cannot know that its siblings are gone: ADVICE round 3)
+    base = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", DMRGX_BENCH_LAUNCHER="1")
     procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=dict(base, RANK=str(r), LOCAL_RANK=str(r)),
                               stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL) for r in range(n)]
     out0, _ = procs[0].communicate()
     rc = procs[0].returncode
     for p in procs[1:]:
         rc = p.wait() or rc
-    sys.stdout.write(out0.decode())
+    text = out0.decode()
+    if rc == 0 and "--no-sweep" not in sys.argv:
+        lines = text.strip().splitlines()
+        try:
+            line = json.loads(lines[-1])
+            line["sweep"] = sweep_legs_multi(n, os.environ.get("DMRGX_BENCH_REHEARSAL") == "1")
+            text = "\n".join(lines[:-1] + [json.dumps(line)]) + "\n"
+        except Exception as e:                                            # noqa: BLE001
+            sys.stderr.write("bench launcher: engine legs failed: %s\n" % e)
+            rc = 1
+    sys.stdout.write(text)
     sys.stdout.flush()
     sys.exit(rc)
 
@@ -440,9 +472,12 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     torch.cuda.empty_cache()                     # the engine legs below run in child processes on the same GPU(s)
-    if rank == 0 and not args.no_sweep:
+    if rank == 0 and not args.no_sweep and not (world > 1 and os.environ.get("DMRGX_BENCH_LAUNCHER") == "1"):
         # sites/sec per sweep on the real engine: one rank -> the full set of legs; N ranks -> the configs[3] engine leg on N ranks
-        # (and configs[2] for N = 2).  The other bench ranks have finished by now and released their GPUs.
+        # (and configs[2] for N = 2).  Started by `python bench.py --gpus N` the launcher process runs the N-rank legs after all ranks
+        # have exited; under torch.distributed.run rank 0 does, after giving its siblings a moment to leave their GPUs.
+        if world > 1:
+            time.sleep(3.0)
         out["sweep"] = sweep_legs() if world == 1 else sweep_legs_multi(world, rehearsal)
     if rank == 0:
         print(json.dumps(out))

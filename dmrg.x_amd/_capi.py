@@ -130,6 +130,7 @@ SIGNATURES = {
     "dmrgx_dot": (C.c_int32, [C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.c_void_p]),
     "dmrgx_dot_async": (C.c_int32, [C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dmrgx_dot2d_batch": (C.c_int32, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dmrgx_eigs_comm_timing": (C.c_int32, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int32]),
     "dmrgx_eigs_lowest": (C.c_int32, [C.c_void_p, C.POINTER(EigsOpts), C.POINTER(C.c_double), C.c_void_p,
                                       C.POINTER(EigsStats), C.c_void_p]),
     "dmrgx_rdm_create_subset": (C.c_int32, [C.POINTER(Sectors), C.POINTER(Sectors), C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32),

@@ -13,6 +13,7 @@
 // world_size > 1: vectors are this rank's stripe segment; per Lanczos step there are exactly two fused all-reduces (of
 // j+2 doubles each) and one all-gather of the Krylov vector before the MatMult.
 #include "common.h"
+#include <mutex>
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -329,6 +330,46 @@ using namespace dmrgx;
 
 static dmrgx_status eigs_davidson(dmrgx_kron_plan* plan, const dmrgx_eigs_opts* opts, double* e0, double* psi_full, dmrgx_eigs_stats* stats, hipStream_t st);
 
+namespace {
+// Where a distributed MatMult spends its time, for the N > 1 bench line: three events per MatMult on the solver's
+// stream, read when the timer goes out of scope (the solve has synchronised by then), summed into process-wide totals.
+std::mutex g_ct_mutex;
+double g_ct_allgather_ms = 0.0, g_ct_apply_ms = 0.0;
+int64_t g_ct_matvecs = 0;
+struct CommTimer {
+    hipStream_t st;
+    std::vector<hipEvent_t> ev;
+    size_t used = 0;
+    explicit CommTimer(hipStream_t s) : st(s) {}
+    void mark()
+    {
+        if (used == ev.size()) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return; ev.push_back(e); }
+        (void)hipEventRecord(ev[used++], st);
+    }
+    ~CommTimer()
+    {
+        double ag = 0.0, ap = 0.0; int64_t nmv = 0;
+        for (size_t i = 0; i + 2 < used; i += 3) {
+            float a = 0.f, b = 0.f;
+            if (hipEventSynchronize(ev[i + 2]) != hipSuccess) break;
+            if (hipEventElapsedTime(&a, ev[i], ev[i + 1]) == hipSuccess && hipEventElapsedTime(&b, ev[i + 1], ev[i + 2]) == hipSuccess) { ag += a; ap += b; ++nmv; }
+        }
+        for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+        if (nmv) { std::lock_guard<std::mutex> lk(g_ct_mutex); g_ct_allgather_ms += ag; g_ct_apply_ms += ap; g_ct_matvecs += nmv; }
+    }
+};
+}  // namespace
+
+extern "C" dmrgx_status dmrgx_eigs_comm_timing(double* allgather_ms, double* apply_ms, int64_t* n_matvec, int32_t reset)
+{
+    std::lock_guard<std::mutex> lk(g_ct_mutex);
+    if (allgather_ms) *allgather_ms = g_ct_allgather_ms;
+    if (apply_ms) *apply_ms = g_ct_apply_ms;
+    if (n_matvec) *n_matvec = g_ct_matvecs;
+    if (reset) { g_ct_allgather_ms = 0.0; g_ct_apply_ms = 0.0; g_ct_matvecs = 0; }
+    return DMRGX_OK;
+}
+
 extern "C" dmrgx_status dmrgx_eigs_lowest(dmrgx_kron_plan* plan, const dmrgx_eigs_opts* opts, double* e0,
                                           double* psi_full, dmrgx_eigs_stats* stats, void* stream)
 {
@@ -405,11 +446,16 @@ extern "C" dmrgx_status dmrgx_eigs_lowest(dmrgx_kron_plan* plan, const dmrgx_eig
         DMRGX_HIP(hipGetLastError());
         return DMRGX_OK;
     };
+    CommTimer ctimer(st);       // (distributed only) HIP events round the all-gather and the apply of every MatMult: dmrgx_eigs_comm_timing
     auto matvec = [&](const double* v_local, double* y_local) -> dmrgx_status {
         if (!dist) return dmrgx_kron_apply(plan, v_local, y_local, st);
         DMRGX_HIP(hipMemcpyAsync(dX.as<double>() + I.local_offset, v_local, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
+        ctimer.mark();
         DMRGX_CHK(gather_full(dX.as<double>()));
-        return dmrgx_kron_apply(plan, dX.as<double>(), y_local, st);
+        ctimer.mark();
+        const dmrgx_status rc = dmrgx_kron_apply(plan, dX.as<double>(), y_local, st);
+        ctimer.mark();
+        return rc;
     };
 
     // ---- start vector: w <- v0 ; V[0] = w/||w|| ------------------------------------------------------------
@@ -650,11 +696,16 @@ static dmrgx_status eigs_davidson(dmrgx_kron_plan* plan, const dmrgx_eigs_opts* 
         DMRGX_HIP(hipGetLastError());
         return DMRGX_OK;
     };
+    CommTimer ctimer(st);       // (distributed only) HIP events round the all-gather and the apply of every MatMult: dmrgx_eigs_comm_timing
     auto matvec = [&](const double* v_local, double* y_local) -> dmrgx_status {
         if (!dist) return dmrgx_kron_apply(plan, v_local, y_local, st);
         DMRGX_HIP(hipMemcpyAsync(dX.as<double>() + I.local_offset, v_local, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
+        ctimer.mark();
         DMRGX_CHK(gather_full(dX.as<double>()));
-        return dmrgx_kron_apply(plan, dX.as<double>(), y_local, st);
+        ctimer.mark();
+        const dmrgx_status rc = dmrgx_kron_apply(plan, dX.as<double>(), y_local, st);
+        ctimer.mark();
+        return rc;
     };
 
     // ---- start vector ----------------------------------------------------------------------------------------------------

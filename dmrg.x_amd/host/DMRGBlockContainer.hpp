@@ -618,6 +618,7 @@ public:
         gse = gse_r;
         trunc_err.push_back(BT_L.TruncErr);
         ierr = SaveStepData(step); CHKERRQ(ierr);
+        if (mpi_size > 1) { int64_t nmv = 0; dmrgx_eigs_comm_timing(&timings.msAllGather, &timings.msApply, &nmv, 1); }      /* this step's share, totals reset */
         ierr = SaveTimingsData(timings); CHKERRQ(ierr);
         ++GlobIdx; ++StepIdx; ++rows_written;
         return 0;
@@ -1585,7 +1586,8 @@ private:
         PetscInt NumStates_Sys = 0, NumStates_Env = 0, NumStates_SysEnl = 0, NumStates_EnvEnl = 0, NumStates_SysRot = 0, NumStates_EnvRot = 0, NumStates_H = 0;
         PetscScalar GSEnergy = 0; PetscReal TruncErr_Sys = 0, TruncErr_Env = 0;
     };
-    struct TimingsData { PetscLogDouble tEnlr = 0, tKron = 0, tDiag = 0, tRdms = 0, tRotb = 0, Total = 0; PetscInt nMatMult = 0, nRotOps = 0; };
+    struct TimingsData { PetscLogDouble tEnlr = 0, tKron = 0, tDiag = 0, tRdms = 0, tRotb = 0, Total = 0; PetscInt nMatMult = 0, nRotOps = 0;
+                         double msAllGather = 0, msApply = 0; };      /* (ranks > 1) HIP-event time of the step's all-gathers / applies on this rank */
     typedef enum { WarmupStep = 0, SweepStep = 1, NullStep = -1 } Step_t;
     typedef enum { SWEEP_MODE_NULL, SWEEP_MODE_NSWEEPS, SWEEP_MODE_MSWEEPS, SWEEP_MODE_TOLERANCE_TEST } SweepMode_t;
 
@@ -1611,12 +1613,12 @@ private:
     }
     PetscErrorCode SaveTimingsHeaders()
     {
-        fprintf(fp_timings, "{\n  \"headers\" : [\"GlobIdx\", \"Total\", \"Enlr\", \"Kron\", \"Diag\", \"Rdms\", \"Rotb\", \"MatMults\", \"RotOps\" ],\n  \"table\" : ");
+        fprintf(fp_timings, "{\n  \"headers\" : [\"GlobIdx\", \"Total\", \"Enlr\", \"Kron\", \"Diag\", \"Rdms\", \"Rotb\", \"MatMults\", \"RotOps\", \"AllGatherMs\", \"ApplyMs\" ],\n  \"table\" : ");
         return 0;
     }
     PetscErrorCode SaveTimingsData(const TimingsData& d)
     {
-        fprintf(fp_timings, "%s    [ %lld, %.9g, %.9g, %.9g, %.9g, %.9g, %.9g, %lld, %lld ]", rows_written ? ",\n" : "", LLD(GlobIdx), d.Total, d.tEnlr, d.tKron, d.tDiag, d.tRdms, d.tRotb, LLD(d.nMatMult), LLD(d.nRotOps));
+        fprintf(fp_timings, "%s    [ %lld, %.9g, %.9g, %.9g, %.9g, %.9g, %.9g, %lld, %lld, %.6g, %.6g ]", rows_written ? ",\n" : "", LLD(GlobIdx), d.Total, d.tEnlr, d.tKron, d.tDiag, d.tRdms, d.tRotb, LLD(d.nMatMult), LLD(d.nRotOps), d.msAllGather, d.msApply);
         fflush(fp_timings);
         return 0;
     }

@@ -142,8 +142,13 @@ inline int CommBootstrap()
             if (rename(tmp.c_str(), path.c_str()) != 0) { fprintf(stderr, "[dmrgx] cannot publish %s\n", path.c_str()); return 1; }
         } else {
             const auto t0 = std::chrono::steady_clock::now();
+            /* a file older than this launch is the leftover of a run that died before rank 0 removed it: rank 0 of THIS launch unlinks it
+               before it publishes, but a faster rank could read it first -- only a file written within the two minutes
+               before this process started, or later, is taken */
+            const time_t started = time(nullptr);
             while (true) {
-                FILE* f = fopen(path.c_str(), "rb");
+                struct stat sb;
+                FILE* f = (stat(path.c_str(), &sb) == 0 && sb.st_mtime >= started - 120) ? fopen(path.c_str(), "rb") : nullptr;
                 if (f) { const size_t n = fread(id, 1, sizeof(id), f); fclose(f); if (n == sizeof(id)) break; }
                 if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(300)) { fprintf(stderr, "[dmrgx] rank %d: no rendezvous file %s\n", rank, path.c_str()); return 1; }
                 std::this_thread::sleep_for(std::chrono::milliseconds(10));

@@ -241,6 +241,11 @@ typedef struct {
 dmrgx_status dmrgx_eigs_lowest(dmrgx_kron_plan* plan, const dmrgx_eigs_opts* opts, double* e0,
                                double* psi_full, dmrgx_eigs_stats* stats, void* stream);
 
+/* Distributed solves only: where the MatMults of the solves since the last reset spent their time on this rank -- the all-gather that
+ * rebuilds x (the reference's VecScatter-to-all, src/DMRGKron.cpp:1833-1834) and the apply behind it -- from HIP events on the
+ * solver's stream (milliseconds, summed over n_matvec MatMults).  reset != 0 clears the totals.  Any pointer may be null. */
+dmrgx_status dmrgx_eigs_comm_timing(double* allgather_ms, double* apply_ms, int64_t* n_matvec, int32_t reset);
+
 /* ---- K3/K4: reduced density matrices + full spectra ------------------------------------------------------ */
 /* For every KronBlock k of the layout: rho_L = Psi Psi^T, rho_R = Psi^T Psi (Psi = n_L x n_R row-major slice of
  * psi_dev in the reference's vector layout) and ALL eigenpairs of each, largest first -- the device part of

@@ -645,3 +645,8 @@ def test_bench_multi_rank_control_flow_rehearsal():
     sw = d["sweep"]
     assert "error" not in sw and sw["ranks"] == 2 and sw["sites_per_s"] > 0, sw
     assert "error" not in sw["configs_2"] and sw["configs_2"]["ranks"] == 2 and sw["configs_2"]["sites_per_s"] > 0, sw["configs_2"]
+    # the N > 1 line explains itself: where a step of the last sweep went on rank 0, the distributed MatMult split into its all-gather and
+    # its apply by HIP events (dmrgx_eigs_comm_timing)
+    bd = sw["step_breakdown_ms"]
+    assert bd["t_allgather_ms"] > 0 and bd["t_apply_ms"] > 0 and bd["t_rdm_ms"] > 0 and bd["t_replicated_ms"] > 0, bd
+    assert bd["t_allgather_ms"] + bd["t_apply_ms"] <= 1.05 * bd["t_solve_ms"] and bd["t_solve_ms"] + bd["t_rdm_ms"] <= 1.001 * bd["t_step_ms"], bd
