@@ -1369,17 +1369,35 @@ dmrgx_status symeig_batched(const std::vector<SymEigMat>& mats_in, hipStream_t s
     };
 
     // ---- 3a: launches ----------------------------------------------------------------------------------------------------------
+    // The WY factors (V^T, Gram matrix, T^-1 by one latency-bound workgroup per block, T12, T V^T) and the divide and conquer below both
+    // need the tridiagonalisation only, and neither fills the chip: the WY chain goes to a second stream and joins in front of the
+    // back-transformation (m = 512: ~100 us per call; timeline in profiles/r04_rdm_timeline_m512.txt).
     const bool any_blk = max_nblk > 0;
+    static hipStream_t side = nullptr;
+    static hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     if (any_blk) {
+        if (!side) {
+            DMRGX_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+            DMRGX_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+            DMRGX_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+        }
+        DMRGX_HIP(hipEventRecord(ev_fork, st));
+        DMRGX_HIP(hipStreamWaitEvent(side, ev_fork, 0));
+        auto run_set_side = [&](const GemmSet& s) -> dmrgx_status {
+            DMRGX_CHK(ggemm_launch(d_tiles + s.big_off, d_groups, d_prods, s.nbig, side, 1));
+            DMRGX_CHK(ggemm_launch(d_tiles + s.small_off, d_groups, d_prods, s.nsmall, side, 0));
+            return DMRGX_OK;
+        };
         const unsigned t32 = (unsigned)((nmax + 31) / 32);
-        hipLaunchKernelGGL(transpose_sq_kernel, dim3(t32, t32, (unsigned)nm), dim3(256), 0, st, d_tp);
+        hipLaunchKernelGGL(transpose_sq_kernel, dim3(t32, t32, (unsigned)nm), dim3(256), 0, side, d_tp);
         DMRGX_HIP(hipGetLastError());
-        DMRGX_CHK(run_set(set_gram));
-        hipLaunchKernelGGL(wy_tinv_kernel, dim3((unsigned)wyb.size()), dim3(WY_SUB), 0, st, d_wyb);
+        DMRGX_CHK(run_set_side(set_gram));
+        hipLaunchKernelGGL(wy_tinv_kernel, dim3((unsigned)wyb.size()), dim3(WY_SUB), 0, side, d_wyb);
         DMRGX_HIP(hipGetLastError());
-        DMRGX_CHK(run_set(set_t12a));
-        DMRGX_CHK(run_set(set_t12b));
-        DMRGX_CHK(run_set(set_tv));
+        DMRGX_CHK(run_set_side(set_t12a));
+        DMRGX_CHK(run_set_side(set_t12b));
+        DMRGX_CHK(run_set_side(set_tv));
+        DMRGX_HIP(hipEventRecord(ev_join, side));
     }
 
     // ---- 2: launches -------------------------------------------------------------------------------------------------------------
@@ -1410,6 +1428,7 @@ dmrgx_status symeig_batched(const std::vector<SymEigMat>& mats_in, hipStream_t s
     DMRGX_HIP(hipGetLastError());
 
     // ---- 3b: launches ------------------------------------------------------------------------------------------------------------
+    if (any_blk) DMRGX_HIP(hipStreamWaitEvent(st, ev_join, 0));
     for (int s = 0; s < max_nblk; ++s) { DMRGX_CHK(run_set(bt_w[(size_t)s])); DMRGX_CHK(run_set(bt_x[(size_t)s])); }
     hmark("all queued");
     if (host_trace) {

@@ -402,12 +402,25 @@ inline PetscErrorCode KronEye_Explicit(Block::SpinBase& LeftBlock, Block::SpinBa
     std::vector<Hamiltonians::Term> TermsLR;
     ierr = KB.ClassifyTerms(Terms, TermsLR); CHKERRQ(ierr);
     if (!LeftBlock.H && !RightBlock.H && TermsLR.empty()) { BlockOut.H = nullptr; return 0; }
-    Mat Hout = SectorMat::Dense(0, out_sizes);
+    /* all sector blocks in one device allocation, zeroed by one launch (one allocation and one launch per block before) */
+    Mat Hout = std::make_shared<SectorMat>();
+    Hout->shift = 0; Hout->sizes = out_sizes;
+    size_t htotal = 0;
+    for (int32_t sz : out_sizes) htotal += (size_t)sz * (size_t)sz;
+    std::shared_ptr<dmrgx_host::DevBuffer> harena;
+    try { harena = std::make_shared<dmrgx_host::DevBuffer>(htotal, dmrgx_host::DevBuffer::device_only_t{}); } catch (const std::exception& e) { SETERRQ1(mpi_comm, PETSC_ERR_MEM, "KronEye_Explicit: %s", e.what()); }
+    if (htotal && dmrgx_memset_zero(harena->dev_uninitialised(), htotal * sizeof(double), nullptr)) SETERRQ1(mpi_comm, 1, "%s", dmrgx_last_error());
     std::vector<dmrgx_axpy_task> tasks;
-    std::vector<double*> blockptr(Hout->cells.size());
-    for (size_t q = 0; q < Hout->cells.size(); ++q) {
-        blockptr[q] = Hout->cells[q].buf->dev_uninitialised();
-        if (dmrgx_memset_zero(blockptr[q], Hout->cells[q].buf->size() * sizeof(double), nullptr)) SETERRQ1(mpi_comm, 1, "%s", dmrgx_last_error());
+    std::vector<double*> blockptr(out_sizes.size());
+    {
+        size_t cursor = 0;
+        for (int32_t q = 0; q < (int32_t)out_sizes.size(); ++q) {
+            dmrgx_host::MatCell c;
+            c.q = q; c.nr = out_sizes[(size_t)q]; c.nc = c.nr; c.ld = c.nc; c.buf = harena; c.off = (int64_t)cursor;
+            blockptr[(size_t)q] = harena->dev_uninitialised() + cursor;
+            cursor += (size_t)c.nr * (size_t)c.nc;
+            Hout->cells.push_back(c);
+        }
     }
     auto push = [&](PetscInt k, PetscInt kc, const MatCell& c, bool tr, double alpha, int32_t rmul) {
         /* out[sub[k] + r0.., sub[kc] + c0..] += alpha * cell (transposed view when tr) ; rmul: 1 (only 1-state right sectors) */

@@ -19,7 +19,9 @@ namespace dmrgx_host {
 /** f64 buffer with a lazily synchronised host mirror. */
 class DevBuffer {
 public:
-    explicit DevBuffer(size_t n) : n_(n), h_(n, 0.0), where_(HOST) {}
+    /** n zeros.  The host mirror is only materialised when somebody asks for a host pointer: buffers that are filled on the device
+        (eigenvectors, enlarged Hamiltonians: 30-70 MB at m = 2048) used to cost a calloc + page faults of that size per step. */
+    explicit DevBuffer(size_t n) : n_(n), where_(HOST) {}
     /** device-resident buffer whose content is produced by a kernel: no host mirror is allocated until someone asks for it */
     struct device_only_t {};
     DevBuffer(size_t n, device_only_t) : n_(n), where_(DEVICE) { alloc_dev(); }
@@ -52,14 +54,18 @@ private:
     void sync_dev() {
         if (!d_) alloc_dev();
         if (where_ == HOST) {
-            if (n_ && dmrgx_memcpy_h2d(d_, h_.data(), n_ * sizeof(double), nullptr)) throw std::runtime_error(dmrgx_last_error());
-            if (dmrgx_stream_sync(nullptr)) throw std::runtime_error(dmrgx_last_error());
+            if (h_.size() != n_) {                /* still the constructor's zeros: no host copy exists, none is made */
+                if (n_ && dmrgx_memset_zero(d_, n_ * sizeof(double), nullptr)) throw std::runtime_error(dmrgx_last_error());
+            } else {
+                if (n_ && dmrgx_memcpy_h2d(d_, h_.data(), n_ * sizeof(double), nullptr)) throw std::runtime_error(dmrgx_last_error());
+                if (dmrgx_stream_sync(nullptr)) throw std::runtime_error(dmrgx_last_error());
+            }
             where_ = BOTH;
         }
     }
     void sync_host() {
+        if (h_.size() != n_) h_.assign(n_, 0.0);          /* (HOST / BOTH without a mirror: the content is the constructor's zeros) */
         if (where_ == DEVICE) {
-            if (h_.size() != n_) h_.assign(n_, 0.0);
             if (n_ && dmrgx_memcpy_d2h(h_.data(), d_, n_ * sizeof(double), nullptr)) throw std::runtime_error(dmrgx_last_error());
             where_ = BOTH;
         }
