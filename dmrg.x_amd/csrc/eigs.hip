@@ -370,6 +370,20 @@ extern "C" dmrgx_status dmrgx_eigs_comm_timing(double* allgather_ms, double* app
     return DMRGX_OK;
 }
 
+// Eight pinned doubles per host thread for scalars that travel to the host behind the solver's own synchronisations
+// ([2]: squared norm of a caller-supplied start vector).
+static double* pinned_scalars()
+{
+    static thread_local double* p = nullptr;
+    if (!p && hipHostMalloc((void**)&p, 64, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); p = nullptr; }
+    return p;
+}
+// A start vector is not trusted when its norm is zero / NaN (seen from the first coefficients) or below what the caller asked for.
+static bool start_too_light(const dmrgx_eigs_opts* opts, const double* pin)
+{
+    return opts->min_initial_norm2 > 0.0 && pin && !(pin[2] >= opts->min_initial_norm2);
+}
+
 extern "C" dmrgx_status dmrgx_eigs_lowest(dmrgx_kron_plan* plan, const dmrgx_eigs_opts* opts, double* e0,
                                           double* psi_full, dmrgx_eigs_stats* stats, void* stream)
 {
@@ -475,6 +489,8 @@ extern "C" dmrgx_status dmrgx_eigs_lowest(dmrgx_kron_plan* plan, const dmrgx_eig
         }
     }
     DMRGX_CHK(multi_dot(0));                                  // c1[0] = w.w
+    double* const pin = opts->use_initial ? pinned_scalars() : nullptr;
+    if (pin) { pin[2] = 0.0; DMRGX_HIP(hipMemcpyAsync(pin + 2, c1, sizeof(double), hipMemcpyDeviceToHost, st)); }      // read after the first synchronisation below
     DMRGX_HIP(hipMemcpyAsync(nrm, c1, sizeof(double), hipMemcpyDeviceToDevice, st));
     DMRGX_CHK(normalise_into(vec(0)));
 
@@ -489,11 +505,13 @@ extern "C" dmrgx_status dmrgx_eigs_lowest(dmrgx_kron_plan* plan, const dmrgx_eig
     // vector after it is zero and the projected matrix is exactly zero: "converged" at E = 0 with psi = 0.  Seen from the first
     // coefficients that come back to the host -- alpha_0 and beta_0^2 both not positive in magnitude -- the solve is repeated from the
     // random start vector instead (the engine's projected start vectors can lose all their weight).
-    auto null_start = [&]() { return opts->use_initial && restarts == 0 && k == 0 && !(std::fabs(hbuf[0]) > 0.0) && !(hbuf[(size_t)m + 1] > 0.0); };
+    auto null_start = [&]() { return opts->use_initial && restarts == 0 && k == 0 && ((!(std::fabs(hbuf[0]) > 0.0) && !(hbuf[(size_t)m + 1] > 0.0)) || start_too_light(opts, pin)); };
     auto redo_from_random = [&]() -> dmrgx_status {
         dmrgx_eigs_opts o2 = *opts;
         o2.use_initial = 0;
-        return dmrgx_eigs_lowest(plan, &o2, e0, psi_full, stats, (void*)st);
+        const dmrgx_status rc = dmrgx_eigs_lowest(plan, &o2, e0, psi_full, stats, (void*)st);
+        if (stats) stats->start_rejected = 1;
+        return rc;
     };
     while (true) {
         DMRGX_HIP(zero_async(Hrow(k), (size_t)(m + 1 - k) * row * sizeof(double), st));
@@ -603,7 +621,7 @@ extern "C" dmrgx_status dmrgx_eigs_lowest(dmrgx_kron_plan* plan, const dmrgx_eig
     DMRGX_HIP(hipStreamSynchronize(st));
     *e0 = lambda;
     if (stats) {
-        stats->n_matvec = n_matvec; stats->n_restart = restarts; stats->converged = converged; stats->residual = resid;
+        stats->n_matvec = n_matvec; stats->n_restart = restarts; stats->converged = converged; stats->start_rejected = 0; stats->residual = resid;
         stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
     }
     if (!converged) DMRGX_FAIL(DMRGX_ERR_NOTCONV, "eigs_lowest: not converged after %d restarts (residual %.3e)", restarts, resid);
@@ -721,6 +739,8 @@ static dmrgx_status eigs_davidson(dmrgx_kron_plan* plan, const dmrgx_eigs_opts* 
         DMRGX_HIP(hipStreamSynchronize(st));
     }
     DMRGX_CHK(orthonormalise_into(0, t, vec(0)));
+    double* const pin = opts->use_initial ? pinned_scalars() : nullptr;
+    if (pin) { pin[2] = 0.0; DMRGX_HIP(hipMemcpyAsync(pin + 2, c2, sizeof(double), hipMemcpyDeviceToHost, st)); }      // c2[0] = |start vector|^2; read after the first look
     mark("start vector");
 
     std::vector<double> G((size_t)m * m, 0.0), th, Y, hcol((size_t)MAX_NCV + 2), ydev;
@@ -744,10 +764,12 @@ static dmrgx_status eigs_davidson(dmrgx_kron_plan* plan, const dmrgx_eigs_opts* 
         DMRGX_CHK(multi_dot(j + 1, wvec(j), c1));                                  // column j of G = V^T w_j
         DMRGX_HIP(hipMemcpyAsync(hcol.data(), c1, (size_t)(j + 2) * sizeof(double), hipMemcpyDeviceToHost, st));
         DMRGX_HIP(hipStreamSynchronize(st));
-        if (n_matvec == 1 && !(hcol[1] > 0.0)) {       // |H v_0|^2 is not positive: the start vector had zero (or NaN) norm -- see the Lanczos path
+        if (n_matvec == 1 && (!(hcol[1] > 0.0) || start_too_light(opts, pin))) {       // |H v_0|^2 is not positive: the start vector had zero (or NaN) norm -- see the Lanczos path; or it is lighter than the caller accepts
             dmrgx_eigs_opts o2 = *opts;
             o2.method = 0; o2.use_initial = 0;
-            return dmrgx_eigs_lowest(plan, &o2, e0, psi_full, stats, (void*)st);
+            const dmrgx_status rc = dmrgx_eigs_lowest(plan, &o2, e0, psi_full, stats, (void*)st);
+            if (stats) stats->start_rejected = 1;
+            return rc;
         }
         for (int i = 0; i <= j; ++i) { G[(size_t)i * m + j] = hcol[(size_t)i]; G[(size_t)j * m + i] = hcol[(size_t)i]; }
         const int mm = j + 1;
@@ -861,7 +883,7 @@ static dmrgx_status eigs_davidson(dmrgx_kron_plan* plan, const dmrgx_eigs_opts* 
     }
     *e0 = lambda;
     if (stats) {
-        stats->n_matvec = n_matvec; stats->n_restart = restarts; stats->converged = converged; stats->residual = resid;
+        stats->n_matvec = n_matvec; stats->n_restart = restarts; stats->converged = converged; stats->start_rejected = 0; stats->residual = resid;
         stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
     }
     if (getenv("DMRGX_EIGS_TRACE")) fprintf(stderr, "[eigs gd] done: %d MatMults, %.3f ms\n", n_matvec, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());

@@ -533,9 +533,10 @@ public:
             o.ncv = (int32_t)eps_ncv; o.max_it = (int32_t)eps_max_it; o.tol = eps_tol; o.seed = 0x9E3779B9u + (uint64_t)GlobIdx;
             o.method = eps_method;
             bool guessed = false;
-            try { ierr = TransformedGuess(KronBlocks, SysBlock, EnvBlock, gsv_r, guessed); CHKERRQ(ierr); }
+            double min_norm2 = 0.0;
+            try { ierr = TransformedGuess(KronBlocks, SysBlock, EnvBlock, gsv_r, guessed, min_norm2); CHKERRQ(ierr); }
             catch (const std::exception& e) { SETERRQ1(mpi_comm, 1, "wavefunction transformation: %s", e.what()); }
-            if (guessed) { o.use_initial = 1; ++guesses_used; }
+            if (guessed) { o.use_initial = 1; o.min_initial_norm2 = min_norm2; }
             dmrgx_eigs_stats st;
             memset(&st, 0, sizeof(st));
             if (H->plan_world > 1) {
@@ -551,6 +552,8 @@ public:
             }
             else if (dmrgx_eigs_lowest(H->plan, &o, &gse_r, gsv_r->buf->dev_uninitialised(), &st, nullptr))
                 SETERRQ1(mpi_comm, 1, "dmrgx_eigs_lowest: %s", dmrgx_last_error());
+            if (guessed && st.start_rejected) { ++guesses_rejected; guessed = false; }
+            if (guessed) ++guesses_used;
             timings.nMatMult = st.n_matvec; total_matmults += st.n_matvec; total_eigs_seconds += st.seconds;
             double ms4[4] = {0, 0, 0, 0}; int64_t napp = 0;
             if (step_profile && dmrgx_kron_plan_timing_read(H->plan, ms4, &napp)) SETERRQ1(mpi_comm, 1, "dmrgx_kron_plan_timing_read: %s", dmrgx_last_error());
@@ -819,7 +822,7 @@ public:
 
     /** Fills `guess` (device, layout of KronBlocks) from the previous step if the two steps are consecutive positions
         of a sweep; returns used = false (guess untouched) otherwise or when any dimension does not line up. */
-    PetscErrorCode TransformedGuess(KronBlocks_t& KronBlocks, Block& SysBlock, Block& EnvBlock, const Vec& guess, bool& used)
+    PetscErrorCode TransformedGuess(KronBlocks_t& KronBlocks, Block& SysBlock, Block& EnvBlock, const Vec& guess, bool& used, double& min_norm2)
     {
         used = false;
         bool projected = false;
@@ -976,16 +979,13 @@ public:
         if (dmrgx_memset_zero(y, (size_t)guess->n * sizeof(double), nullptr)) SETERRQ1(mpi_comm, 1, "%s", dmrgx_last_error());
         if (dmrgx_dgemm_batch((int32_t)t1.size(), t1.data(), nullptr)) SETERRQ1(mpi_comm, 1, "wavefunction transformation: %s", dmrgx_last_error());
         if (dmrgx_dgemm_batch((int32_t)t2.size(), t2.data(), nullptr)) SETERRQ1(mpi_comm, 1, "wavefunction transformation: %s", dmrgx_last_error());
-        if (projected) {
-            /* a projection through basis overlaps drops whatever the current version of the block does not hold (sectors or parts
-               without a matching overlap cell are left zero): the previous state had norm 1, so the norm of the result says how much
-               survived.  Below one half the vector is not a start vector any more -- at zero it would "converge" at E = 0 in a solver
-               that trusts it -- and the step starts from the random vector instead.  (One dot and one look, on the projected steps of
-               the first sweep only) */
-            double n2 = 0.0;
-            if (dmrgx_dot((int64_t)guess->n, y, y, &n2, nullptr)) SETERRQ1(mpi_comm, 1, "wavefunction transformation: %s", dmrgx_last_error());
-            if (!(n2 >= 0.25)) { ++guesses_rejected; return 0; }
-        }
+        /* A projection through basis overlaps drops whatever the current version of the block does not hold (sectors or parts without
+           a matching overlap cell are left zero): the previous state had norm 1, so the norm of the result says how much survived.
+           Below one half (norm^2 < 0.25) the vector is not a start vector any more -- at zero it would "converge" at E = 0 in a solver
+           that trusts it.  The solver checks it (dmrgx_eigs_opts.min_initial_norm2) with the first coefficients it reads anyway and
+           falls back to the random vector; round 4's first version took the norm here, a synchronisation of its own in front of every
+           projected step's solve. */
+        min_norm2 = projected ? 0.25 : 0.0;
         used = true;
         if (projected) ++guesses_projected;
         return 0;

@@ -228,12 +228,18 @@ typedef struct {
      * (worth it only when a MatMult costs milliseconds).  Applies when use_initial is set; from a random start the Lanczos
      * path is used (the preconditioned iteration is twice as slow there). */
     int32_t method;
+    /* > 0 (with use_initial): the start vector is only trusted if its squared norm is at least this -- the engine's start vectors are
+     * projections of a normalised state, so their norm says how much of it survived.  A lighter vector is dropped and the solve runs
+     * from the random start vector (stats->start_rejected = 1).  The norm is read with the first coefficients that come back to the
+     * host anyway: no extra synchronisation.  0: no check beyond "not zero / NaN". */
+    double min_initial_norm2;
 } dmrgx_eigs_opts;
 
 typedef struct {
     int32_t n_matvec;       /* number of dmrgx_kron_apply calls ("superblock MatMults")                  */
     int32_t n_restart;
     int32_t converged;
+    int32_t start_rejected; /* 1: the supplied start vector was dropped (zero / NaN norm, or below min_initial_norm2)  */
     double  residual;       /* final ||H psi - e0 psi||                                                  */
     double  seconds;        /* wall time of the solve (host clock around a stream sync)                  */
 } dmrgx_eigs_stats;

@@ -100,7 +100,9 @@ def test_step_by_step_parity_with_oracle_under_truncation(tmp_path):
         for side in ("TruncErr_Sys", "TruncErr_Env"):
             assert abs(r[side] - o[side]) <= 1e-10 * abs(o[side]) + 1e-13, (r["GlobIdx"], side, r[side], o[side])
     assert max(o["TruncErr_Sys"] for o in orc.steps) > 1e-4               # the truncation was real
-    assert run["MatMults"] > 0 and timings["headers"][-2:] == ["MatMults", "RotOps"]
+    # Timings.json: the reference's seven columns first (include/DMRGBlockContainer.hpp:2568-2583), the engine's own after them
+    assert run["MatMults"] > 0 and timings["headers"] == ["GlobIdx", "Total", "Enlr", "Kron", "Diag", "Rdms", "Rotb", "MatMults", "RotOps", "AllGatherMs", "ApplyMs"]
+    assert all(len(r) == len(timings["headers"]) for r in timings["table"])
     # correlators: same measurement steps, same values as the oracle's restatement
     corr = json.load(open(str(tmp_path) + "/Correlations.json"))
     orc2 = DMRGOracle(H, 4, qn_sector=1.0)

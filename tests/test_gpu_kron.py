@@ -166,7 +166,19 @@ def test_eigs_null_or_nan_start_vector_is_not_trusted(mods):
                 psi0[3] = float("nan")
             e0, psi, stats = plan.eigs_lowest(tol=1e-12, seed=9, psi0=psi0, method=method)
             assert stats.converged == 1 and abs(e0 - w[0]) <= 1e-10 * abs(w[0]), (method, bad, e0, w[0])
-            assert abs(float(psi.norm()) - 1.0) < 1e-12
+            assert abs(float(psi.norm()) - 1.0) < 1e-12 and stats.start_rejected == 1
+        # a start vector that lost most of its weight (the engine asks for |psi0|^2 >= 0.25 of its projected vectors): dropped when the
+        # caller says so, used when not -- seen from the number of MatMults (the exact ground state as start converges at once)
+        _, gs, ref = plan.eigs_lowest(tol=1e-12, seed=9, method=0)
+        light = 0.3 * gs
+        e1, _, used = plan.eigs_lowest(tol=1e-10, seed=9, psi0=light, method=method)
+        e2, psi2, dropped = plan.eigs_lowest(tol=1e-10, seed=9, psi0=light, method=method, min_initial_norm2=0.25)
+        e3, _, kept = plan.eigs_lowest(tol=1e-10, seed=9, psi0=0.6 * gs, method=method, min_initial_norm2=0.25)
+        assert used.start_rejected == 0 and kept.start_rejected == 0 and dropped.start_rejected == 1
+        assert used.n_matvec <= 4 and kept.n_matvec <= 4 and dropped.n_matvec > 10, (used.n_matvec, kept.n_matvec, dropped.n_matvec)
+        for e in (e1, e2, e3):
+            assert abs(e - w[0]) <= 1e-9 * abs(w[0])
+        assert abs(float(psi2.norm()) - 1.0) < 1e-12
     plan.destroy()
 
 
