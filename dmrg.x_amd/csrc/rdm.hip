@@ -840,7 +840,22 @@ static dmrgx_status rdm_create_impl(const dmrgx_sectors* left, const dmrgx_secto
         if (!cn.empty()) hipLaunchKernelGGL(colnorm_kernel, dim3((maxc + 63) / 64, (unsigned)cn.size()), dim3(256), 0, st, (const ColNormTask*)packed_at<ColNormTask>(dtab, o_c), buf, buf);
         DMRGX_HIP(hipGetLastError());
         if (!rq.empty()) DMRGX_HIP(hipMemcpyAsync(rq.data(), buf + rq_base, rq.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+        std::vector<double> ew(use_dc ? rq.size() : 0);
+        if (!ew.empty()) DMRGX_HIP(hipMemcpyAsync(ew.data(), buf + ew_base, ew.size() * sizeof(double), hipMemcpyDeviceToHost, st));
         DMRGX_HIP(hipStreamSynchronize(st));
+        // Two independent routes to every eigenvalue: the secular equations of the divide and conquer (ew, ascending, column c of V) and
+        // the Rayleigh quotient of the finished column c (rq, what the caller gets).  They agree to round-off; a failed leaf or secular
+        // solve (NaN, a wrong root) shows here instead of as a wrong truncation further down.
+        for (int mi = 0; mi < nm && !ew.empty(); ++mi) {
+            const MatDesc& m = P->mats[mi];
+            if (m.n <= 0) continue;
+            const double *a = ew.data() + (diag_off[mi] - diag_base), *b = rq.data() + (diag_off[mi] - diag_base);
+            double scale = 0.0, worst = 0.0;
+            bool bad = false;
+            for (int32_t c = 0; c < m.n; ++c) { scale = std::max(scale, std::fabs(a[c])); const double d = std::fabs(a[c] - b[c]); if (!(d <= worst)) worst = d; if (!(d == d)) bad = true; }
+            if (bad || !(worst <= 1e-8 * scale + 1e-300))
+                DMRGX_FAIL(DMRGX_ERR_NOTCONV, "rdm_create: density matrix %d (n = %d): the direct solver's eigenvalues and the Rayleigh quotients of its vectors differ by %.3e (largest eigenvalue %.3e)", mi, m.n, worst, scale);
+        }
     }
     stage("rayleigh");
     // ---- sort descending on the host, remember the column of V for each rank ------------------------------------

@@ -22,7 +22,11 @@ struct SymEigMat {
 
 constexpr int SYMEIG_MAX_N = 3072;     // the merge kernels keep O(n) vectors of one sub-problem in LDS
 
-// Enqueue the eigendecomposition of every matrix on `st` (asynchronous; workspace comes from the stream-ordered pool).
+// Enqueue the eigendecomposition of every matrix on `st`; workspace comes from the stream-ordered pool.  The results are only valid
+// after `st` has been synchronised by the caller -- but the call is NOT free of host synchronisation: when the persistent
+// tridiagonalisation ran, the call waits for it once (it reads the kernel's status word to decide between carrying on and repeating
+// the step by launches) before it enqueues the rest, and the WY factors run on an internal second stream that joins `st` again
+// before the call returns.
 dmrgx_status symeig_batched(const std::vector<SymEigMat>& mats, hipStream_t st);
 
 // The tridiagonalisation normally runs as ONE persistent launch with the matrices resident in the LDS of most CUs of the
