@@ -242,16 +242,18 @@ basis_rotate_kernel(const double* __restrict__ V, int64_t ldv, int m, const doub
 }
 
 // Generalized Davidson: u = V y, r = W y - theta u (W = H V), t = r / (theta - D) with |theta - D| kept away from 0.
-// Writes t; partial[b] = sum_e r[e]^2.
+// Writes t; partial[b] = sum_e r[e]^2.  The Ritz coefficients come by value in the kernel arguments: the host has just computed them,
+// and an upload of their own was a stream operation (staging copy + blit launch) in front of every correction vector.
+struct RitzCoef { double y[MAX_NCV]; };
 __global__ void __launch_bounds__(DOT_THREADS)
-ritz_precond_kernel(const double* __restrict__ V, const double* __restrict__ W, int64_t ldv, int nv, const double* __restrict__ y, double theta,
+ritz_precond_kernel(const double* __restrict__ V, const double* __restrict__ W, int64_t ldv, int nv, const RitzCoef y, double theta,
                     const double* __restrict__ D, double floor_, double* __restrict__ t, int64_t n, double* __restrict__ partial)
 {
     // (Olsen's correction t - (u.t / u.t2) t2 with t2 = u / (theta - D) was measured in round 3 -- 2 436 instead of 2 431 MatMults in a
     //  sweep of configs[3]: with a diagonal preconditioner it is noise -- and is not part of the library)
     __shared__ double ys[MAX_NCV];
     __shared__ double red[DOT_THREADS / 64];
-    if (threadIdx.x < nv) ys[threadIdx.x] = y[threadIdx.x];
+    if (threadIdx.x < nv) ys[threadIdx.x] = y.y[threadIdx.x];
     __syncthreads();
     double nrm = 0.0;
     for (int64_t e = (int64_t)blockIdx.x * DOT_THREADS + threadIdx.x; e < n; e += (int64_t)gridDim.x * DOT_THREADS) {
@@ -370,12 +372,13 @@ extern "C" dmrgx_status dmrgx_eigs_comm_timing(double* allgather_ms, double* app
     return DMRGX_OK;
 }
 
-// Eight pinned doubles per host thread for scalars that travel to the host behind the solver's own synchronisations
-// ([2]: squared norm of a caller-supplied start vector).
+// Pinned doubles per host thread for what travels to the host behind the solver's own synchronisations: [0, 8) scalars ([2]: squared
+// norm of a caller-supplied start vector), [8, 8 + MAX_NCV + 2) the newest column of the projected matrix of the Davidson iteration
+// (a read-back into pageable memory is staged and blocks the host for ~20 us; one per MatMult).
 static double* pinned_scalars()
 {
     static thread_local double* p = nullptr;
-    if (!p && hipHostMalloc((void**)&p, 64, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); p = nullptr; }
+    if (!p && hipHostMalloc((void**)&p, (8 + MAX_NCV + 2) * sizeof(double), hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); p = nullptr; }
     return p;
 }
 // A start vector is not trusted when its norm is zero / NaN (seen from the first coefficients) or below what the caller asked for.
@@ -743,7 +746,9 @@ static dmrgx_status eigs_davidson(dmrgx_kron_plan* plan, const dmrgx_eigs_opts* 
     if (pin) { pin[2] = 0.0; DMRGX_HIP(hipMemcpyAsync(pin + 2, c2, sizeof(double), hipMemcpyDeviceToHost, st)); }      // c2[0] = |start vector|^2; read after the first look
     mark("start vector");
 
-    std::vector<double> G((size_t)m * m, 0.0), th, Y, hcol((size_t)MAX_NCV + 2), ydev;
+    std::vector<double> G((size_t)m * m, 0.0), th, Y, ydev;
+    if (!pin) DMRGX_FAIL(DMRGX_ERR_MEM, "eigs_lowest (gd): no pinned host memory for the read-backs");
+    double* const hcol = pin + 8;
     int j = 0, n_matvec = 0, restarts = 0, converged = 0;
     double lambda = 0.0, resid = 0.0;
     const double floor_rel = 1e-3;
@@ -762,7 +767,7 @@ static dmrgx_status eigs_davidson(dmrgx_kron_plan* plan, const dmrgx_eigs_opts* 
         DMRGX_CHK(matvec(vec(j), wvec(j)));
         ++n_matvec;
         DMRGX_CHK(multi_dot(j + 1, wvec(j), c1));                                  // column j of G = V^T w_j
-        DMRGX_HIP(hipMemcpyAsync(hcol.data(), c1, (size_t)(j + 2) * sizeof(double), hipMemcpyDeviceToHost, st));
+        DMRGX_HIP(hipMemcpyAsync(hcol, c1, (size_t)(j + 2) * sizeof(double), hipMemcpyDeviceToHost, st));
         DMRGX_HIP(hipStreamSynchronize(st));
         if (n_matvec == 1 && (!(hcol[1] > 0.0) || start_too_light(opts, pin))) {       // |H v_0|^2 is not positive: the start vector had zero (or NaN) norm -- see the Lanczos path; or it is lighter than the caller accepts
             dmrgx_eigs_opts o2 = *opts;
@@ -797,9 +802,10 @@ static dmrgx_status eigs_davidson(dmrgx_kron_plan* plan, const dmrgx_eigs_opts* 
         ritz_is_v0 = false;
         ydev.assign((size_t)mm, 0.0);
         for (int i = 0; i < mm; ++i) ydev[(size_t)i] = Y[(size_t)i * mm + 0];
-        DMRGX_HIP(h2d_async(dY.p, ydev.data(), ydev.size() * sizeof(double), st));
+        RitzCoef yarg;
+        for (int i = 0; i < mm; ++i) yarg.y[i] = ydev[(size_t)i];
         const double floor_ = floor_rel * std::max(1.0, std::fabs(lambda)) * 1e-2 + 1e-12;
-        hipLaunchKernelGGL(ritz_precond_kernel, dim3(nblk), dim3(DOT_THREADS), 0, st, (const double*)V, (const double*)W, n, mm, (const double*)dY.as<double>(), lambda,
+        hipLaunchKernelGGL(ritz_precond_kernel, dim3(nblk), dim3(DOT_THREADS), 0, st, (const double*)V, (const double*)W, n, mm, yarg, lambda,
                            (const double*)dD.as<double>(), floor_, t, n, dPartial.as<double>());
         DMRGX_HIP(hipGetLastError());
         hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(DOT_THREADS), 0, st, dPartial.as<double>(), nrm, 1, nblk);
