@@ -69,10 +69,11 @@ inline void ggemm_append_tiles_mixed(std::vector<GTile>& big, std::vector<GTile>
 // tile row) stay on one XCD for L2 reuse, clusters are dealt longest-first to the least-loaded XCD (LPT), and each
 // XCD runs its longest clusters first so the tail is made of short tiles.  Lists are padded with group = -1.
 //
-// Since round 4 the launch keeps `ggemm_slots` RESIDENT workgroups (every workgroup slot of the chip) and workgroup w walks the
-// entries w, w + slots, w + 2 slots, ... of the scheduled list: the tiles of an XCD are dealt, in cluster order, to the
-// workgroup of that XCD with the least work so far.  On the device GTile::pad is the index of the group's first GEMM product
-// -- -1 if it has none -- (on the host, before scheduling, the tile's cost in k-steps), which is why the scheduler needs the groups.
+// Since round 4 the launch keeps `ggemm_slots` RESIDENT workgroups (every workgroup slot of the chip): workgroup b starts on entry b of
+// the scheduled list and then claims the next unclaimed entry of its XCD's queue (entries x, x + 8, x + 16, ... belong to XCD x) with
+// one atomic per tile, so a queue is worked off in order by whichever workgroup of that XCD is free.  On the device GTile::pad is the
+// index of the group's first GEMM product -- -1 if it has none -- (on the host, before scheduling, the tile's cost in k-steps), which is
+// why the scheduler needs the groups.
 // EVERY list handed to ggemm_launch must have gone through ggemm_schedule.
 int ggemm_slots(int unit = 1);
 void ggemm_schedule_core(std::vector<GTile>& tiles, const std::vector<int32_t>& first_gemm_product_of_group, int unit);

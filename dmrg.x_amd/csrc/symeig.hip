@@ -1373,8 +1373,8 @@ dmrgx_status symeig_batched(const std::vector<SymEigMat>& mats_in, hipStream_t s
     // need the tridiagonalisation only, and neither fills the chip: the WY chain goes to a second stream and joins in front of the
     // back-transformation (m = 512: ~100 us per call; timeline in profiles/r04_rdm_timeline_m512.txt).
     const bool any_blk = max_nblk > 0;
-    static hipStream_t side = nullptr;
-    static hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    static thread_local hipStream_t side = nullptr;            // (one per host thread: callers on different threads / devices do not share it)
+    static thread_local hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     if (any_blk) {
         if (!side) {
             DMRGX_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
