@@ -4,7 +4,8 @@ as module:function (so time blocked inside the HIP runtime shows up as such)."""
 import bisect, collections, os, subprocess, sys
 
 path, top = sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 45
-exclude = sys.argv[3].split(",") if len(sys.argv) > 3 else []      # drop samples with one of these substrings in the stack ("the rest of the step")
+exclude = [x for x in sys.argv[3].split(",") if x] if len(sys.argv) > 3 else []      # drop samples with one of these substrings in the stack ("the rest of the step")
+include = [x for x in sys.argv[4].split(",") if x] if len(sys.argv) > 4 else []      # keep only samples with one of these substrings in the stack
 maps, samples = [], []
 for l in open(path):
     if l.startswith("M "):
@@ -58,6 +59,7 @@ for s in samples:
     if not fr: continue
     ntot += 1
     if exclude and any(x in f for _, f in fr for x in exclude): continue
+    if include and not any(x in f for _, f in fr for x in include): continue
     n += 1
     leaf[fr[0][0] + ":" + fr[0][1][:70]] += 1
     seen = set()
