@@ -102,6 +102,8 @@ struct dmrgx_comm {
     char* slots = nullptr;
     size_t map_bytes = 0, slot_bytes = 0;
     std::vector<char> host;         // pageable staging buffer
+    char* pinned = nullptr;         // RCCL back-end: pinned staging of small host payloads (dmrgx_comm_allgather_host), grown on demand
+    size_t pinned_bytes = 0;
 };
 
 extern "C" dmrgx_status dmrgx_set_device(int32_t device)
@@ -297,12 +299,21 @@ extern "C" dmrgx_status dmrgx_comm_allgather_host(dmrgx_comm* C, const void* sen
         const size_t seg = (bytes_per_rank + 7) & ~(size_t)7, need = seg * (size_t)C->world;
         if (C->scratch.bytes < need) DMRGX_CHK(C->scratch.alloc(need));
         char* d = C->scratch.as<char>();
-        DMRGX_HIP(hipMemcpyAsync(d + (size_t)C->rank * seg, send, bytes_per_rank, hipMemcpyHostToDevice, st));
+        // host -> pinned -> device, all-gather on the device, device -> pinned -> host: three asynchronous operations and ONE wait (copies
+        // from and to pageable memory are staged by the runtime and block the host once each: two extra stalls per truncation step)
+        if (C->pinned_bytes < need + seg) {
+            if (C->pinned) { DMRGX_HIP(hipStreamSynchronize(st)); (void)hipHostFree(C->pinned); C->pinned = nullptr; C->pinned_bytes = 0; }
+            DMRGX_HIP(hipHostMalloc((void**)&C->pinned, 2 * (need + seg), hipHostMallocDefault));
+            C->pinned_bytes = 2 * (need + seg);
+        }
+        char* hs = C->pinned;              // this rank's segment going out
+        char* hr = C->pinned + seg;        // everybody's segments coming back
+        memcpy(hs, send, bytes_per_rank);
+        DMRGX_HIP(hipMemcpyAsync(d + (size_t)C->rank * seg, hs, bytes_per_rank, hipMemcpyHostToDevice, st));
         DMRGX_NCCL(C->api, C->api->AllGather(d + (size_t)C->rank * seg, d, seg, ncclChar, C->nccl, st));
-        std::vector<char> h(need);
-        DMRGX_HIP(hipMemcpyAsync(h.data(), d, need, hipMemcpyDeviceToHost, st));
+        DMRGX_HIP(hipMemcpyAsync(hr, d, need, hipMemcpyDeviceToHost, st));
         DMRGX_HIP(hipStreamSynchronize(st));
-        for (int p = 0; p < C->world; ++p) memcpy((char*)recv + (size_t)p * bytes_per_rank, h.data() + (size_t)p * seg, bytes_per_rank);
+        for (int p = 0; p < C->world; ++p) memcpy((char*)recv + (size_t)p * bytes_per_rank, hr + (size_t)p * seg, bytes_per_rank);
         return DMRGX_OK;
     }
     DMRGX_HIP(hipStreamSynchronize(st));
@@ -338,6 +349,7 @@ extern "C" dmrgx_status dmrgx_comm_destroy(dmrgx_comm* C)
     if (!C) return DMRGX_OK;
     if (C->backend == DMRGX_COMM_RCCL && C->nccl) { (void)hipDeviceSynchronize(); (void)C->api->CommDestroy(C->nccl); }
     if (C->hdr) munmap((void*)C->hdr, C->map_bytes);
+    if (C->pinned) (void)hipHostFree(C->pinned);
     delete C;
     return DMRGX_OK;
 }
