@@ -239,8 +239,9 @@ def _medium_golden():
     return json.load(open(os.path.join(ROOT, "tests", "golden", "engine_medium_m.json")))
 
 
-@pytest.mark.parametrize("name,ranks", [("j1j2_10x4_sz1", 1), ("j1j2_8x4_sz1", 1), ("j1j2_8x4_sz1", 2), ("xxz_8x6_sz1", 1), ("j1j2_6x4_sz1", 1)])
-def test_medium_m_step_by_step_against_the_oracle(tmp_path, name, ranks):
+@pytest.mark.parametrize("name,ranks,extra", [("j1j2_10x4_sz1", 1, ()), ("j1j2_8x4_sz1", 1, ()), ("j1j2_8x4_sz1", 2, ()), ("xxz_8x6_sz1", 1, ()), ("j1j2_6x4_sz1", 1, ()),
+                                              ("j1j2_6x4_sz1", 3, ()), ("j1j2_6x4_sz1", 1, ("-rdm_warm_start", 1)), ("j1j2_6x4_sz1", 1, ("-H_eps_type", "gd"))])
+def test_medium_m_step_by_step_against_the_oracle(tmp_path, name, ranks, extra):
     """The engine against the CPU oracle's DMRG step by step at m = 24 ... 48, where the code paths of the production sizes run inside
     the engine: enlarged sectors of 20-35 states are diagonalised by divide and conquer with real merges and deflation
     (csrc/symeig.hip, leaves of 16), back-transformed through WY blocks, and every GEMM tile spans several 16 x 16 MFMA blocks
@@ -249,11 +250,12 @@ def test_medium_m_step_by_step_against_the_oracle(tmp_path, name, ranks):
     up small, grow m sweep by sweep and turn round `-min_block` sites before the edge: only then is every m-cut decided by the spectrum
     and not by round-off.  Up to the first ill-defined cut -- 70-180 steps into a run, in its last sweep -- sizes, energies and both
     truncation errors agree at 1e-10; across the four runs that is more than 150 steps at m >= 24.  After it, energies agree at the
-    truncation-error scale.  Match: include/DMRGBlockContainer.hpp:1656-2057, src/DMRGBlock.cpp:766-771."""
+    truncation-error scale.  The smallest run is repeated on three ranks (density matrices dealt over the ranks, striped solve), with the
+    warm-started density-matrix solver and with the generalized-Davidson solver type.  Match: include/DMRGBlockContainer.hpp:1656-2057, src/DMRGBlock.cpp:766-771."""
     g = _medium_golden()[name]
     o = g["options"]
     rows, run, _ = run_engine(tmp_path, "-Lx", o["Lx"], "-Ly", o["Ly"], "-J1", o["J1"], "-Jz1", o["Jz1"], "-J2", o["J2"], "-Jz2", o["Jz2"], "-qn_sector", g["qn_sector"],
-                              "-mwarmup", g["mwarmup"], "-msweeps", ",".join(str(m) for m in g["msweeps"]), "-min_block", g["min_block"], "-H_eps_tol", 1e-13, ranks=ranks)
+                              "-mwarmup", g["mwarmup"], "-msweeps", ",".join(str(m) for m in g["msweeps"]), "-min_block", g["min_block"], "-H_eps_tol", 1e-13, *extra, ranks=ranks)
     steps = g["steps"]
     assert len(rows) == len(steps) and run["Ranks"] == ranks
     first_ill = next((i for i, st in enumerate(steps) if not st["well_defined"]), len(steps))
