@@ -240,7 +240,8 @@ def _medium_golden():
 
 
 @pytest.mark.parametrize("name,ranks,extra", [("j1j2_10x4_sz1", 1, ()), ("j1j2_8x4_sz1", 1, ()), ("j1j2_8x4_sz1", 2, ()), ("xxz_8x6_sz1", 1, ()), ("j1j2_6x4_sz1", 1, ()),
-                                              ("j1j2_6x4_sz1", 3, ()), ("j1j2_6x4_sz1", 1, ("-rdm_warm_start", 1)), ("j1j2_6x4_sz1", 1, ("-H_eps_type", "gd"))])
+                                              ("j1j2_6x4_sz1", 3, ()), ("j1j2_6x4_sz1", 1, ("-rdm_warm_start", 1)), ("j1j2_6x4_sz1", 1, ("-H_eps_type", "gd")),
+                                              ("j1j2_10x4_sz1", 1, ("-H_eps_type", "gd")), ("j1j2_8x4_sz1", 2, ("-H_eps_type", "gd")), ("xxz_8x6_sz1", 2, ())])
 def test_medium_m_step_by_step_against_the_oracle(tmp_path, name, ranks, extra):
     """The engine against the CPU oracle's DMRG step by step at m = 24 ... 48, where the code paths of the production sizes run inside
     the engine: enlarged sectors of 20-35 states are diagonalised by divide and conquer with real merges and deflation
