@@ -1415,16 +1415,36 @@ public:
         BasisTransformation* BT[2] = {&BT_L, &BT_R};
         for (int side = 0; side < 2; ++side) {
             std::vector<Eigen_t> eigen;
+            eigen.reserve((size_t)(spec_off[(size_t)(2 * nb)] / 2 + 1));
+            std::vector<size_t> run_end;                                   /* ends of the per-KronBlock runs of `eigen` */
+            bool runs_sorted = true;
             for (PetscInt k = 0; k < nb; ++k) {
                 const PetscInt blk = side == 0 ? bil[k] : bir[k], n = M[side]->Sizes(blk);
                 const double* w = spectra.data() + spec_off[(size_t)(2 * k + side)];
-                for (PetscInt e = 0; e < n; ++e) eigen.push_back({w[(size_t)e], k, e, blk});
+                for (PetscInt e = 0; e < n; ++e) { eigen.push_back({w[(size_t)e], k, e, blk}); if (e > 0 && w[(size_t)e] > w[(size_t)e - 1]) runs_sorted = false; }
+                run_end.push_back(eigen.size());
             }
             ierr = SaveEntanglementSpectrum(side, eigen, *M[side]); CHKERRQ(ierr);
-            std::stable_sort(eigen.begin(), eigen.end(), greater_eigval);
+            /* stable_sort(greater_eigval) of the reference (include/DMRGBlockContainer.hpp:1795).  Every block's spectrum arrives in
+               descending order, so the stable sort is a stable merge of nb sorted runs (ties keep the KronBlock order either way):
+               log2(nb) merge passes instead of log2(#eigenvalues) -- 0.2 ms of a configs[3] step went into the sort
+               (profiles/r04_hostprof_glue_m2048.txt).  Should a run not be sorted, the sort itself is done. */
+            auto gt = [](const Eigen_t& a, const Eigen_t& b) { return a.eigval > b.eigval; };
+            if (runs_sorted) {
+                std::vector<size_t> ends = run_end;
+                while (ends.size() > 1) {
+                    std::vector<size_t> next;
+                    size_t begin = 0;
+                    for (size_t r = 0; r < ends.size(); r += 2) {
+                        if (r + 1 < ends.size()) { std::inplace_merge(eigen.begin() + (std::ptrdiff_t)begin, eigen.begin() + (std::ptrdiff_t)ends[r], eigen.begin() + (std::ptrdiff_t)ends[r + 1], gt); begin = ends[r + 1]; next.push_back(ends[r + 1]); }
+                        else { begin = ends[r]; next.push_back(ends[r]); }
+                    }
+                    ends.swap(next);
+                }
+            } else std::stable_sort(eigen.begin(), eigen.end(), gt);
             const PetscInt m = PetscMin(MStates, (PetscInt)eigen.size());
             eigen.resize((size_t)m);
-            std::stable_sort(eigen.begin(), eigen.end(), less_blkIdx);
+            std::stable_sort(eigen.begin(), eigen.end(), [](const Eigen_t& a, const Eigen_t& b) { return a.blkIdx < b.blkIdx; });   /* stable_sort(less_blkIdx), :1852 */
             PetscReal trunc = 1.0;
             for (const Eigen_t& e : eigen) trunc -= (e.eigval > 0) * e.eigval;
             BT[side]->TruncErr = trunc;
