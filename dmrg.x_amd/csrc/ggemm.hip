@@ -777,47 +777,55 @@ static inline int64_t tile_cost(const GTile& t) { return 4 * (int64_t)t.pad + 12
 
 void ggemm_schedule_core(std::vector<GTile>& tiles, const std::vector<int32_t>& first_gemm, int unit)
 {
+    // (host cost matters: every grouped-GEMM user calls this once per list, ~40 lists in a sweep step, 30 000 tiles in the MatMult's --
+    //  shifts instead of divisions, one pass per stage, the output written in place: profiles/r04_hostprof_glue_m2048.txt)
     constexpr int NX = 8;
     if (tiles.empty()) return;
-    struct Cl { size_t begin, end; int64_t cost; };
-    std::vector<Cl> cl;
-    for (size_t i = 0; i < tiles.size();) {
+    struct Cl { uint32_t begin, end; int32_t len16; int64_t cost; };
+    static_assert(GG_CLUSTER == 8, "cluster edge as a shift");
+    const int sh = unit == 2 ? 4 : 3;                 // tiles of 128 x 128 carry tm / tn in units of 64: a cluster is 16 units wide
+    static thread_local std::vector<Cl> cl;
+    cl.clear();
+    const size_t nt = tiles.size();
+    for (size_t i = 0; i < nt;) {
         size_t j = i;
         int64_t c = 0;
         // a cluster = the consecutive tiles of one group inside one GG_CLUSTER x GG_CLUSTER block of its tile grid
-        const int W = GG_CLUSTER * unit, cm = tiles[i].tm / W, cn = tiles[i].tn / W;
-        while (j < tiles.size() && tiles[j].group == tiles[i].group && tiles[j].tm / W == cm && tiles[j].tn / W == cn && j - i < 256) { c += tile_cost(tiles[j]); ++j; }
-        cl.push_back(Cl{i, j, c});
+        const int32_t grp = tiles[i].group, cm = tiles[i].tm >> sh, cn = tiles[i].tn >> sh;
+        while (j < nt && tiles[j].group == grp && (tiles[j].tm >> sh) == cm && (tiles[j].tn >> sh) == cn && j - i < 256) { c += tile_cost(tiles[j]); ++j; }
+        cl.push_back(Cl{(uint32_t)i, (uint32_t)j, tiles[i].pad >> 4, c});
         i = j;
     }
     std::stable_sort(cl.begin(), cl.end(), [](const Cl& a, const Cl& b) { return a.cost > b.cost; });
     // clusters go to the least-loaded XCD, heaviest first (LPT) ...
-    std::vector<std::vector<Cl>> binc(NX);
+    static thread_local std::vector<Cl> binc[NX];
     int64_t load[NX] = {0};
+    size_t count[NX] = {0};
+    for (int x = 0; x < NX; ++x) binc[x].clear();
     for (const Cl& c : cl) {
         int best = 0;
         for (int x = 1; x < NX; ++x) if (load[x] < load[best]) best = x;
         load[best] += c.cost;
+        count[best] += c.end - c.begin;
         binc[best].push_back(c);
     }
-    // ... and inside an XCD the clusters with the LONGEST tiles run first, whatever their total: the launch ends when the
-    // last tile ends, so the tail should be made of the shortest tiles, not of a small cluster of long ones
-    std::vector<std::vector<GTile>> bins(NX);
     size_t maxbin = 0;
-    for (int x = 0; x < NX; ++x) {
-        // (coarse buckets of 16 k-steps, stable: clusters of similar tile length keep the LPT order, which keeps the clusters
-        //  of one group -- same operands -- close together)
-        std::stable_sort(binc[x].begin(), binc[x].end(), [&](const Cl& a, const Cl& b) { return (tiles[a.begin].pad >> 4) > (tiles[b.begin].pad >> 4); });
-        for (const Cl& c : binc[x]) for (size_t t = c.begin; t < c.end; ++t) bins[x].push_back(tiles[t]);
-        maxbin = std::max(maxbin, bins[x].size());
-    }
+    for (int x = 0; x < NX; ++x) maxbin = std::max(maxbin, count[x]);
     // eight interleaved per-XCD queues, padded with group = -1: workgroup b starts on entry b, the resident workgroups of an XCD
     // then claim the rest of its queue in order (a cluster's tiles next to each other, so that they run at the same time and meet in
-    // the L2); see the kernel
-    std::vector<GTile> out(maxbin * NX, GTile{-1, 0, 0, 0});
-    for (int x = 0; x < NX; ++x) for (size_t i = 0; i < bins[x].size(); ++i) out[i * NX + x] = bins[x][i];
-    // device meaning of GTile::pad: the group's first GEMM product (both descriptor loads of a tile then depend on the tile record only)
-    for (GTile& t : out) t.pad = t.group >= 0 ? first_gemm[(size_t)t.group] : -1;
+    // the L2); see the kernel.  Device meaning of GTile::pad: the group's first GEMM product (both descriptor loads of a tile then
+    // depend on the tile record only).
+    std::vector<GTile> out(maxbin * NX, GTile{-1, 0, 0, -1});
+    for (int x = 0; x < NX; ++x) {
+        // ... and inside an XCD the clusters with the LONGEST tiles run first, whatever their total: the launch ends when the
+        // last tile ends, so the tail should be made of the shortest tiles, not of a small cluster of long ones
+        // (coarse buckets of 16 k-steps, stable: clusters of similar tile length keep the LPT order, which keeps the clusters
+        //  of one group -- same operands -- close together)
+        std::stable_sort(binc[x].begin(), binc[x].end(), [](const Cl& a, const Cl& b) { return a.len16 > b.len16; });
+        size_t pos = (size_t)x;
+        for (const Cl& c : binc[x])
+            for (uint32_t t = c.begin; t < c.end; ++t, pos += NX) { GTile v = tiles[t]; v.pad = first_gemm[(size_t)v.group]; out[pos] = v; }
+    }
     tiles.swap(out);
 }
 
