@@ -100,9 +100,10 @@ dmrgx_status upload(DevBuf& buf, const std::vector<T>& host, hipStream_t st) {
 struct PackedUpload {
     std::vector<char> host;
     template <class T> size_t add(const std::vector<T>& v) {
-        const size_t off = (host.size() + 15) & ~(size_t)15;
-        host.resize(off + v.size() * sizeof(T));
-        if (!v.empty()) memcpy(host.data() + off, v.data(), v.size() * sizeof(T));
+        const size_t off = (host.size() + 15) & ~(size_t)15, bytes = v.size() * sizeof(T);
+        if (host.capacity() < off + bytes) host.reserve(std::max(2 * host.capacity(), off + bytes + (bytes >> 1)));
+        host.resize(off);                                                       // (alignment padding only: the table itself is appended, not zero-filled first)
+        if (bytes) { const char* p = reinterpret_cast<const char*>(v.data()); host.insert(host.end(), p, p + bytes); }
         return off;
     }
     dmrgx_status upload(DevBuf& buf, hipStream_t st) {
