@@ -29,7 +29,7 @@ F64_PEAK_TFLOPS = 78.6   # MI355X dense f64 MFMA peak (AMD datasheet; v_mfma_f64
 HBM_PEAK_TBS = 8.0
 
 
-def cpu_baseline(sb, budget_s=15.0):
+def cpu_baseline(sb, budget_s=15.0, gpu_apply=None):
     """Literal reference row loop (oracle/kron_ref.c) on all host cores over evenly spread row chunks."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from helpers import oracle_shell_from_superblock
@@ -42,15 +42,21 @@ def cpu_baseline(sb, budget_s=15.0):
     nthreads = int(os.environ.get("DMRGX_CPU_THREADS", min(len(os.sched_getaffinity(0)), 16)))   # box share: 16 cores per GPU
     nchunk = 8
 
+    y_gpu = gpu_apply(x) if gpu_apply is not None else None
+    scale = float(np.abs(y_gpu).max()) if y_gpu is not None else 1.0
+    parity = [0.0]
+
     def run(rows):
         rows = int(min(max(rows, 8 * nthreads), N // nchunk))
         t, f = 0.0, 0.0
         for c in range(nchunk):
             r0 = max(0, min(N - rows, int((c + 0.5) * N / nchunk) - rows // 2))
             t0 = time.perf_counter()
-            ref.apply(x, r0, r0 + rows, nthreads)
+            yr = ref.apply(x, r0, r0 + rows, nthreads)
             t += time.perf_counter() - t0
             f += float(ref.flops(r0, r0 + rows))
+            if y_gpu is not None:       # the sampled rows of the literal row loop against the timed GPU path (checker, outside every timed region)
+                parity[0] = max(parity[0], float(np.abs(yr[r0:r0 + rows] - y_gpu[r0:r0 + rows]).max() / scale))
         return t, f, rows * nchunk
     rows = 8 * nthreads
     t, f, nrows = run(rows)
@@ -58,13 +64,19 @@ def cpu_baseline(sb, budget_s=15.0):
         rows = int(rows * min(8.0, max(2.0, 0.8 * budget_s / max(t, 1e-3))))
         t, f, nrows = run(rows)
     full_time = t * total_flops / f
+    # the row loop adds the ~1e7 products of a row one after the other: its own rounding error is eps sqrt(products per row) relative
+    # to the row's magnitude (the two CPU statements differ by 1.5e-13 at m = 2048) -- the bar of tests/test_gpu_kron.py
+    tol_rows = max(1e-13, float(np.finfo(float).eps) * (total_flops / 2.0 / N) ** 0.5)
+    if y_gpu is not None:
+        assert parity[0] <= tol_rows, f"GPU MatMult differs from the reference row loop on the sampled rows: {parity[0]} > {tol_rows}"
     return {"value": 1.0 / full_time, "unit": "MatMults/s", "cores": int(ref.threads_used), "kind": "port",
+            "parity_max_rel_err": parity[0] if y_gpu is not None else None, "parity_tolerance": tol_rows,
             "sample": f"{nrows} of {N} rows in {nchunk} evenly spread chunks ({t:.1f} s measured, "
                       f"{f / t / 1e9:.1f} GF/s unfactored), extrapolated by the row loop's exact flop count "
                       f"({total_flops / 1e9:.0f} GF per MatMult)"}
 
 
-def cpu_baseline_factored(sb, reps=5):
+def cpu_baseline_factored(sb, reps=5, gpu_apply=None):
     """the same MatMult in factored, operator-merged form (oracle/kron_factored.py: per-sector numpy / OpenBLAS GEMMs,
     exactly F_alg flops) on this host's cores, timed IN FULL (every row of the superblock; median of `reps` after one warm-up)."""
     from oracle.kron_factored import FactoredApplyCPU
@@ -76,7 +88,14 @@ def cpu_baseline_factored(sb, reps=5):
         limit = None
     f = FactoredApplyCPU(sb)
     x = np.random.default_rng(0).standard_normal(sb.n_states)
-    f.apply(x)
+    y_cpu = f.apply(x)
+    # parity of the timed GPU MatMult with this CPU statement of it, on the same x: the checker, after the
+    # timed region.  Same factorisation and blocked sums on both sides: the parity tests' 1e-13 of max|y| holds at this size.
+    parity = None
+    if gpu_apply is not None:
+        y_gpu = gpu_apply(x)
+        parity = float(np.abs(y_gpu - y_cpu).max() / np.abs(y_cpu).max())
+        assert parity <= 1e-13, f"GPU MatMult differs from the CPU oracle at bench size: {parity}"
     ts = []
     for _ in range(reps):
         t0 = time.perf_counter()
@@ -85,7 +104,7 @@ def cpu_baseline_factored(sb, reps=5):
     if limit is not None:
         limit.restore_original_limits()
     t = sorted(ts)[len(ts) // 2]
-    return {"value": 1.0 / t, "unit": "MatMults/s", "cores": nthreads, "kind": "port-factored",
+    return {"value": 1.0 / t, "unit": "MatMults/s", "cores": nthreads, "kind": "port-factored", "parity_max_rel_err": parity,
             "sample": f"all {sb.n_states} rows, {reps} full applies after one warm-up (median {t:.3f} s, {f.flops / t / 1e9:.0f} GF/s on the "
                       f"{f.flops / 1e9:.1f} GF of SURVEY 8d's F_alg: terms merged per right operator, structural zeros of O(x)1 skipped)"}
 
@@ -459,8 +478,16 @@ def main():
         # two CPU statements of the same MatMult on this host: the factored, operator-merged form -- the same
         # algorithm as the HIP plan, so value / cpu_baseline.value is hardware against hardware -- and beside it the literal
         # unfactored row loop the reference executes (sampled rows, extrapolated by its exact flop count)
-        out["cpu_baseline"] = cpu_baseline_factored(sb)
-        out["cpu_baseline"]["reference_row_loop"] = cpu_baseline(sb)
+        def gpu_apply(x_host):
+            xd = torch.from_numpy(x_host).cuda()
+            yd = torch.full_like(xd, float("nan"))
+            plan.apply(xd, yd)
+            torch.cuda.synchronize()
+            return yd.cpu().numpy()
+        out["cpu_baseline"] = cpu_baseline_factored(sb, gpu_apply=gpu_apply)
+        out["parity_max_rel_err"] = out["cpu_baseline"]["parity_max_rel_err"]      # |y_gpu - y_oracle|_max / |y_oracle|_max, full-size MatMult
+        out["cpu_baseline"]["reference_row_loop"] = cpu_baseline(sb, gpu_apply=gpu_apply)
+        out["parity_rows_max_rel_err"] = out["cpu_baseline"]["reference_row_loop"]["parity_max_rel_err"]
     elif rank == 0:
         out["cpu_baseline"] = None
     if comm is not None:

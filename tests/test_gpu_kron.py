@@ -131,6 +131,90 @@ def test_full_size_properties(mods, cfg):
     plan.destroy()
 
 
+_FULL = {}
+
+
+def _full_size_oracle(wl, cfg):
+    """Superblock of a BASELINE config at FULL size with both CPU statements of its MatMult (built once per module: the set-up of the
+    literal row loop's descriptors takes 20-90 s of host time at m = 2048 / 4096)."""
+    if cfg not in _FULL:
+        from oracle.kron_factored import FactoredApplyCPU
+        sb = wl.synthetic_superblock(cfg)
+        x = np.random.default_rng(4242).standard_normal(sb.n_states)
+        y_fac = FactoredApplyCPU(sb).apply(x)
+        _FULL.clear()                                   # one full-size case in host memory at a time
+        _FULL[cfg] = (sb, x, y_fac, ShellApplyC(oracle_shell_from_superblock(sb)))
+    return _FULL[cfg]
+
+
+@pytest.mark.parametrize("cfg", ["cfg3", "cfg5", "cfg4real"])      # (cfg4real last: the striped test below shares its oracle)
+def test_full_size_apply_matches_the_oracle_numerically(mods, cfg):
+    """The MatMult at the size and in the code path the bench times: thousands of tiles per launch -- resident
+    workgroups claiming tiles from the per-XCD queues, the next tile's operands fetched beside the epilogue stores, split-K slabs at
+    K ~ 1e4 -- against BOTH CPU statements of src/DMRGKron.cpp:1827-1869: every row against the factored form (oracle/kron_factored.py)
+    and >= 4096 rows spread over all KronBlocks against the literal row loop of :1842-1864 (oracle/kron_ref.c)."""
+    sbm, wl, _ = mods
+    sb, x, y_fac, rows_ref = _full_size_oracle(wl, cfg)
+    plan = sbm.KronPlan(sb)
+    info = plan.info
+    slots = 4 * 256                                     # resident workgroups of the 64 x 64 kernel (csrc/ggemm.hip: ggemm_slots)
+    if cfg != "cfg3":                                   # m >= 2048: the launch must be in the claiming ("dyn") regime
+        assert info.n_tiles_stage1 > slots and info.n_tiles_stage2 > slots, (info.n_tiles_stage1, info.n_tiles_stage2)
+    y = _apply(plan, x)
+    scale = np.abs(y_fac).max()
+    # same factorisation, blocked summation on both sides: the small-size bar holds at full size
+    assert np.abs(y - y_fac).max() <= RTOL * scale, np.abs(y - y_fac).max() / scale
+    # the literal row loop adds the n ~ 1e7 products of a row one after the other: ITS rounding error is ~ eps sqrt(n) relative to
+    # the row's magnitude sqrt(n) sigma (random-walk bound), 1.5e-13 at m = 2048 between the two CPU statements themselves -- that,
+    # not 1e-13, is the bar a comparison with it can hold
+    off = sb.block_offsets()
+    worst, nrows = 0.0, 0
+    order = sorted(range(len(sb.blocks)), key=lambda k: off[k + 1] - off[k])      # small KronBlocks first: they give all their rows
+    for i, k in enumerate(order):
+        n = off[k + 1] - off[k]
+        take = min(n, -(-(4100 - nrows) // (len(order) - i)) + 2)
+        for r0 in {off[k], off[k] + (n - take) // 2, off[k + 1] - take}:      # first, middle and last rows of every KronBlock
+            c = -(-take // 3)
+            r0 = int(min(r0, off[k + 1] - c))
+            yr = rows_ref.apply(x, r0, r0 + c)
+            prods_per_row = rows_ref.flops(r0, r0 + c) / 2.0 / c
+            tol = max(RTOL, np.finfo(float).eps * prods_per_row ** 0.5)
+            err = np.abs(y[r0:r0 + c] - yr[r0:r0 + c]).max() / scale
+            assert err <= tol, (k, r0, err, tol)
+            worst, nrows = max(worst, err), nrows + c
+    assert nrows >= min(4096, sb.n_states // 2)
+    # the apply must be repeatable bit for bit (fixed-order slab reduction, no atomics on data; the tile claims only decide WHO computes)
+    assert np.array_equal(_apply(plan, x), y)
+    plan.destroy()
+
+
+@pytest.mark.parametrize("W", [2, 8])
+def test_full_size_striped_apply_matches_the_oracle(mods, W):
+    """Every rank's stripe of the bench's own superblock (cfg4real, full size), applied in turn on the one GPU and gathered, against the
+    factored CPU statement: the plans a --gpus 2 / --gpus 8 run would build."""
+    sbm, wl, _ = mods
+    sb, x, y_fac, _ = _full_size_oracle(wl, "cfg4real")
+    xd = torch.from_numpy(x).cuda()
+    xs = ys = None
+    for r in range(W):
+        p = sbm.KronPlan(sb, world_size=W, rank=r)
+        info = p.info
+        if xs is None:
+            xs = torch.zeros(info.vec_len, dtype=torch.float64, device="cuda")
+            p.to_striped(xd, xs)
+            ys = torch.full_like(xs, float("nan"))        # every stripe must be overwritten; the padding of a segment is never read
+        assert info.local_offset == r * info.seg_stride
+        p.apply(xs, ys[info.local_offset:info.local_offset + info.local_len])
+        if r == W - 1:
+            yd = torch.zeros_like(xd)
+            p.from_striped(ys, yd)
+            torch.cuda.synchronize()
+        p.destroy()
+    y = yd.cpu().numpy()
+    assert np.isfinite(y).all()
+    assert np.abs(y - y_fac).max() <= RTOL * np.abs(y_fac).max()
+
+
 def test_eigs_lowest_vs_dense(mods):
     sbm, wl, _ = mods
     sb = wl.synthetic_superblock("cfg2", m=32, Ly=2, seed=3)
