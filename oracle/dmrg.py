@@ -13,13 +13,15 @@ import scipy.sparse.linalg as spla
 
 from .qn import QuantumNumbers, OracleError, OpSm, OpSz, OpSp
 from .block import Block
-from .kron import KronBlocks, KronEye_Explicit, KronSumConstruct_explicit
+from .kron import KronBlocks, KronEye_Explicit, KronSumConstruct_explicit, KronSumOperator
 
 
 def lowest_eigenpair(H, seed=0, dense_below=1500, tol=1e-13):
     """EPS_HEP / EPS_SMALLEST_REAL / nev=1 (include/DMRGBlockContainer.hpp:1489-1498)."""
     N = H.shape[0]
-    if N <= dense_below:
+    if isinstance(H, KronSumOperator):
+        H = H.as_linear_operator()
+    elif N <= dense_below:
         w, v = np.linalg.eigh(H.toarray())
         return float(w[0]), v[:, 0].copy()
     rng = np.random.default_rng(seed)
@@ -122,7 +124,7 @@ def correlator_value(kb, psi, sys_ops, env_ops):
 class DMRGOracle:
     """CPU DMRG following DMRGBlockContainer<Block::SpinBase, J1J2XXZModel_SquareLattice>."""
 
-    def __init__(self, Ham, mwarmup, qn_sector=0.0, seed=1234, verbose=False):
+    def __init__(self, Ham, mwarmup, qn_sector=0.0, seed=1234, verbose=False, matrix_free_above=1 << 62):
         self.Ham = Ham
         self.mwarmup = int(mwarmup)
         self.qn_sector = float(qn_sector)
@@ -133,6 +135,7 @@ class DMRGOracle:
         self.steps = []
         self.seed = seed
         self.verbose = verbose
+        self.matrix_free_above = matrix_free_above
         self.gse = None
         self.trunc_err = []
         self.GlobIdx = 0
@@ -164,7 +167,8 @@ class DMRGOracle:
         NumSitesTotal = SysEnl.NumSites() + EnvEnl.NumSites()
         Terms = self.Ham.H(NumSitesTotal)
         kb = KronBlocks(SysEnl, EnvEnl, (self.qn_sector,))
-        H = KronSumConstruct_explicit(kb, Terms)
+        # (the explicit matrix up to matrix_free_above states, as the reference's -do_shell 0 path; above it the same operator matrix-free)
+        H = KronSumConstruct_explicit(kb, Terms) if kb.NumStates() <= self.matrix_free_above else KronSumOperator(kb, Terms)
         gse, psi = lowest_eigenpair(H, seed=self.seed + self.GlobIdx)
         BT_L, BT_R = GetTruncation(kb, psi, MStates)
         if do_measurements and self.measurements:                # :1543

@@ -289,6 +289,59 @@ def KronSumConstruct_explicit(kb, Terms, ks_tol=KS_TOL):
     return _sorted(acc)
 
 
+class KronSumOperator:
+    """The same operator as KronSumConstruct_explicit, matrix-free: y_k = sum_t a_t A_t[IL, IL'] X_k' B_t[IR, IR']^T per KronBlock,
+    with the left operators of the terms that share a right operator summed first (the map the reference builds at
+    src/DMRGKron.cpp:955-960).  For superblocks whose explicit matrix would not fit the oracle's time budget (10^5 states and up:
+    tests/golden/make_engine_golden_large_m.py); checked against the explicit matrix in tests/test_oracle_golden.py."""
+
+    def __init__(self, kb, Terms):
+        self.kb = kb
+        Lq, Rq = kb.LeftBlock.Magnetization, kb.RightBlock.Magnetization
+        N = kb.NumStates()
+        self.shape, self.dtype = (N, N), np.dtype(np.float64)
+        groups = {}
+        for (a, opA, A, opB, B) in kron_sum_terms(kb, Terms):
+            key = (opA if B is None else opB, id(A) if B is None else id(B), B is None)
+            g = groups.setdefault(key, dict(opA=opA, opB=opB, A=None, B=B))
+            assert g["opA"] == opA and g["opB"] == opB
+            if A is not None:
+                g["A"] = a * A if g["A"] is None else g["A"] + a * A
+            else:
+                g["scale"] = g.get("scale", 0.0) + a
+        self.tasks = []                       # (row block k, column block kc, dense subA or None, scale, dense subB or None)
+        for g in groups.values():
+            for k, (_, IL, IR, size) in enumerate(kb.kb):
+                kc, sA, sB = _col_block(kb, IL, IR, g["opA"], g["opB"])
+                ILc, IRc = IL + sA, IR + sB
+                if not (0 <= ILc < Lq.NumSectors() and 0 <= IRc < Rq.NumSectors()) or kc < 0:
+                    continue
+                if kb.kb[kc][1] != ILc or kb.kb[kc][2] != IRc:
+                    continue
+                subA = None if g["A"] is None else g["A"][Lq.qn_offset[IL]:Lq.qn_offset[IL + 1], Lq.qn_offset[ILc]:Lq.qn_offset[ILc + 1]]
+                subB = None if g["B"] is None else g["B"][Rq.qn_offset[IR]:Rq.qn_offset[IR + 1], Rq.qn_offset[IRc]:Rq.qn_offset[IRc + 1]]
+                if (subA is not None and subA.nnz == 0) or (subB is not None and subB.nnz == 0):
+                    continue
+                self.tasks.append((k, kc, None if subA is None else np.ascontiguousarray(subA.toarray()), g.get("scale", 1.0),
+                                   None if subB is None else np.ascontiguousarray(subB.toarray().T)))
+        self.dims = [(Lq.qn_size[IL], Rq.qn_size[IR]) for (_, IL, IR, _) in kb.kb]
+
+    def matvec(self, x):
+        kb = self.kb
+        x = np.asarray(x, dtype=np.float64).ravel()
+        X = [x[kb.kb_offset[k]:kb.kb_offset[k + 1]].reshape(self.dims[k]) for k in range(kb.size())]
+        y = np.zeros_like(x)
+        Y = [y[kb.kb_offset[k]:kb.kb_offset[k + 1]].reshape(self.dims[k]) for k in range(kb.size())]
+        for (k, kc, subA, scale, subBT) in self.tasks:
+            T = X[kc] if subBT is None else X[kc] @ subBT
+            Y[k] += scale * T if subA is None else subA @ T
+        return y
+
+    def as_linear_operator(self):
+        import scipy.sparse.linalg as spla
+        return spla.LinearOperator(self.shape, matvec=self.matvec, dtype=self.dtype)
+
+
 # --------------------------------------------------------------------------------------------------
 #  Shell path: per-(row, term) descriptors and the literal matvec
 # --------------------------------------------------------------------------------------------------
