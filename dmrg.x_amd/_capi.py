@@ -82,7 +82,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_voi
 class EigsOpts(C.Structure):
     _fields_ = [("ncv", C.c_int32), ("max_it", C.c_int32), ("tol", C.c_double), ("seed", C.c_uint64),
                 ("use_initial", C.c_int32), ("max_matvec", C.c_int32), ("allgather", ALLGATHER_FN), ("allreduce_sum", ALLREDUCE_FN), ("user", C.c_void_p),
-                ("comm", C.c_void_p), ("method", C.c_int32), ("min_initial_norm2", C.c_double)]
+                ("comm", C.c_void_p), ("method", C.c_int32), ("min_initial_norm2", C.c_double), ("gd_minv", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class EigsStats(C.Structure):

@@ -18,11 +18,12 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <cstddef>
 
 namespace dmrgx {
 namespace {
 
-constexpr int DOT_BLOCKS = 1024, DOT_THREADS = 256, DOT_CHUNK = 8, MAX_NCV = 64, FUSE_NV = 24;
+constexpr int DOT_BLOCKS = 1024, DOT_THREADS = 256, DOT_CHUNK = 8, MAX_NCV = 64, FUSE_NV = 24, GD_NV = 8;
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -117,43 +118,45 @@ multi_axpy_kernel(const double* __restrict__ V, int64_t ldv, int nv, const doubl
 
 // First Gram-Schmidt pass fused with the dots of the second: w' = w - V c is formed per element and immediately
 // multiplied into this thread's partial sums of V^T w' and w'.w' (V's values are still in registers), so the basis is
-// read from HBM once for both.  nv <= FUSE_NV (the default ncv = 16 gives nv <= 17).
+// read from HBM once for both.  nv <= NVMAX: FUSE_NV for the Lanczos path (the default ncv = 16 gives nv <= 17), GD_NV for the
+// small search space of the Davidson path (a third of the registers).
 // partial[i * DOT_BLOCKS + block], i < nv: V_i . w' ; i == nv: w'.w'
+template <int NVMAX>
 __global__ void __launch_bounds__(DOT_THREADS)
 axpy_dot_kernel(const double* __restrict__ V, int64_t ldv, int nv, const double* __restrict__ c, double* __restrict__ w, int64_t n,
                 double* __restrict__ partial, double* __restrict__ hacc)
 {
-    __shared__ double cs[FUSE_NV];
-    __shared__ double red[DOT_THREADS / 64][FUSE_NV + 1];
+    __shared__ double cs[NVMAX];
+    __shared__ double red[DOT_THREADS / 64][NVMAX + 1];
     if (threadIdx.x < nv) cs[threadIdx.x] = c[threadIdx.x];
     __syncthreads();
     if (blockIdx.x == 0 && threadIdx.x < nv && hacc) hacc[threadIdx.x] += cs[threadIdx.x];
-    double acc[FUSE_NV + 1];
+    double acc[NVMAX + 1];
 #pragma unroll
-    for (int i = 0; i <= FUSE_NV; ++i) acc[i] = 0.0;
+    for (int i = 0; i <= NVMAX; ++i) acc[i] = 0.0;
     for (int64_t e = (int64_t)blockIdx.x * DOT_THREADS + threadIdx.x; e < n; e += (int64_t)gridDim.x * DOT_THREADS) {
-        double v[FUSE_NV];
+        double v[NVMAX];
 #pragma unroll
-        for (int i = 0; i < FUSE_NV; ++i) v[i] = i < nv ? V[(int64_t)i * ldv + e] : 0.0;
+        for (int i = 0; i < NVMAX; ++i) v[i] = i < nv ? V[(int64_t)i * ldv + e] : 0.0;
         double x = w[e];
 #pragma unroll
-        for (int i = 0; i < FUSE_NV; ++i) if (i < nv) x -= cs[i] * v[i];
+        for (int i = 0; i < NVMAX; ++i) if (i < nv) x -= cs[i] * v[i];
         w[e] = x;
 #pragma unroll
-        for (int i = 0; i < FUSE_NV; ++i) if (i < nv) acc[i] += v[i] * x;
-        acc[FUSE_NV] += x * x;
+        for (int i = 0; i < NVMAX; ++i) if (i < nv) acc[i] += v[i] * x;
+        acc[NVMAX] += x * x;
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-    for (int i = 0; i <= FUSE_NV; ++i) {
-        if (i < nv || i == FUSE_NV) {
+    for (int i = 0; i <= NVMAX; ++i) {
+        if (i < nv || i == NVMAX) {
             const double s2 = wave_sum(acc[i]);
             if (lane == 0) red[wave][i] = s2;
         }
     }
     __syncthreads();
     if (threadIdx.x <= nv) {
-        const int src = threadIdx.x < nv ? threadIdx.x : FUSE_NV;
+        const int src = threadIdx.x < nv ? threadIdx.x : NVMAX;
         double s2 = 0.0;
         for (int wv = 0; wv < DOT_THREADS / 64; ++wv) s2 += red[wv][src];
         partial[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] = s2;
@@ -241,35 +244,265 @@ basis_rotate_kernel(const double* __restrict__ V, int64_t ldv, int m, const doub
     }
 }
 
-// Generalized Davidson: u = V y, r = W y - theta u (W = H V), t = r / (theta - D) with |theta - D| kept away from 0.
-// Writes t; partial[b] = sum_e r[e]^2.  The Ritz coefficients come by value in the kernel arguments: the host has just computed them,
-// and an upload of their own was a stream operation (staging copy + blit launch) in front of every correction vector.
-struct RitzCoef { double y[MAX_NCV]; };
+// ---- generalized Davidson: the small problem lives on the device ------------------------------------------------------------------
+// State of the projected problem, one device block of doubles (GdState offsets): nothing of it is needed on the host, so an iteration
+// has no read-back / host solve / upload in its dependency chain (rounds 2-4: one blocking synchronisation per MatMult, 0.83 ms of idle
+// GPU per configs[3] step, 0.19 ms of a 3.2 ms step at m = 512).  The host only LOOKS at (|r|^2, theta) through pinned memory, one
+// iteration behind the queue.
+constexpr int GD_MAX = FUSE_NV;              // largest search space (ncv) the Davidson path accepts
+constexpr int GD_LD = GD_MAX;                // row stride of the small matrices
+struct GdState {
+    double G[GD_MAX * GD_LD];                // projected matrix V^T H V (symmetric, valid in [0, mm) x [0, mm))
+    double Y[GD_MAX * GD_LD];                // Ritz basis of the last solve (columns), ascending Ritz values
+    double th[GD_MAX];                       // Ritz values
+    double y[GD_MAX];                        // coefficients of the current Ritz vector in the current basis
+    double yprev[GD_MAX];                    // ... of the previous iteration's Ritz vector (GD+k restart)
+    double Q[GD_MAX * GD_LD];                // restart rotation, row-major mm x kk with ld = kk
+    double theta;                            // lowest Ritz value
+    double hv0_2;                            // |H v_0|^2 (start-vector check: not positive <=> zero / NaN start vector)
+    double e0[GD_MAX];                       // (1, 0, 0, ...): the Ritz vector's coefficients right after a restart
+    int after_restart;                       // the basis was rotated since y was computed: the previous Ritz vector is the first basis vector
+    int pad_;
+};
+
+// One workgroup: the newest column of G (reduced here from the per-block partial sums of multi_dot_kernel, or taken reduced when an
+// all-reduce had to come first), the symmetric eigenproblem of G by cyclic Jacobi with round-robin pair ordering (all n/2 rotations of a
+// round at once), warm-started in the basis [previous Ritz vectors | new direction] where G is an arrowhead; at a restart the rotation
+// Q = [keep lowest Ritz vectors | previous iteration's Ritz vector, orthonormalised] and G <- Q^T G Q.
+constexpr int RITZ_THREADS = 64;
+__global__ void __launch_bounds__(RITZ_THREADS)
+gd_ritz_kernel(GdState* __restrict__ S, const double* __restrict__ col_src, int col_is_partial, int nblk, int mm, int warm, int restart, int keep)
+{
+    __shared__ double A[GD_MAX][GD_MAX + 1], Qa[GD_MAX][GD_MAX + 1], Yn[GD_MAX][GD_MAX + 1];
+    __shared__ double col[GD_MAX + 1], cs_c[GD_MAX / 2], cs_s[GD_MAX / 2], dg[GD_MAX];
+    __shared__ int pp[GD_MAX / 2], qq[GD_MAX / 2], perm[GD_MAX];
+    __shared__ double offn, dgn;
+    const int tid = threadIdx.x, lane = tid;                                // ONE wave: every barrier below is a wait on the wave's own LDS traffic
+    const int j = mm - 1;
+    // ---- newest column of G: sums of the per-block partials in fixed order (all mm + 1 sums at once: one load latency) ---------------
+    if (col_is_partial) {
+        double v[GD_MAX + 1];
+#pragma unroll
+        for (int i = 0; i <= GD_MAX; ++i) {
+            v[i] = 0.0;
+            if (i <= mm) for (int b = tid; b < nblk; b += RITZ_THREADS) v[i] += col_src[(int64_t)i * nblk + b];
+        }
+#pragma unroll
+        for (int i = 0; i <= GD_MAX; ++i) if (i <= mm) { const double s2 = wave_sum(v[i]); if (lane == 0) col[i] = s2; }
+    } else if (tid <= mm) col[tid] = col_src[tid];
+    __syncthreads();
+    if (tid < mm) { S->G[tid * GD_LD + j] = col[tid]; S->G[j * GD_LD + tid] = col[tid]; }
+    if (tid == 0 && mm == 1) S->hv0_2 = col[1];
+    if (tid < GD_MAX && mm == 1) S->e0[tid] = tid == 0 ? 1.0 : 0.0;
+    // the previous Ritz vector in this basis: its coefficients padded with a zero, or -- a restart since -- the first basis vector
+    if (tid < mm) S->yprev[tid] = S->after_restart ? (tid == 0 ? 1.0 : 0.0) : (tid < mm - 1 ? S->y[tid] : 0.0);
+    __syncthreads();
+    if (tid == 0) S->after_restart = restart;
+    const int n = (mm + 1) & ~1;                                          // even order for the pair schedule (padding: a decoupled zero row)
+    // ---- matrix to diagonalise: arrowhead in the previous Ritz basis (warm) or G itself ------------------------------------------
+    const int mp = mm - 1;
+    for (int e = tid; e < n * n; e += RITZ_THREADS) {
+        const int a = e / n, b = e % n;
+        double v = 0.0;
+        if (a < mm && b < mm) {
+            if (!warm || mp == 0) v = (a == j || b == j) ? col[a == j ? b : a] : S->G[a * GD_LD + b];
+            else if (a < mp && b < mp) v = a == b ? S->th[a] : 0.0;
+            else if (a == mp && b == mp) v = col[j];
+            else {                                                        // border: b_i = sum_k Yp[k][i] g[k]
+                const int i = a == mp ? b : a;
+                for (int k = 0; k < mp; ++k) v += S->Y[k * GD_LD + i] * col[k];
+            }
+        }
+        A[a][b] = v;
+        Qa[a][b] = a == b ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    // ---- cyclic Jacobi, round-robin ordering: round r pairs (r, n-1) and ((r + k) mod (n-1), (r - k) mod (n-1)), k = 1 .. n/2 - 1 --
+    for (int sweep = 0; sweep < 30 && n > 1; ++sweep) {
+        {
+            double off = 0.0, dgs = 0.0;
+            for (int e = lane; e < n * n; e += 64) { const int a = e / n, b = e % n; const double v = A[a][b]; if (a == b) dgs += v * v; else off += v * v; }
+            off = wave_sum(off); dgs = wave_sum(dgs);
+            if (lane == 0) { offn = off; dgn = dgs; }
+        }
+        __syncthreads();
+        if (offn <= 1e-32 * (dgn + offn) || offn == 0.0) break;
+        for (int r = 0; r < n - 1; ++r) {
+            if (tid < n / 2) {
+                const int k = tid;
+                const int p0 = k == 0 ? r : (r + k) % (n - 1), q0 = k == 0 ? n - 1 : (r - k + (n - 1)) % (n - 1);
+                const int p = min(p0, q0), q = max(p0, q0);
+                const double apq = A[p][q];
+                double c = 1.0, sn = 0.0;
+                if (apq != 0.0) {
+                    const double tau = (A[q][q] - A[p][p]) / (2.0 * apq);
+                    const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                    c = 1.0 / sqrt(1.0 + t * t); sn = t * c;
+                }
+                pp[k] = p; qq[k] = q; cs_c[k] = c; cs_s[k] = sn;
+            }
+            __syncthreads();
+            for (int e = tid; e < (n / 2) * n; e += RITZ_THREADS) {               // columns p, q of A and of the accumulated rotation
+                const int k = e / n, i = e % n;
+                const int p = pp[k], q = qq[k];
+                const double c = cs_c[k], sn = cs_s[k];
+                const double aip = A[i][p], aiq = A[i][q];
+                A[i][p] = c * aip - sn * aiq; A[i][q] = sn * aip + c * aiq;
+                const double qip = Qa[i][p], qiq = Qa[i][q];
+                Qa[i][p] = c * qip - sn * qiq; Qa[i][q] = sn * qip + c * qiq;
+            }
+            __syncthreads();
+            for (int e = tid; e < (n / 2) * n; e += RITZ_THREADS) {               // rows p, q of A
+                const int k = e / n, i = e % n;
+                const int p = pp[k], q = qq[k];
+                const double c = cs_c[k], sn = cs_s[k];
+                const double api = A[p][i], aqi = A[q][i];
+                A[p][i] = c * api - sn * aqi; A[q][i] = sn * api + c * aqi;
+            }
+            __syncthreads();
+        }
+    }
+    // ---- ascending order (rank by counting; the padding row, if any, is dropped) ------------------------------------------------
+    if (tid < mm) dg[tid] = A[tid][tid];
+    __syncthreads();
+    if (tid < mm) {
+        int rank = 0;
+        for (int o = 0; o < mm; ++o) rank += (dg[o] < dg[tid] || (dg[o] == dg[tid] && o < tid)) ? 1 : 0;
+        perm[rank] = tid;
+    }
+    __syncthreads();
+    // Y = blkdiag(Yp, 1) Qa (warm) or Qa, columns in ascending order
+    for (int e = tid; e < mm * mm; e += RITZ_THREADS) {
+        const int i = e / mm, cidx = e % mm;
+        const int src = perm[cidx];
+        double v;
+        if (!warm || mp == 0 || i == mp) v = Qa[i][src];
+        else { v = 0.0; for (int k = 0; k < mp; ++k) v += S->Y[i * GD_LD + k] * Qa[k][src]; }
+        Yn[i][cidx] = v;
+    }
+    __syncthreads();
+    for (int e = tid; e < mm * mm; e += RITZ_THREADS) S->Y[(e / mm) * GD_LD + (e % mm)] = Yn[e / mm][e % mm];
+    if (tid < mm) { S->th[tid] = dg[perm[tid]]; S->y[tid] = Yn[tid][0]; }
+    if (tid == 0) S->theta = dg[perm[0]];
+    if (!restart) return;
+    // ---- restart: Q = [Ritz vectors 0 .. keep-1 | previous Ritz vector orthonormalised against them] (keep + 1 columns) -----------
+    __syncthreads();
+    const int kk = keep + 1;
+    {
+        // p = yprev - sum_c Q_c (Q_c . yprev), twice; lanes hold the entries
+        double pv = lane < mm ? S->yprev[lane] : 0.0;
+        for (int pass = 0; pass < 2; ++pass)
+            for (int c = 0; c < keep; ++c) {
+                const double qc = lane < mm ? Yn[lane][c] : 0.0;
+                double d = qc * pv;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+                pv -= d * qc;
+            }
+        double nn = pv * pv;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) nn += __shfl_xor(nn, o, 64);
+        // (a previous Ritz vector that lies in the span of the kept ones adds nothing: the next Ritz vector takes its place)
+        const double last = nn > 1e-16 ? pv / sqrt(nn) : (lane < mm ? Yn[lane][keep] : 0.0);
+        if (lane < mm) A[lane][keep] = last;                              // A is free: it now holds Q (mm x kk)
+    }
+    for (int e = tid; e < mm * keep; e += RITZ_THREADS) A[e / keep][e % keep] = Yn[e / keep][e % keep];
+    __syncthreads();
+    for (int e = tid; e < mm * kk; e += RITZ_THREADS) S->Q[e] = A[e / kk][e % kk];
+    // G <- Q^T G Q: diag(theta) on the Ritz block exactly, the border through G q
+    if (tid < mm) { double v = 0.0; for (int b = 0; b < mm; ++b) v += S->G[tid * GD_LD + b] * A[b][keep]; col[tid] = v; }      // G q_last
+    __syncthreads();
+    if (tid < kk) { double v = 0.0; for (int a = 0; a < mm; ++a) v += A[a][tid] * col[a]; dg[tid] = v; }                      // Q^T G q_last
+    __syncthreads();
+    for (int e = tid; e < GD_MAX * GD_LD; e += RITZ_THREADS) {
+        const int a = e / GD_LD, b = e % GD_LD;
+        double v = 0.0;
+        if (a < keep && b < keep) v = a == b ? S->th[a] : 0.0;
+        else if (a < kk && b < kk) v = dg[a == keep ? b : a];
+        S->G[e] = v;
+    }
+    // (y stays: the correction kernel that follows still works in the old basis; after_restart tells the next call)
+}
+
+// u = V y, r = W y - theta u (W = H V), t = r / (theta - D) with |theta - D| kept away from 0; y and theta are read from the device
+// state.  Writes t; partial: [i * nblk + b], i < nv: V_i . t (the first Gram-Schmidt pass of the correction, while V's values are in
+// registers: nv <= NVMAX = 8 values per lane -- with the 17 of rounds 3-4's search space this fusion cost a wave per SIMD and was
+// dropped, DESIGN K2); i == nv: t . t; i == nv + 1: r . r.  DOTS = false: only r . r, at index 0.
+template <int NVMAX, bool DOTS>
 __global__ void __launch_bounds__(DOT_THREADS)
-ritz_precond_kernel(const double* __restrict__ V, const double* __restrict__ W, int64_t ldv, int nv, const RitzCoef y, double theta,
-                    const double* __restrict__ D, double floor_, double* __restrict__ t, int64_t n, double* __restrict__ partial)
+ritz_precond_kernel(const double* __restrict__ V, const double* __restrict__ W, int64_t ldv, int nv, const GdState* __restrict__ S,
+                    const double* __restrict__ D, double floor_rel, double* __restrict__ t, int64_t n, double* __restrict__ partial)
 {
     // (Olsen's correction t - (u.t / u.t2) t2 with t2 = u / (theta - D) was measured in round 3 -- 2 436 instead of 2 431 MatMults in a
     //  sweep of configs[3]: with a diagonal preconditioner it is noise -- and is not part of the library)
-    __shared__ double ys[MAX_NCV];
-    __shared__ double red[DOT_THREADS / 64];
-    if (threadIdx.x < nv) ys[threadIdx.x] = y.y[threadIdx.x];
+    __shared__ double ys[NVMAX];
+    __shared__ double red[DOT_THREADS / 64][NVMAX + 2];
+    if (threadIdx.x < NVMAX) ys[threadIdx.x] = threadIdx.x < nv ? S->y[threadIdx.x] : 0.0;
+    const double theta = S->theta;
+    const double floor_ = floor_rel * fmax(1.0, fabs(theta)) * 1e-2 + 1e-12;
     __syncthreads();
-    double nrm = 0.0;
+    double acc[NVMAX + 2];
+#pragma unroll
+    for (int i = 0; i < NVMAX + 2; ++i) acc[i] = 0.0;
     for (int64_t e = (int64_t)blockIdx.x * DOT_THREADS + threadIdx.x; e < n; e += (int64_t)gridDim.x * DOT_THREADS) {
+        double v[NVMAX];
         double u = 0.0, hu = 0.0;
-        for (int i = 0; i < nv; ++i) { u += ys[i] * V[(int64_t)i * ldv + e]; hu += ys[i] * W[(int64_t)i * ldv + e]; }
+#pragma unroll
+        for (int i = 0; i < NVMAX; ++i) if (i < nv) { v[i] = V[(int64_t)i * ldv + e]; u += ys[i] * v[i]; hu += ys[i] * W[(int64_t)i * ldv + e]; } else v[i] = 0.0;
         const double r = hu - theta * u;
         double den = theta - D[e];
         if (fabs(den) < floor_) den = den < 0.0 ? -floor_ : floor_;
         const double te = r / den;
         t[e] = te;
-        nrm += r * r;
+        if (DOTS) {
+#pragma unroll
+            for (int i = 0; i < NVMAX; ++i) if (i < nv) acc[i] += v[i] * te;
+            acc[NVMAX] += te * te;
+        }
+        acc[NVMAX + 1] += r * r;
     }
-    nrm = wave_sum(nrm);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = nrm;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NVMAX + 2; ++i) {
+        if ((DOTS && (i < nv || i == NVMAX)) || i == NVMAX + 1) {
+            const double s2 = wave_sum(acc[i]);
+            if (lane == 0) red[wave][i] = s2;
+        }
+    }
     __syncthreads();
-    if (threadIdx.x == 0) { double s2 = 0.0; for (int k = 0; k < DOT_THREADS / 64; ++k) s2 += red[k]; partial[blockIdx.x] = s2; }
+    if (DOTS) {
+        if (threadIdx.x <= nv + 1) {
+            const int src = threadIdx.x < nv ? threadIdx.x : (threadIdx.x == nv ? NVMAX : NVMAX + 1);
+            double s2 = 0.0;
+            for (int wv = 0; wv < DOT_THREADS / 64; ++wv) s2 += red[wv][src];
+            partial[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] = s2;
+        }
+    } else if (threadIdx.x == 0) {
+        double s2 = 0.0;
+        for (int wv = 0; wv < DOT_THREADS / 64; ++wv) s2 += red[wv][NVMAX + 1];
+        partial[blockIdx.x] = s2;
+    }
+}
+
+// out[i] = sum_b partial[i * nblk + b] (as reduce_partials_kernel); the block of index `look_idx` also hands (|r|^2, theta, |H v_0|^2) to
+// the host's look buffer (pinned memory, fetched behind an event).  look_only: the sums are in `out` already (an all-reduce came between).
+__global__ void __launch_bounds__(DOT_THREADS)
+gd_reduce_look_kernel(const double* __restrict__ partial, double* __restrict__ out, int count, int nblk, int look_idx, int look_only,
+                      const GdState* __restrict__ S, double* __restrict__ look)
+{
+    __shared__ double red[DOT_THREADS / 64];
+    const int i = blockIdx.x;
+    if (i >= count) return;
+    double t = 0.0;
+    if (!look_only) {
+        double s = 0.0;
+        for (int b = threadIdx.x; b < nblk; b += DOT_THREADS) s += partial[(int64_t)i * nblk + b];
+        s = wave_sum(s);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (threadIdx.x == 0) { for (int k = 0; k < DOT_THREADS / 64; ++k) t += red[k]; out[i] = t; }
+    } else if (threadIdx.x == 0) t = out[i];
+    if (threadIdx.x == 0 && i == look_idx) { look[0] = t; look[1] = S->theta; look[2] = S->hv0_2; }
 }
 
 // counter-based uniform(-1,1) start vector (splitmix64 of seed + global index)
@@ -510,10 +743,16 @@ extern "C" dmrgx_status dmrgx_eigs_lowest(dmrgx_kron_plan* plan, const dmrgx_eig
     // random start vector instead (the engine's projected start vectors can lose all their weight).
     auto null_start = [&]() { return opts->use_initial && restarts == 0 && k == 0 && ((!(std::fabs(hbuf[0]) > 0.0) && !(hbuf[(size_t)m + 1] > 0.0)) || start_too_light(opts, pin)); };
     auto redo_from_random = [&]() -> dmrgx_status {
+        // (called right after a synchronisation: nothing is queued on the work space, which the repeated solve allocates again -- ADVICE
+        //  round 4: the rejected attempt's buffers are released first and its MatMults and seconds stay in the returned totals)
+        dV.release(); dW.release(); dTmp.release(); dX.release();
         dmrgx_eigs_opts o2 = *opts;
         o2.use_initial = 0;
-        const dmrgx_status rc = dmrgx_eigs_lowest(plan, &o2, e0, psi_full, stats, (void*)st);
-        if (stats) stats->start_rejected = 1;
+        dmrgx_eigs_stats s2;
+        memset(&s2, 0, sizeof(s2));
+        const dmrgx_status rc = dmrgx_eigs_lowest(plan, &o2, e0, psi_full, &s2, (void*)st);
+        if (stats) { *stats = s2; stats->n_matvec += n_matvec; stats->start_rejected = 1;
+                     stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(); }
         return rc;
     };
     while (true) {
@@ -529,7 +768,7 @@ extern "C" dmrgx_status dmrgx_eigs_lowest(dmrgx_kron_plan* plan, const dmrgx_eig
             DMRGX_CHK(multi_dot(nv));                         // pass 1: c1 = V^T w                (one fused all-reduce)
             if (nv <= FUSE_NV) {
                 // w' = w - V c1 fused with pass 2's dots: c2 = V^T w', w'.w'            (one fused all-reduce)
-                hipLaunchKernelGGL(axpy_dot_kernel, dim3(nblk), dim3(DOT_THREADS), 0, st, V, n, nv, c1, w, n, dPartial.as<double>(), Hrow(j));
+                hipLaunchKernelGGL(axpy_dot_kernel<FUSE_NV>, dim3(nblk), dim3(DOT_THREADS), 0, st, V, n, nv, c1, w, n, dPartial.as<double>(), Hrow(j));
                 DMRGX_HIP(hipGetLastError());
                 hipLaunchKernelGGL(reduce_partials_kernel, dim3(nv + 1), dim3(DOT_THREADS), 0, st, dPartial.as<double>(), c2, nv + 1, nblk);
                 DMRGX_HIP(hipGetLastError());
@@ -633,10 +872,14 @@ extern "C" dmrgx_status dmrgx_eigs_lowest(dmrgx_kron_plan* plan, const dmrgx_eig
 
 
 // ---- generalized Davidson (opts->method == 1) ---------------------------------------------------------------------------------
-// Basis V (orthonormal), W = H V, projected matrix G = V^T W on the host.  Per iteration: one MatMult (the new basis vector), the
-// new column of G (one fused dot pass), the lowest Ritz pair of G, then ONE pass that forms the Ritz vector, the true residual
-// r = H u - theta u and the diagonally preconditioned correction t = r / (theta - diag H) (dmrgx_kron_diag), which is
-// orthogonalised against V by the same CGS2 kernels the Lanczos path uses.  Thick restart keeps the lowest Ritz vectors.
+// Basis V (orthonormal), W = H V, projected matrix G = V^T W.  Per iteration: one MatMult (the new basis vector), the new column of G
+// (one fused dot pass), the lowest Ritz pair of G (gd_ritz_kernel, on the device), then ONE pass that forms the Ritz vector, the true
+// residual r = H u - theta u, the diagonally preconditioned correction t = r / (theta - diag H) (dmrgx_kron_diag) and the first
+// Gram-Schmidt dots V^T t, which is then orthogonalised against V by the CGS2 kernels of the Lanczos path.
+// Round 5: a SMALL search space with a GD+k restart.  The vector work of an iteration is 4 j + 7 passes over vectors for a basis of j
+// (5 j + 7 before the dots were fused), so the basis is held at gd_basis <= 8 vectors and restarted to the lowest Ritz vector(s) plus
+// the previous iteration's Ritz vector -- the restart that keeps the convergence of the unrestarted method (Stathopoulos & Saad;
+// measured on CPU-side model problems, tests/experiments/gd_restart_basis.py: 12.9 MatMults per solve for every maximal basis from 24 down to 4).
 // Distributed like the Lanczos path: vectors are stripe segments, every dot is all-reduced, x is all-gathered before a MatMult.
 static dmrgx_status eigs_davidson(dmrgx_kron_plan* plan, const dmrgx_eigs_opts* opts, double* e0, double* psi_full, dmrgx_eigs_stats* stats, hipStream_t st)
 {
@@ -646,13 +889,20 @@ static dmrgx_status eigs_davidson(dmrgx_kron_plan* plan, const dmrgx_eigs_opts* 
     const bool hooks = opts->allgather && opts->allreduce_sum;
     if (dist && !hooks && !opts->comm) DMRGX_FAIL(DMRGX_ERR_ARG, "eigs_lowest: a striped plan needs a communicator (opts->comm) or the allgather/allreduce hooks");
     const int64_t n = I.local_len, N = I.n_states;
-    int m = opts->ncv > 0 ? opts->ncv : 16;
-    m = (int)std::min<int64_t>(std::min(m, FUSE_NV - 1), N);
+    // search space: opts->ncv vectors at most (default GD_NV = 8: SLEPc's meaning of ncv for its gd solver), restarted to gd_minv Ritz
+    // vectors + the previous Ritz vector.  A basis that could not grow after a restart (fewer than minv + 2 vectors) is widened.
+    int m = opts->ncv > 0 ? opts->ncv : GD_NV;
+    m = (int)std::min<int64_t>(std::min(m, GD_MAX - 1), N);
     if (m < 2) DMRGX_FAIL(DMRGX_ERR_ARG, "eigs_lowest (gd): needs at least a two-dimensional search space");
-    const int max_mv = opts->max_it > 0 ? opts->max_it * m : std::max<int>(100 * m, (int)(2 * N));
+    if (m < 3 && N >= 3) m = 3;
+    const int keep = std::max(1, std::min(opts->gd_minv > 0 ? opts->gd_minv : 1, m - 2));
+    const int kk = keep + 1;                   // basis after a restart
+    const int max_mv = opts->max_it > 0 ? opts->max_it * 16 : std::max<int>(1600, (int)(2 * N));
+    const int hand_over = 96;                  // MatMults after which a start vector that was not close after all goes to the Lanczos path
     const double tol = opts->tol > 0 ? opts->tol : 1e-8;
     const auto t_begin = std::chrono::steady_clock::now();
     const int nblk = DOT_BLOCKS;
+    const bool fused = m <= GD_NV;             // the correction kernel also takes the first Gram-Schmidt dots
 
     static const bool trace_setup = getenv("DMRGX_EIGS_TRACE") != nullptr;      // developer aid: wall time of the set-up stages (synchronising)
     auto mark = [&](const char* what) {
@@ -661,27 +911,32 @@ static dmrgx_status eigs_davidson(dmrgx_kron_plan* plan, const dmrgx_eigs_opts* 
         fprintf(stderr, "[eigs gd] setup %-12s t = %.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
     };
     mark("enter");
-    DevBuf dV, dW, dT, dX, dD, dTmp, dPartial, dScal, dY;
+    DevBuf dV, dW, dT, dX, dD, dTmp, dPartial, dScal, dState;
     DMRGX_CHK(dV.alloc((size_t)(m + 1) * n * sizeof(double)));
     DMRGX_CHK(dW.alloc((size_t)(m + 1) * n * sizeof(double)));
     DMRGX_CHK(dT.alloc((size_t)n * sizeof(double)));
     DMRGX_CHK(dD.alloc((size_t)n * sizeof(double)));
-    DMRGX_CHK(dTmp.alloc((size_t)(m / 2 + 2) * n * sizeof(double)));
+    DMRGX_CHK(dTmp.alloc((size_t)kk * n * sizeof(double)));
     if (dist) DMRGX_CHK(dX.alloc((size_t)I.vec_len * sizeof(double)));
-    DMRGX_CHK(dPartial.alloc((size_t)(MAX_NCV + DOT_CHUNK + 1) * DOT_BLOCKS * sizeof(double)));
+    DMRGX_CHK(dPartial.alloc((size_t)(MAX_NCV + DOT_CHUNK + 2) * DOT_BLOCKS * sizeof(double)));
     DMRGX_CHK(dScal.alloc((size_t)(3 * (MAX_NCV + 2)) * sizeof(double)));
-    DMRGX_CHK(dY.alloc((size_t)MAX_NCV * MAX_NCV * sizeof(double)));
+    DMRGX_CHK(dState.alloc(sizeof(GdState)));
     double* V = dV.as<double>();
     double* W = dW.as<double>();
     double* t = dT.as<double>();
     double* c1 = dScal.as<double>();
     double* c2 = c1 + (MAX_NCV + 2);
     double* nrm = c2 + (MAX_NCV + 2);
+    GdState* S = dState.as<GdState>();
+    const double* const S_y = (const double*)((const char*)dState.p + offsetof(GdState, y));
+    const double* const S_e0 = (const double*)((const char*)dState.p + offsetof(GdState, e0));
+    const double* const S_Q = (const double*)((const char*)dState.p + offsetof(GdState, Q));
     auto vec = [&](int j) { return V + (size_t)j * n; };
     auto wvec = [&](int j) { return W + (size_t)j * n; };
     // (every basis vector is written whole before it is read; only the padding of a striped segment relies on the initial zeros)
     if (dist) { DMRGX_HIP(zero_async(dV.p, dV.bytes, st)); DMRGX_HIP(zero_async(dW.p, dW.bytes, st)); }
-    DMRGX_HIP(zero_async(dT.p, dT.bytes, st));
+    if (dist) DMRGX_HIP(zero_async(dT.p, dT.bytes, st));
+    DMRGX_HIP(zero_async(dState.p, dState.bytes, st));
     if (dist) DMRGX_HIP(zero_async(dX.p, dX.bytes, st));
     mark("buffers");
     DMRGX_CHK(dmrgx_kron_diag(plan, dD.as<double>(), st));
@@ -694,20 +949,21 @@ static dmrgx_status eigs_davidson(dmrgx_kron_plan* plan, const dmrgx_eigs_opts* 
     auto gather_full = [&](double* full) -> dmrgx_status {
         return hooks ? opts->allgather(opts->user, full, I.seg_stride, st) : dmrgx_comm_allgather(opts->comm, full, I.seg_stride, st);
     };
-    // out[0..nv) = V[0..nv)^T x, out[nv] = x.x
-    auto multi_dot = [&](int nv, const double* x, double* out) -> dmrgx_status {
+    // per-block partial sums of V[0..nv)^T x and x.x (dPartial); reduce == true: also out[0..nv] = the sums (all-reduced)
+    auto multi_dot = [&](int nv, const double* x, double* out, bool reduce) -> dmrgx_status {
         const int chunks = (nv + 1 + DOT_CHUNK - 1) / DOT_CHUNK;
         if (vec2) hipLaunchKernelGGL(multi_dot_kernel<true>, dim3(nblk, chunks), dim3(DOT_THREADS), 0, st, V, n, nv, x, n, dPartial.as<double>());
         else hipLaunchKernelGGL(multi_dot_kernel<false>, dim3(nblk, chunks), dim3(DOT_THREADS), 0, st, V, n, nv, x, n, dPartial.as<double>());
         DMRGX_HIP(hipGetLastError());
+        if (!reduce) return DMRGX_OK;
         hipLaunchKernelGGL(reduce_partials_kernel, dim3(nv + 1), dim3(DOT_THREADS), 0, st, dPartial.as<double>(), out, nv + 1, nblk);
         DMRGX_HIP(hipGetLastError());
         return allreduce(out, nv + 1);
     };
-    // dst = (x - V V^T x) / || . ||  (CGS2 with the fused kernels of the Lanczos path); x is overwritten
-    auto orthonormalise_into = [&](int nv, double* x, double* dst) -> dmrgx_status {
-        DMRGX_CHK(multi_dot(nv, x, c1));
-        hipLaunchKernelGGL(axpy_dot_kernel, dim3(nblk), dim3(DOT_THREADS), 0, st, V, n, nv, c1, x, n, dPartial.as<double>(), (double*)nullptr);
+    // second half of CGS2 on x, whose first-pass dots c1 = V^T x are reduced: dst = (x - V V^T x) / || . ||; x is overwritten
+    auto orthonormalise_tail = [&](int nv, double* x, double* dst) -> dmrgx_status {
+        if (nv <= GD_NV) hipLaunchKernelGGL(axpy_dot_kernel<GD_NV>, dim3(nblk), dim3(DOT_THREADS), 0, st, V, n, nv, c1, x, n, dPartial.as<double>(), (double*)nullptr);
+        else hipLaunchKernelGGL(axpy_dot_kernel<FUSE_NV>, dim3(nblk), dim3(DOT_THREADS), 0, st, V, n, nv, c1, x, n, dPartial.as<double>(), (double*)nullptr);
         DMRGX_HIP(hipGetLastError());
         hipLaunchKernelGGL(reduce_partials_kernel, dim3(nv + 1), dim3(DOT_THREADS), 0, st, dPartial.as<double>(), c2, nv + 1, nblk);
         DMRGX_HIP(hipGetLastError());
@@ -741,123 +997,103 @@ static dmrgx_status eigs_davidson(dmrgx_kron_plan* plan, const dmrgx_eigs_opts* 
         DMRGX_HIP(hipMemcpyAsync(t, dX.as<double>() + I.local_offset, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, st));
         DMRGX_HIP(hipStreamSynchronize(st));
     }
-    DMRGX_CHK(orthonormalise_into(0, t, vec(0)));
+    DMRGX_CHK(multi_dot(0, t, c1, true));
+    DMRGX_CHK(orthonormalise_tail(0, t, vec(0)));
     double* const pin = opts->use_initial ? pinned_scalars() : nullptr;
-    if (pin) { pin[2] = 0.0; DMRGX_HIP(hipMemcpyAsync(pin + 2, c2, sizeof(double), hipMemcpyDeviceToHost, st)); }      // c2[0] = |start vector|^2; read after the first look
+    if (pin) { pin[2] = 0.0; DMRGX_HIP(hipMemcpyAsync(pin + 2, c2, sizeof(double), hipMemcpyDeviceToHost, st)); }      // c2[0] = |start vector|^2; read at the first look
     mark("start vector");
 
-    std::vector<double> G((size_t)m * m, 0.0), th, Y, ydev;
-    if (!pin) DMRGX_FAIL(DMRGX_ERR_MEM, "eigs_lowest (gd): no pinned host memory for the read-backs");
-    double* const hcol = pin + 8;
+    // the looks come back through pinned memory behind an event, so that the orthogonalisation of the next direction is already queued
+    // when the host waits for them; one buffer + event per host thread (callers on different threads / devices do not share them)
+    static thread_local double* h_look = nullptr;
+    static thread_local hipEvent_t ev_look = nullptr;
+    if (!h_look) { DMRGX_HIP(hipHostMalloc((void**)&h_look, 64, hipHostMallocDefault)); DMRGX_HIP(hipEventCreateWithFlags(&ev_look, hipEventDisableTiming)); }
+    DevBuf dLook;
+    DMRGX_CHK(dLook.alloc(4 * sizeof(double)));
     int j = 0, n_matvec = 0, restarts = 0, converged = 0;
     double lambda = 0.0, resid = 0.0;
     const double floor_rel = 1e-3;
-    // Ritz problem, warm-started: in the basis [previous Ritz vectors | new direction] the projected matrix is an arrowhead
-    // (diag(theta_prev) bordered by one row), which cyclic Jacobi finishes in 2-3 sweeps instead of 8 from G itself
-    std::vector<double> Yp, thp;                // previous Ritz basis (mp x mp, columns) and values; empty: none
-    int mp = 0;
-    // the residual norm comes back through pinned memory behind an event, so that the orthogonalisation of the next direction is
-    // already queued when the host waits for it
-    // pinned scalar + event for the residual look: one pair per host thread (callers on different threads / devices do not share it)
-    static thread_local double* h_r2 = nullptr;
-    static thread_local hipEvent_t ev_r2 = nullptr;
-    if (!h_r2) { DMRGX_HIP(hipHostMalloc((void**)&h_r2, 64, hipHostMallocDefault)); DMRGX_HIP(hipEventCreateWithFlags(&ev_r2, hipEventDisableTiming)); }
-    bool ritz_is_v0 = false;                    // a restart has just made the Ritz vector the first basis vector
+    bool warm = false;                          // the device state holds the Ritz basis of the previous iteration in the current basis
+    bool rotated = false;                       // a restart has been queued since the last Ritz solve: the Ritz vector is the first basis vector
+    int mm = 0;
     while (true) {
         DMRGX_CHK(matvec(vec(j), wvec(j)));
         ++n_matvec;
-        DMRGX_CHK(multi_dot(j + 1, wvec(j), c1));                                  // column j of G = V^T w_j
-        DMRGX_HIP(hipMemcpyAsync(hcol, c1, (size_t)(j + 2) * sizeof(double), hipMemcpyDeviceToHost, st));
-        DMRGX_HIP(hipStreamSynchronize(st));
-        if (n_matvec == 1 && (!(hcol[1] > 0.0) || start_too_light(opts, pin))) {       // |H v_0|^2 is not positive: the start vector had zero (or NaN) norm -- see the Lanczos path; or it is lighter than the caller accepts
-            dmrgx_eigs_opts o2 = *opts;
-            o2.method = 0; o2.use_initial = 0;
-            const dmrgx_status rc = dmrgx_eigs_lowest(plan, &o2, e0, psi_full, stats, (void*)st);
-            if (stats) stats->start_rejected = 1;
-            return rc;
-        }
-        for (int i = 0; i <= j; ++i) { G[(size_t)i * m + j] = hcol[(size_t)i]; G[(size_t)j * m + i] = hcol[(size_t)i]; }
-        const int mm = j + 1;
-        std::vector<double> A((size_t)mm * mm, 0.0);
-        if (mp == mm - 1 && mp > 0) {
-            for (int i = 0; i < mp; ++i) {
-                A[(size_t)i * mm + i] = thp[(size_t)i];
-                double bi = 0.0;
-                for (int k = 0; k < mp; ++k) bi += Yp[(size_t)k * mp + i] * G[(size_t)k * m + j];
-                A[(size_t)i * mm + mp] = bi; A[(size_t)mp * mm + i] = bi;
-            }
-            A[(size_t)mp * mm + mp] = G[(size_t)j * m + j];
-            std::vector<double> Qa;
-            jacobi_eigh(mm, A, th, Qa);
-            Y.assign((size_t)mm * mm, 0.0);                                          // Y = blkdiag(Yp, 1) . Qa
-            for (int i = 0; i < mp; ++i)
-                for (int c = 0; c < mm; ++c) { double v = 0.0; for (int k = 0; k < mp; ++k) v += Yp[(size_t)i * mp + k] * Qa[(size_t)k * mm + c]; Y[(size_t)i * mm + c] = v; }
-            for (int c = 0; c < mm; ++c) Y[(size_t)mp * mm + c] = Qa[(size_t)mp * mm + c];
-        } else {
-            for (int a2 = 0; a2 < mm; ++a2) for (int b2 = 0; b2 < mm; ++b2) A[(size_t)a2 * mm + b2] = G[(size_t)a2 * m + b2];
-            jacobi_eigh(mm, A, th, Y);
-        }
-        Yp = Y; thp = th; mp = mm;
-        lambda = th[0];
-        ritz_is_v0 = false;
-        ydev.assign((size_t)mm, 0.0);
-        for (int i = 0; i < mm; ++i) ydev[(size_t)i] = Y[(size_t)i * mm + 0];
-        RitzCoef yarg;
-        for (int i = 0; i < mm; ++i) yarg.y[i] = ydev[(size_t)i];
-        const double floor_ = floor_rel * std::max(1.0, std::fabs(lambda)) * 1e-2 + 1e-12;
-        hipLaunchKernelGGL(ritz_precond_kernel, dim3(nblk), dim3(DOT_THREADS), 0, st, (const double*)V, (const double*)W, n, mm, yarg, lambda,
-                           (const double*)dD.as<double>(), floor_, t, n, dPartial.as<double>());
+        mm = j + 1;
+        const bool restart = mm == m;
+        DMRGX_CHK(multi_dot(mm, wvec(j), c1, dist));                               // column j of G = V^T w_j (reduced by the Ritz kernel itself unless an all-reduce must come first)
+        hipLaunchKernelGGL(gd_ritz_kernel, dim3(1), dim3(RITZ_THREADS), 0, st, S, dist ? (const double*)c1 : (const double*)dPartial.as<double>(), dist ? 0 : 1, nblk, mm, warm ? 1 : 0, restart ? 1 : 0, keep);
         DMRGX_HIP(hipGetLastError());
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(DOT_THREADS), 0, st, dPartial.as<double>(), nrm, 1, nblk);
+        warm = !restart;
+        rotated = false;
+        // correction vector (+ first Gram-Schmidt dots) and |r|^2
+        const int look_idx = fused ? mm + 1 : 0;
+        double* red_out = fused ? c1 : nrm;
+        if (fused) hipLaunchKernelGGL((ritz_precond_kernel<GD_NV, true>), dim3(nblk), dim3(DOT_THREADS), 0, st, (const double*)V, (const double*)W, n, mm, (const GdState*)S,
+                                      (const double*)dD.as<double>(), floor_rel, t, n, dPartial.as<double>());
+        else hipLaunchKernelGGL((ritz_precond_kernel<FUSE_NV, false>), dim3(nblk), dim3(DOT_THREADS), 0, st, (const double*)V, (const double*)W, n, mm, (const GdState*)S,
+                                (const double*)dD.as<double>(), floor_rel, t, n, dPartial.as<double>());
         DMRGX_HIP(hipGetLastError());
-        DMRGX_CHK(allreduce(nrm, 1));
-        DMRGX_HIP(hipMemcpyAsync(h_r2, nrm, sizeof(double), hipMemcpyDeviceToHost, st));
-        DMRGX_HIP(hipEventRecord(ev_r2, st));
-        // queued behind the read-back, before the host looks at it: the restart (when the basis is full) and the next direction
-        const bool may_continue = mm < N && n_matvec < max_mv && n_matvec < 6 * m;
+        const int nred = fused ? mm + 2 : 1;
+        hipLaunchKernelGGL(gd_reduce_look_kernel, dim3(nred), dim3(DOT_THREADS), 0, st, (const double*)dPartial.as<double>(), red_out, nred, nblk, look_idx, 0, (const GdState*)S, dLook.as<double>());
+        DMRGX_HIP(hipGetLastError());
+        if (dist) {
+            DMRGX_CHK(allreduce(red_out, nred));
+            hipLaunchKernelGGL(gd_reduce_look_kernel, dim3(nred), dim3(DOT_THREADS), 0, st, (const double*)dPartial.as<double>(), red_out, nred, nblk, look_idx, 1, (const GdState*)S, dLook.as<double>());
+            DMRGX_HIP(hipGetLastError());
+        }
+        DMRGX_HIP(hipMemcpyAsync(h_look, dLook.p, 3 * sizeof(double), hipMemcpyDeviceToHost, st));
+        DMRGX_HIP(hipEventRecord(ev_look, st));
+        // queued behind the look, before the host reads it: the restart (when the basis is full) and the next direction
+        const bool may_continue = mm < N && n_matvec < max_mv && n_matvec < hand_over;
         if (may_continue) {
-            if (mm == m) {
-                // thick restart: the kk lowest Ritz vectors span the new basis (V <- V Y, W <- W Y, G <- diag(theta))
-                const int kk = std::max(1, std::min({m / 2, m - 1, m / 2 + 2}));      // (dTmp holds m / 2 + 2 vectors)      // as many as the Lanczos path keeps: a slowly converging solve loses too much with fewer
-                std::vector<double> Q((size_t)m * kk);
-                for (int i = 0; i < m; ++i) for (int b2 = 0; b2 < kk; ++b2) Q[(size_t)i * kk + b2] = Y[(size_t)i * m + b2];
-                DMRGX_HIP(h2d_async(dY.p, Q.data(), Q.size() * sizeof(double), st));
+            bool have_dots = fused;
+            if (restart) {
+                // GD+k restart: V <- V Q, W <- W Q with Q = [lowest Ritz vectors | previous Ritz vector] from the device state; G <- Q^T G Q there
                 for (double* B : {V, W}) {
-                    hipLaunchKernelGGL(basis_rotate_kernel, dim3(1024, (kk + DOT_CHUNK - 1) / DOT_CHUNK), dim3(DOT_THREADS), 0, st, (const double*)B, n, m, (const double*)dY.as<double>(), kk, kk,
+                    hipLaunchKernelGGL(basis_rotate_kernel, dim3(1024, (kk + DOT_CHUNK - 1) / DOT_CHUNK), dim3(DOT_THREADS), 0, st, (const double*)B, n, m, S_Q, kk, kk,
                                        dTmp.as<double>(), n, n);
                     DMRGX_HIP(hipGetLastError());
                     DMRGX_HIP(hipMemcpyAsync(B, dTmp.p, (size_t)kk * n * sizeof(double), hipMemcpyDeviceToDevice, st));
                 }
-                std::fill(G.begin(), G.end(), 0.0);
-                for (int i = 0; i < kk; ++i) G[(size_t)i * m + i] = th[(size_t)i];
-                Yp.assign((size_t)kk * kk, 0.0);
-                for (int i = 0; i < kk; ++i) Yp[(size_t)i * kk + i] = 1.0;
-                thp.assign(th.begin(), th.begin() + kk); mp = kk;
                 j = kk - 1;
                 ++restarts;
-                ritz_is_v0 = true;
+                rotated = true;
+                have_dots = false;              // (the dots were taken against the old basis)
             }
-            DMRGX_CHK(orthonormalise_into(j + 1, t, vec(j + 1)));                 // next basis vector from the preconditioned residual
+            if (!have_dots) DMRGX_CHK(multi_dot(j + 1, t, c1, true));
+            DMRGX_CHK(orthonormalise_tail(j + 1, t, vec(j + 1)));                 // next basis vector from the preconditioned residual
         }
-        DMRGX_HIP(hipEventSynchronize(ev_r2));
-        resid = std::sqrt(std::max(*h_r2, 0.0));
+        DMRGX_HIP(hipEventSynchronize(ev_look));
+        resid = std::sqrt(std::max(h_look[0], 0.0));
+        lambda = h_look[1];
+        if (n_matvec == 1 && (!(h_look[2] > 0.0) || start_too_light(opts, pin))) {      // |H v_0|^2 is not positive: the start vector had zero (or NaN) norm -- see the Lanczos path; or it is lighter than the caller accepts
+            DMRGX_HIP(hipStreamSynchronize(st));
+            dV.release(); dW.release(); dTmp.release(); dT.release(); dD.release();      // (the repeated solve allocates its own work space)
+            dmrgx_eigs_opts o2 = *opts;
+            o2.method = 0; o2.use_initial = 0;
+            dmrgx_eigs_stats s2;
+            memset(&s2, 0, sizeof(s2));
+            const dmrgx_status rc = dmrgx_eigs_lowest(plan, &o2, e0, psi_full, &s2, (void*)st);
+            if (stats) { *stats = s2; stats->n_matvec += n_matvec; stats->start_rejected = 1;
+                         stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(); }
+            return rc;
+        }
         static const bool trace = getenv("DMRGX_EIGS_TRACE") != nullptr;
-        if (trace) fprintf(stderr, "[eigs gd] matvec %d: theta %.12f  |r| %.3e  (target %.3e)  t = %.3f ms\n", n_matvec, lambda, resid, tol * std::fabs(lambda),
+        if (trace) fprintf(stderr, "[eigs gd] matvec %d: basis %d theta %.12f  |r| %.3e  (target %.3e)  t = %.3f ms\n", n_matvec, mm, lambda, resid, tol * std::fabs(lambda),
                            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
         if (resid <= tol * std::max(std::fabs(lambda), 1e-300) || mm == N) { converged = 1; break; }
         if (n_matvec >= max_mv) break;
-        if (n_matvec >= 6 * m) {
+        if (n_matvec >= hand_over) {
             // a start vector that was not close after all (the preconditioned iteration then trails Lanczos, see above): hand the
             // current Ritz vector to the Lanczos path instead of iterating on
-            ydev.assign((size_t)mm, 0.0);
-            for (int i = 0; i < mm; ++i) ydev[(size_t)i] = Y[(size_t)i * mm + 0];
-            DMRGX_HIP(h2d_async(dY.p, ydev.data(), ydev.size() * sizeof(double), st));
-            hipLaunchKernelGGL(basis_rotate_kernel, dim3(1024, 1), dim3(DOT_THREADS), 0, st, (const double*)V, n, mm, (const double*)dY.as<double>(), 1, 1,
+            hipLaunchKernelGGL(basis_rotate_kernel, dim3(1024, 1), dim3(DOT_THREADS), 0, st, (const double*)V, n, mm, S_y, 1, 1,
                                dist ? psi_full + I.local_offset : psi_full, n, n);
             DMRGX_HIP(hipGetLastError());
             DMRGX_HIP(hipStreamSynchronize(st));
+            dV.release(); dW.release(); dTmp.release(); dT.release(); dD.release();
             dmrgx_eigs_opts o2 = *opts;
-            o2.method = 0; o2.use_initial = 1;
+            o2.method = 0; o2.use_initial = 1; o2.min_initial_norm2 = 0.0;
             dmrgx_eigs_stats s2;
             memset(&s2, 0, sizeof(s2));
             const dmrgx_status rc = dmrgx_eigs_lowest(plan, &o2, e0, psi_full, &s2, (void*)st);
@@ -867,19 +1103,14 @@ static dmrgx_status eigs_davidson(dmrgx_kron_plan* plan, const dmrgx_eigs_opts* 
         }
         ++j;
     }
-    DMRGX_HIP(hipStreamSynchronize(st));                                           // (host vectors of queued uploads go out of scope below)
     // ---- eigenvector: psi = V y, renormalised --------------------------------------------------------------------------------
     {
         // the Ritz vector: V y in the basis the Ritz problem was solved in -- or, when a restart has been queued since, simply the
         // first vector of the new basis
-        const int mm = ritz_is_v0 ? 1 : j + 1;
-        ydev.assign((size_t)mm, 0.0);
-        if (ritz_is_v0) ydev[0] = 1.0;
-        else for (int i = 0; i < mm; ++i) ydev[(size_t)i] = Y[(size_t)i * mm + 0];
-        DMRGX_HIP(h2d_async(dY.p, ydev.data(), ydev.size() * sizeof(double), st));
-        hipLaunchKernelGGL(basis_rotate_kernel, dim3(1024, 1), dim3(DOT_THREADS), 0, st, (const double*)V, n, mm, (const double*)dY.as<double>(), 1, 1, t, n, n);
+        const int nb = rotated ? 1 : mm;
+        hipLaunchKernelGGL(basis_rotate_kernel, dim3(1024, 1), dim3(DOT_THREADS), 0, st, (const double*)V, n, nb, rotated ? S_e0 : S_y, 1, 1, t, n, n);
         DMRGX_HIP(hipGetLastError());
-        DMRGX_CHK(multi_dot(0, t, c1));
+        DMRGX_CHK(multi_dot(0, t, c1, true));
         DMRGX_HIP(hipMemcpyAsync(nrm, c1, sizeof(double), hipMemcpyDeviceToDevice, st));
         double* dst = dist ? psi_full + I.local_offset : psi_full;
         hipLaunchKernelGGL(scale_copy_kernel, dim3(1024), dim3(256), 0, st, (const double*)t, dst, n, (const double*)nrm);

@@ -175,6 +175,7 @@ public:
         ierr = PetscOptionsGetReal(NULL, NULL, "-qn_sector", &qn_sector, NULL); CHKERRQ(ierr);
         ierr = PetscOptionsGetReal(NULL, NULL, "-H_eps_tol", &eps_tol, NULL); CHKERRQ(ierr);
         ierr = PetscOptionsGetInt(NULL, NULL, "-H_eps_ncv", &eps_ncv, NULL); CHKERRQ(ierr);
+        ierr = PetscOptionsGetInt(NULL, NULL, "-H_eps_gd_minv", &eps_gd_minv, NULL); CHKERRQ(ierr);
         ierr = PetscOptionsGetInt(NULL, NULL, "-H_eps_max_it", &eps_max_it, NULL); CHKERRQ(ierr);
         {   /* SLEPc's solver choice for the superblock problem: krylovschur (its default; here thick-restart Lanczos) or gd */
             char type[64] = "krylovschur"; PetscBool set = PETSC_FALSE;
@@ -531,7 +532,7 @@ public:
             dmrgx_eigs_opts o;
             memset(&o, 0, sizeof(o));
             o.ncv = (int32_t)eps_ncv; o.max_it = (int32_t)eps_max_it; o.tol = eps_tol; o.seed = 0x9E3779B9u + (uint64_t)GlobIdx;
-            o.method = eps_method;
+            o.method = eps_method; o.gd_minv = (int32_t)eps_gd_minv;
             bool guessed = false;
             double min_norm2 = 0.0;
             try { ierr = TransformedGuess(KronBlocks, SysBlock, EnvBlock, gsv_r, guessed, min_norm2); CHKERRQ(ierr); }
@@ -1680,7 +1681,7 @@ private:
     PetscBool init = PETSC_FALSE, verbose = PETSC_FALSE, no_symm = PETSC_FALSE, do_shell = PETSC_TRUE, dry_run = PETSC_FALSE, warmed_up = PETSC_FALSE;
     PetscReal qn_sector = 0.0;
     PetscReal eps_tol = 1.0e-8;     /* SLEPc's default relative residual tolerance */
-    PetscInt eps_ncv = 16, eps_max_it = 1000;
+    PetscInt eps_ncv = 0, eps_max_it = 1000, eps_gd_minv = 0;      /* 0: the library's default for the solver type (ncv: 16 krylovschur, 8 gd; minv 1) */
     int32_t eps_method = 0;         /* -H_eps_type: 0 krylovschur (thick-restart Lanczos), 1 gd (generalized Davidson, diagonal preconditioner) */
     std::string scratch_dir, data_dir;
     FILE *fp_step = NULL, *fp_timings = NULL, *fp_entanglement = NULL, *fp_data = NULL, *fp_corr = NULL, *fp_kron = NULL;

@@ -114,7 +114,7 @@ class KronPlan:
                                                             self._stream_ptr(stream)))
 
     def eigs_lowest(self, ncv=16, max_it=1000, tol=1e-8, seed=1, psi0=None, allgather=None, allreduce=None, stream=None,
-                    max_matvec=0, comm=None, method=0, min_initial_norm2=0.0):
+                    max_matvec=0, comm=None, method=0, min_initial_norm2=0.0, gd_minv=0):
         """Lowest eigenpair (EPS_HEP / EPS_SMALLEST_REAL / nev=1).  Returns (e0, psi_full tensor, stats).
 
         max_matvec > 0 (benchmarks): run exactly that many Lanczos steps; non-convergence is then not an error.
@@ -131,6 +131,7 @@ class KronPlan:
         opts.allgather, opts.allreduce_sum = self._cb
         opts.comm = comm.handle if comm is not None else None
         opts.method = method            # 0: thick-restart Lanczos, 1: generalized Davidson (diagonal preconditioner)
+        opts.gd_minv = gd_minv          # method 1: Ritz vectors kept at a restart beside the previous Ritz vector (0: default 1)
         opts.min_initial_norm2 = min_initial_norm2      # > 0: psi0 is dropped (stats.start_rejected) when |psi0|^2 is below this
         e0 = C.c_double(0.0)
         stats = _capi.EigsStats()

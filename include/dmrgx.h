@@ -224,8 +224,8 @@ typedef struct {
     dmrgx_comm* comm;
     /* 0: thick-restart Lanczos (SLEPc's default for this solve, -H_eps_type krylovschur).  1: generalized Davidson with the
      * diagonal of H_sb as preconditioner (-H_eps_type gd with a Jacobi preconditioner): same convergence criterion (true
-     * residual), about a quarter fewer MatMults from the engine's transformed start vectors, two host looks per iteration
-     * (worth it only when a MatMult costs milliseconds).  Applies when use_initial is set; from a random start the Lanczos
+     * residual), about a quarter fewer MatMults from the engine's transformed start vectors; the projected problem is
+     * solved on the device, the host only looks at (|r|, theta) one iteration behind the queue.  Applies when use_initial is set; from a random start the Lanczos
      * path is used (the preconditioned iteration is twice as slow there). */
     int32_t method;
     /* > 0 (with use_initial): the start vector is only trusted if its squared norm is at least this -- the engine's start vectors are
@@ -233,6 +233,11 @@ typedef struct {
      * from the random start vector (stats->start_rejected = 1).  The norm is read with the first coefficients that come back to the
      * host anyway: no extra synchronisation.  0: no check beyond "not zero / NaN". */
     double min_initial_norm2;
+    /* method 1: number of lowest Ritz vectors the search space is restarted to, beside the previous iteration's Ritz vector (SLEPc:
+     * -eps_gd_minv with -eps_gd_plusk 1).  0: the default, 1.  The search space itself holds `ncv` vectors (0: the default of the
+     * method -- 16 for method 0, 8 for method 1). */
+    int32_t gd_minv;
+    int32_t reserved_;
 } dmrgx_eigs_opts;
 
 typedef struct {

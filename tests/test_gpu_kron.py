@@ -310,8 +310,11 @@ def test_eigs_generalized_davidson_vs_dense_and_lanczos(mods):
     w, v = np.linalg.eigh(H)
     rng = np.random.default_rng(1)
     # (without a start vector the option falls through to Lanczos; a random psi0 exercises the Davidson iteration from far away)
-    for kwargs in (dict(psi0=torch.from_numpy(rng.standard_normal(n)).cuda()), dict(psi0=torch.from_numpy(rng.standard_normal(n)).cuda(), ncv=6),
-                   dict(psi0=torch.from_numpy(v[:, 0] + 1e-3 * rng.standard_normal(n)).cuda()), dict(seed=9)):
+    # search spaces: the library's default (ncv = 0 -> 8 vectors, restarted to 1 Ritz vector + the previous one: the fused correction
+    # kernel), the smallest that can grow after a restart (3), two kept Ritz vectors, and 16 (the correction kernel without the dots)
+    far = lambda: torch.from_numpy(rng.standard_normal(n)).cuda()                                        # noqa: E731
+    for kwargs in (dict(psi0=far(), ncv=0), dict(psi0=far(), ncv=6), dict(psi0=far(), ncv=3), dict(psi0=far(), ncv=5, gd_minv=2), dict(psi0=far()),
+                   dict(psi0=torch.from_numpy(v[:, 0] + 1e-3 * rng.standard_normal(n)).cuda(), ncv=0), dict(seed=9)):
         e0, psi, stats = plan.eigs_lowest(tol=1e-12, method=1, **kwargs)
         assert stats.converged == 1 and stats.n_matvec > 0
         assert abs(e0 - w[0]) <= 1e-10 * abs(w[0])

@@ -24,6 +24,19 @@ for s,e,nm in rows[i0:]:
 print("last %d steps: wall %.3f s, GPU busy %.3f s = %.1f %%, idle per step %.2f ms"%(n,(hi-lo)/1e9,busy/1e9,100*busy/(hi-lo),(hi-lo-busy)/1e6/n))
 print("idle gaps > 20 us by (kernel before -> kernel after), ms per step:")
 for k,v in gaps.most_common(14): print("  %6.3f  %s -> %s"%(v/1e6/n,k[0],k[1]))
+kt=collections.Counter(); kc=collections.Counter(); small=0
+for s,e,nm in rows[i0:]:
+    k=nm.replace("(anonymous namespace)::","").replace("dmrgx::","").replace("void ","").split("(")[0][-44:]
+    kt[k]+=e-s; kc[k]+=1
+    g=s-prev_end
+print("kernel time of the last %d steps, ms per step (launches per step):"%n)
+for k,v in kt.most_common(28): print("  %7.3f  (%6.1f)  %s"%(v/1e6/n,kc[k]/n,k))
+gsum=0; prev_end=lo
+for s,e,nm in rows[i0:]:
+    g=s-prev_end
+    if 0<g<=20000: gsum+=g
+    prev_end=max(prev_end,e)
+print("gaps <= 20 us between consecutive kernels: %.3f ms per step over %.0f launches per step"%(gsum/1e6/n,len(rows[i0:])/n))
 PY
 rm -f $f $out/data/EntanglementSpectra.json $out/data/KronStats.json $out/data/Correlations.json
 cat $out/busy.txt
