@@ -178,6 +178,19 @@ def engine_run(opts, timeout=300, ranks=1, rehearsal=False):
             run["InSweep"] = {"gemm_tflops": fl / tg / 1e12, "roofline_frac": fl / tg / 1e12 / F64_PEAK_TFLOPS,
                               "mean_flops_alg_per_matmult": fl / sum(k["timed_applies"] for k in ks),
                               "mean_n_states": sum(k["n_states"] for k in ks) / len(ks), "gemm_seconds": tg}
+        # what a MatMult of the LAST sweep costs beyond its GEMM launches: (Diag - sum of HIP-event GEMM time) / MatMults --
+        # the solver's vector kernels, the projected problem, the split-K fix-up, launch gaps and synchronisations
+        if ks and last is not None:
+            sweep_of = {int(st[0]): int(st[2]) for st in steps if st[1] == "Sweep"}
+            kl = [k for k in ks if sweep_of.get(int(k["GlobIdx"])) == last]
+            nmv = sum(int(tm[col["MatMults"]]) for tm in rows) if "MatMults" in col else 0
+            if kl and nmv:
+                gemm_ms = sum((k["ms_stage1"] + k["ms_stage2"]) * (k["matmults"] / k["timed_applies"]) for k in kl if k["timed_applies"] > 0)
+                diag_ms = 1e3 * sum(float(r[col["Diag"]]) for r in rows)
+                run["NonGemmMsPerMatMult"] = (diag_ms - gemm_ms) / nmv
+                run["GemmMsPerMatMult"] = gemm_ms / nmv
+        run["SolverPath"] = {k: run.get(k) for k in ("RdmCalls", "RdmBlockJacobiCalls", "TridPersistentCalls", "TridLaunchPathCalls", "TridFallbacks",
+                                                     "TridMaxWorkgroupsPerMatrix", "RdmMaxMergeLevels", "RdmMaxWyBlocks")}
         run["SweepEnergies"] = {}
         for st in steps:
             if st[1] == "Sweep":
@@ -191,7 +204,7 @@ def sweep_legs():
     sites/sec per sweep on configs[3] -- the lattice and m the north star quotes (J1-J2 20x8 cylinder, J2 = 0.5, m = 2048: it
     fits one MI355X, about a minute) -- and on configs[1] (J1-J2 8x4, m = 512), and the E0 relative error on configs[0]
     (Heisenberg 16x1 chain, m = 64, 2 sweeps) against exact diagonalisation."""
-    def leg(run, config):
+    def leg(run, config, expect_launch_path=False):
         out = {"sites_per_s": run["LastSweepSteps"] / run["LastSweepSeconds"], "config": config, "sweep_steps": run["LastSweepSteps"],
                "sweep_seconds": run["LastSweepSeconds"], "sweep_matmults": run["LastSweepMatMults"],
                "matmults_per_s_in_sweep": run["LastSweepMatMults"] / run["LastSweepSeconds"], "gs_energy": run["GSEnergy"],
@@ -199,6 +212,17 @@ def sweep_legs():
         if "InSweep" in run:       # the roofline of the dominant kernel on the REAL superblocks of the sweep
             out["roofline_frac"] = run["InSweep"]["roofline_frac"]
             out["in_sweep"] = run["InSweep"]
+        if "NonGemmMsPerMatMult" in run:
+            out["nongemm_ms_per_matmult"] = run["NonGemmMsPerMatMult"]
+            out["gemm_ms_per_matmult"] = run["GemmMsPerMatMult"]
+        # which path the density-matrix solver took (dmrgx_rdm_info -> DMRGRun.json): a leg that silently fell back to the slower
+        # tridiagonalisation (a bounded-spin time-out latches for the rest of the process) or to the block-Jacobi solver is not a measurement
+        # of the code this line describes -- it fails instead of looking 5 ms per step slower
+        sp = run["SolverPath"]
+        out["solver_path"] = sp
+        assert sp["TridFallbacks"] == 0, ("the persistent tridiagonalisation timed out and fell back to one launch per column", config, sp)
+        if not expect_launch_path:
+            assert sp["RdmBlockJacobiCalls"] == 0 and sp["TridLaunchPathCalls"] == 0 and sp["TridPersistentCalls"] == sp["RdmCalls"], ("unexpected density-matrix solver path", config, sp)
         # self-consistency of the printed energies (the parity tier compares them with the oracle, tests/test_gpu_engine.py):
         # DMRG is variational, so the energy at the end of a sweep may not rise above the previous sweep's by more than the
         # truncation error allows
@@ -257,7 +281,8 @@ def sweep_legs():
     if os.environ.get("DMRGX_BENCH_CONFIGS4", "1") != "0" and time.perf_counter() - t_legs < 200.0:
         try:
             run4 = engine_run(["-Lx", 32, "-Ly", 8, "-J1", 1, "-Jz1", 0, "-J2", 1, "-Jz2", 0, "-mwarmup", 4096, "-nsweeps", 1, "-H_eps_type", "gd"], timeout=900)
-            out["configs_4"] = leg(run4, "configs[4] on one GPU: XY 32x8 cylinder (256 sites), m=4096, warm-up + one finite-system sweep (real engine run, -H_eps_type gd)")
+            out["configs_4"] = leg(run4, "configs[4] on one GPU: XY 32x8 cylinder (256 sites), m=4096, warm-up + one finite-system sweep (real engine run, -H_eps_type gd)",
+                                   expect_launch_path=True)      # (sectors above order ~1700 take one launch per column by design)
             out["configs_4"]["device_bytes_peak"] = run4.get("DeviceBytesPeak")
             out["configs_4"]["device_bytes_resident_after_sweep"] = run4.get("DeviceBytesResidentAfterSweep")
         except Exception as e:                                    # noqa: BLE001 -- reported in the JSON line

@@ -50,6 +50,11 @@ class KronDesc(C.Structure):
                 ("world_size", C.c_int32), ("rank", C.c_int32)]
 
 
+class RdmReport(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in ("n_sweeps", "solver", "trid_persistent_matrices", "trid_launch_matrices", "max_workgroups_per_matrix",
+                                         "merge_levels", "wy_blocks_max", "timed_out", "process_timeouts", "persistent_off")]
+
+
 class KronInfo(C.Structure):
     _fields_ = [("n_states", C.c_int64), ("vec_len", C.c_int64), ("local_offset", C.c_int64), ("local_len", C.c_int64),
                 ("seg_stride", C.c_int64), ("flops_alg", C.c_double), ("bytes_alg", C.c_double), ("flops_exec", C.c_double),
@@ -114,7 +119,7 @@ SIGNATURES = {
     "dmrgx_rdm_create_warm": (C.c_int32, [C.POINTER(Sectors), C.POINTER(Sectors), C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
     "dmrgx_rdm_eigenvectors": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
-    "dmrgx_rdm_info": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32)]),
+    "dmrgx_rdm_info": (C.c_int32, [C.c_void_p, C.POINTER(RdmReport)]),
     "dmrgx_rdm_destroy": (C.c_int32, [C.c_void_p]),
     "dmrgx_cells_axpy": (C.c_int32, [C.c_int32, C.POINTER(AxpyTask), C.c_void_p]),
     "dmrgx_rotate_ops": (C.c_int32, [C.POINTER(Sectors), C.POINTER(Rotation), C.c_int32, C.POINTER(SecOp), C.POINTER(C.POINTER(C.c_void_p)), C.c_void_p]),

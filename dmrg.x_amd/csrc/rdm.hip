@@ -463,6 +463,8 @@ struct dmrgx_rdm {
     std::vector<int64_t> perm_off;
     std::vector<uint8_t> selected;             // per matrix: built and diagonalised by this rank (dmrgx_rdm_create_subset)
     int32_t sweeps = 0;
+    int32_t solver = 0;                        // 0: tridiagonalisation + divide and conquer (symeig.hip), 1: block Jacobi
+    SymEigReport symeig;                       // what the direct solver did (solver == 0)
 };
 
 static dmrgx_status rdm_create_impl(const dmrgx_sectors* left, const dmrgx_sectors* right, int32_t nblocks,
@@ -568,6 +570,7 @@ static dmrgx_status rdm_create_impl(const dmrgx_sectors* left, const dmrgx_secto
     const int64_t diag_base = total; total += dtot;
     const int64_t rq_base = total; total += dtot;            // Rayleigh quotients, same indexing as the diagonals
     const int64_t w_base = total; total += 2 * N;            // W = Psi^T V_L (n_R x n_L) and Psi V_R (n_L x n_R) per block
+    P->solver = use_dc ? 0 : 1;
     const int64_t ew_base = total; total += use_dc ? dtot : 0;   // eigenvalues as the direct solver returns them (ascending)
     // warm start: per matrix with a previous eigenbasis E (rows), W = E A and E^T (n x n each)
     // QR preconditioner of the Jacobi path: its basis replaces the caller's v0_rows, which then only remain a hint
@@ -692,7 +695,7 @@ static dmrgx_status rdm_create_impl(const dmrgx_sectors* left, const dmrgx_secto
             const MatDesc& m = P->mats[mi];
             if (m.n > 0) sm.push_back(SymEigMat{m.n, m.npad, m.npad, 0, buf + m.a_off, buf + m.v_off, buf + ew_base + (diag_off[mi] - diag_base)});
         }
-        DMRGX_CHK(symeig_batched(sm, st));
+        DMRGX_CHK(symeig_batched(sm, st, &P->symeig));
         stage("symeig");
     }
     bool any_warm = false;
@@ -904,10 +907,19 @@ extern "C" dmrgx_status dmrgx_rdm_eigenvectors(const dmrgx_rdm* R, int32_t side,
     return DMRGX_OK;
 }
 
-extern "C" dmrgx_status dmrgx_rdm_info(const dmrgx_rdm* R, int32_t* n_sweeps)
+extern "C" dmrgx_status dmrgx_rdm_info(const dmrgx_rdm* R, dmrgx_rdm_report* out)
 {
-    if (!R || !n_sweeps) DMRGX_FAIL(DMRGX_ERR_ARG, "rdm_info: bad argument");
-    *n_sweeps = R->sweeps;
+    if (!R || !out) DMRGX_FAIL(DMRGX_ERR_ARG, "rdm_info: bad argument");
+    memset(out, 0, sizeof(*out));
+    out->n_sweeps = R->sweeps;
+    out->solver = R->solver;
+    out->trid_persistent_matrices = R->symeig.persistent_matrices;
+    out->trid_launch_matrices = R->symeig.launch_matrices;
+    out->max_workgroups_per_matrix = R->symeig.max_workgroups_per_matrix;
+    out->merge_levels = R->symeig.merge_levels;
+    out->wy_blocks_max = R->symeig.wy_blocks_max;
+    out->timed_out = R->symeig.timed_out;
+    symeig_process_state(&out->process_timeouts, &out->persistent_off);
     return DMRGX_OK;
 }
 

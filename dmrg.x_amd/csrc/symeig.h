@@ -27,11 +27,24 @@ constexpr int SYMEIG_MAX_N = 3072;     // the merge kernels keep O(n) vectors of
 // tridiagonalisation ran, the call waits for it once (it reads the kernel's status word to decide between carrying on and repeating
 // the step by launches) before it enqueues the rest, and the WY factors run on an internal second stream that joins `st` again
 // before the call returns.
-dmrgx_status symeig_batched(const std::vector<SymEigMat>& mats, hipStream_t st);
+// What a call did (optional): which tridiagonalisation path the matrices took, how the persistent kernel was laid out, how deep the
+// divide-and-conquer tree went -- the reference checks "all eigenpairs converged" after its LAPACK call
+// (include/DMRGBlockContainer.hpp:1987); here the equivalent of a silent failure would be a silently slower path.
+struct SymEigReport {
+    int32_t persistent_matrices = 0;     // tridiagonalised by the persistent LDS-resident kernel
+    int32_t launch_matrices = 0;         // tridiagonalised by one launch per column: by design (rows do not fit) or after a time-out
+    int32_t max_workgroups_per_matrix = 0;
+    int32_t merge_levels = 0;            // depth of the divide-and-conquer tree of the largest matrix
+    int32_t wy_blocks_max = 0;           // compact-WY blocks of the back-transformation of the largest matrix
+    int32_t timed_out = 0;               // this call's persistent round ran into its bounded spin (1) or was lapped (2) and was repeated by launches
+};
+dmrgx_status symeig_batched(const std::vector<SymEigMat>& mats, hipStream_t st, SymEigReport* report = nullptr);
 
 // The tridiagonalisation normally runs as ONE persistent launch with the matrices resident in the LDS of most CUs of the
 // chip; processes that share a GPU with other ranks (the host-staged rehearsal communicator) switch it off and use one launch per
 // column (also selected by DMRGX_TRID=launch, and automatically after a bounded-spin timeout).
 void symeig_set_persistent(bool on);
+// process-wide: persistent rounds that timed out so far, and whether the persistent kernel is switched off (by a time-out or by the call above)
+void symeig_process_state(int32_t* timeouts, int32_t* persistent_off);
 
 }  // namespace dmrgx

@@ -1020,6 +1020,7 @@ std::vector<int> tree_bounds(int n, int level)
 }
 
 bool g_coop_disabled = false;                       // set once a persistent round has timed out (process-wide)
+int32_t g_coop_timeouts = 0;                        // how often that happened
 
 struct GemmSet {                                   // the tile lists of one dependent GEMM step
     size_t big_off = 0, small_off = 0;
@@ -1035,9 +1036,17 @@ template <class K> dmrgx_status set_dyn_lds(K kernel, size_t bytes)
 }  // namespace
 
 void symeig_set_persistent(bool on) { g_coop_disabled = !on; }
-
-dmrgx_status symeig_batched(const std::vector<SymEigMat>& mats_in, hipStream_t st)
+void symeig_process_state(int32_t* timeouts, int32_t* persistent_off)
 {
+    if (timeouts) *timeouts = g_coop_timeouts;
+    if (persistent_off) *persistent_off = g_coop_disabled ? 1 : 0;
+}
+
+dmrgx_status symeig_batched(const std::vector<SymEigMat>& mats_in, hipStream_t st, SymEigReport* report)
+{
+    SymEigReport rep_local;
+    SymEigReport& rep = report ? *report : rep_local;
+    rep = SymEigReport();
     std::vector<SymEigMat> M;
     for (const SymEigMat& s : mats_in) {
         if (s.n < 0 || s.n > SYMEIG_MAX_N) DMRGX_FAIL(DMRGX_ERR_ARG, "symeig: matrix of order %d (supported: 0..%d)", s.n, SYMEIG_MAX_N);
@@ -1162,6 +1171,7 @@ dmrgx_status symeig_batched(const std::vector<SymEigMat>& mats_in, hipStream_t s
             if (!r) { rounds.emplace_back(); r = &rounds.back(); }
             r->mats.push_back(q); r->G.push_back(G); r->wgs += G;
             coop_set.push_back(q);
+            rep.max_workgroups_per_matrix = std::max(rep.max_workgroups_per_matrix, G);
         }
         if (!rounds.empty()) {
             int64_t gtot = 2;                                                        // in u64 words; the status word owns the first 16 bytes
@@ -1199,6 +1209,7 @@ dmrgx_status symeig_batched(const std::vector<SymEigMat>& mats_in, hipStream_t s
         }
     } else for (int q = 0; q < nm; ++q) launch_set.push_back(q);
     if (!launch_set.empty()) DMRGX_CHK(trid_by_launches(launch_set));
+    rep.persistent_matrices = (int32_t)coop_set.size(); rep.launch_matrices = (int32_t)launch_set.size();
     hmark("trid launched");
 
     // ---- 3a. (independent of the eigenvectors) V = (V^T)^T, the Gram blocks, T factors and T V^T ---------------------------------
@@ -1263,6 +1274,7 @@ dmrgx_status symeig_batched(const std::vector<SymEigMat>& mats_in, hipStream_t s
         int D = 0;
         while ((n + (1 << D) - 1) / (1 << D) > DC_LEAF) ++D;
         depth[i] = D; dmax = std::max(dmax, D);
+        rep.merge_levels = dmax; rep.wy_blocks_max = std::max(rep.wy_blocks_max, w.nblk);
         DcMat& q = dm[i];
         q.Q[0] = M[i].X; q.ldq[0] = M[i].ldx;
         q.Q[1] = B + w.Q1; q.ldq[1] = n;
@@ -1358,6 +1370,8 @@ dmrgx_status symeig_batched(const std::vector<SymEigMat>& mats_in, hipStream_t s
                                                                     : "[dmrgx] persistent tridiagonalisation timed out waiting for a partner workgroup (GPU shared with another "
                                                                       "persistent kernel?): using one launch per column from now on\n");
             g_coop_disabled = true;
+            ++g_coop_timeouts;
+            rep.timed_out = coop_status; rep.launch_matrices += rep.persistent_matrices; rep.persistent_matrices = 0;
             DMRGX_CHK(trid_by_launches(coop_set));     // A was only read by the persistent kernel
         }
     }

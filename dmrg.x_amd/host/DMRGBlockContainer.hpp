@@ -451,8 +451,11 @@ public:
             size_t in_use = 0, cached = 0, peak = 0;
             dmrgx_mem_stats(&in_use, &cached, &peak);
             fprintf(fp_data, "],\n  \"GSEnergy\": %.16g,\n  \"MatMults\": %lld,\n  \"LastSweepSeconds\": %.9g,\n  \"LastSweepSteps\": %lld,\n  \"LastSweepMatMults\": %lld,\n  \"EigensolveSeconds\": %.9g,\n"
-                             "  \"DeviceBytesResidentAfterSweep\": %zu,\n  \"DeviceBytesPeak\": %zu,\n  \"DeviceBytesCached\": %zu,\n  \"StartVectorsTransformed\": %lld,\n  \"StartVectorsThroughOverlap\": %lld,\n  \"StartVectorsRejected\": %lld,\n  \"Ranks\": %d\n}\n",
-                    gse, LLD(total_matmults), last_sweep_seconds, LLD(last_sweep_steps), LLD(last_sweep_matmults), total_eigs_seconds, device_bytes_after_sweep, peak, cached, LLD(guesses_used), LLD(guesses_projected), LLD(guesses_rejected), (int)mpi_size);
+                             "  \"DeviceBytesResidentAfterSweep\": %zu,\n  \"DeviceBytesPeak\": %zu,\n  \"DeviceBytesCached\": %zu,\n  \"StartVectorsTransformed\": %lld,\n  \"StartVectorsThroughOverlap\": %lld,\n  \"StartVectorsRejected\": %lld,\n"
+                             "  \"RdmCalls\": %lld,\n  \"RdmBlockJacobiCalls\": %lld,\n  \"TridPersistentCalls\": %lld,\n  \"TridLaunchPathCalls\": %lld,\n  \"TridFallbacks\": %lld,\n"
+                             "  \"TridMaxWorkgroupsPerMatrix\": %lld,\n  \"RdmMaxMergeLevels\": %lld,\n  \"RdmMaxWyBlocks\": %lld,\n  \"Ranks\": %d\n}\n",
+                    gse, LLD(total_matmults), last_sweep_seconds, LLD(last_sweep_steps), LLD(last_sweep_matmults), total_eigs_seconds, device_bytes_after_sweep, peak, cached, LLD(guesses_used), LLD(guesses_projected), LLD(guesses_rejected),
+                    LLD(rdm_calls), LLD(rdm_jacobi_calls), LLD(trid_persistent_calls), LLD(trid_launch_calls), LLD(trid_fallbacks), LLD(trid_max_wgs), LLD(rdm_max_levels), LLD(rdm_max_wy_blocks), (int)mpi_size);
             fclose(fp_data); fp_data = NULL;
         }
         init = PETSC_FALSE;
@@ -1412,7 +1415,21 @@ public:
             }
         }
         PetscTime(&tr1);
-        if (!mpi_rank && verbose) { int32_t nsw = 0; dmrgx_rdm_info(rdm, &nsw); printf("  RDM: %lld KronBlocks, %lld warm-started, block-Jacobi sweeps %d, create %.6f s\n", LLD(nb), LLD(nwarm), nsw, tr1 - tr0); }
+        {
+            /* which path the density-matrix solver took: a time-out fallback or an unexpected launch path must show in DMRGRun.json, not only on stderr */
+            dmrgx_rdm_report rr;
+            if (dmrgx_rdm_info(rdm, &rr)) { dmrgx_rdm_destroy(rdm); SETERRQ1(mpi_comm, 1, "dmrgx_rdm_info: %s", dmrgx_last_error()); }
+            ++rdm_calls;
+            if (rr.solver == 1) ++rdm_jacobi_calls;
+            if (rr.timed_out) ++trid_fallbacks;
+            if (rr.trid_launch_matrices > 0) ++trid_launch_calls;
+            if (rr.trid_persistent_matrices > 0) ++trid_persistent_calls;
+            trid_max_wgs = std::max<PetscInt>(trid_max_wgs, rr.max_workgroups_per_matrix);
+            rdm_max_levels = std::max<PetscInt>(rdm_max_levels, rr.merge_levels);
+            rdm_max_wy_blocks = std::max<PetscInt>(rdm_max_wy_blocks, rr.wy_blocks_max);
+            if (!mpi_rank && verbose) printf("  RDM: %lld KronBlocks, %lld warm-started, block-Jacobi sweeps %d, persistent / launch-path matrices %d / %d, workgroups per matrix <= %d, merge levels %d, create %.6f s\n",
+                                             LLD(nb), LLD(nwarm), rr.n_sweeps, rr.trid_persistent_matrices, rr.trid_launch_matrices, rr.max_workgroups_per_matrix, rr.merge_levels, tr1 - tr0);
+        }
         BasisTransformation* BT[2] = {&BT_L, &BT_R};
         for (int side = 0; side < 2; ++side) {
             std::vector<Eigen_t> eigen;
@@ -1738,6 +1755,8 @@ private:
     std::vector<int64_t> block_ver;                       /**< current version of every stored block (0: as initialised) */
     std::vector<std::shared_ptr<BasisOverlap>> block_ovl; /**< [i]: parent version of block_rot[i+1] -> current version of block i */
     int64_t ver_counter = 0;
+    /** which path the density-matrix solver took, per truncation (dmrgx_rdm_info): DMRGRun.json RdmCalls ... RdmMaxWyBlocks */
+    PetscInt rdm_calls = 0, rdm_jacobi_calls = 0, trid_persistent_calls = 0, trid_launch_calls = 0, trid_fallbacks = 0, trid_max_wgs = 0, rdm_max_levels = 0, rdm_max_wy_blocks = 0;
     PetscInt guesses_projected = 0, guesses_rejected = 0;                       /**< start vectors that went through a basis overlap */
     PetscBool use_guess = PETSC_TRUE;
     PetscBool use_guess_overlap = PETSC_TRUE;   /* -wavefunction_guess_overlap 0: no start vector where the stored chain of bases is broken (round-2 behaviour) */

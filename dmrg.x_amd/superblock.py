@@ -198,9 +198,9 @@ class ReducedDensityMatrices:
                                                 C.cast(ptrs, C.c_void_p), st, C.byref(self._handle)))
         else:
             _capi.check(L.dmrgx_rdm_create(C.byref(sl), C.byref(sr), len(blocks), bil, bir, C.c_void_p(psi.data_ptr()), st, C.byref(self._handle)))
-        n = C.c_int32(0)
-        _capi.check(L.dmrgx_rdm_info(self._handle, C.byref(n)))
-        self.sweeps = n.value
+        self.report = _capi.RdmReport()         # which solver path ran: tridiagonalisation kind, workgroups per matrix, merge levels, time-outs
+        _capi.check(L.dmrgx_rdm_info(self._handle, C.byref(self.report)))
+        self.sweeps = self.report.n_sweeps
 
     def size(self, side, k):
         return (self.left_sizes[self.blocks[k][0]], self.right_sizes[self.blocks[k][1]])[side]

@@ -285,7 +285,22 @@ dmrgx_status dmrgx_rdm_eigenvalues(const dmrgx_rdm* rdm, int32_t side, int32_t k
 /* dst_dev[r*ld + i], r < count: the eigenvector of the r-th largest eigenvalue as a ROW (a row of RotMatT,
  * == FillRotation_BlockDiag, include/DMRGBlockContainer.hpp:2032-2054). */
 dmrgx_status dmrgx_rdm_eigenvectors(const dmrgx_rdm* rdm, int32_t side, int32_t k, int32_t count, double* dst_dev, int64_t ld, void* stream);
-dmrgx_status dmrgx_rdm_info(const dmrgx_rdm* rdm, int32_t* n_sweeps);
+/* What the solver of this set of density matrices did.  The reference checks "all eigenpairs converged" after every LAPACK call
+ * (include/DMRGBlockContainer.hpp:1987); here a failure would not be a wrong result but a silently slower path, so the path is reported:
+ * DMRGRun.json counts TridFallbacks / TridLaunchPathCalls from it and bench.py refuses a leg that took an unexpected path. */
+typedef struct {
+    int32_t n_sweeps;                   /* block-Jacobi solver: outer sweeps (0 for the direct solver)                                   */
+    int32_t solver;                     /* 0: Householder tridiagonalisation + divide and conquer (csrc/symeig.hip), 1: block Jacobi    */
+    int32_t trid_persistent_matrices;   /* matrices tridiagonalised by the persistent LDS-resident kernel                                */
+    int32_t trid_launch_matrices;       /* ... by one launch per column: by design (order > ~1700) or after a time-out                   */
+    int32_t max_workgroups_per_matrix;  /* persistent kernel: workgroups that shared the rows of one matrix                              */
+    int32_t merge_levels;               /* depth of the divide-and-conquer tree of the largest matrix                                    */
+    int32_t wy_blocks_max;              /* compact-WY blocks (64 reflectors) in the back-transformation of the largest matrix            */
+    int32_t timed_out;                  /* this call's persistent round timed out (1) / was lapped (2) and was repeated by launches      */
+    int32_t process_timeouts;           /* persistent rounds that timed out in this process so far                                       */
+    int32_t persistent_off;             /* the persistent kernel is switched off for the rest of the process (time-out, shared GPU)      */
+} dmrgx_rdm_report;
+dmrgx_status dmrgx_rdm_info(const dmrgx_rdm* rdm, dmrgx_rdm_report* out);
 dmrgx_status dmrgx_rdm_destroy(dmrgx_rdm* rdm);
 
 /* ---- K6: operator rotation + dense-cell accumulate ------------------------------------------------------------ */

@@ -10,7 +10,7 @@ one lattice: a J1-J2 4 x 8 cylinder (the Ly = 8 bond topology of the headline co
 has 256 states and the density matrices of the steps next to it have rank >= m up to m ~ 400.  Every m is EVEN: at the centre step
 system and environment are the same block, the density-matrix spectra of the sectors q and 1 - q are then identical, every eigenvalue
 comes in an exact pair and an odd m would cut one.  Two things differ at this size:
-  * the oracle solves superblocks above 20 000 states matrix-free (oracle/kron.py: KronSumOperator, the same operator as the explicit
+  * the oracle solves superblocks above 3 000 states matrix-free (oracle/kron.py: KronSumOperator, the same operator as the explicit
     matrix, checked in tests/test_oracle_golden.py) -- the explicit sparse matrix of a 10^5-state superblock takes minutes per step;
   * "well-defined cut" is stated in ABSOLUTE terms.  At m ~ 300 the spectrum of a density matrix is dense (relative spacing of
     neighbouring eigenvalues ~ 10 %), so the medium-m rule "relative gap > 1e-2" fails at one cut in ten by chance; what decides
@@ -47,7 +47,7 @@ if __name__ == "__main__":
         c["msweeps"] = [int(x) for x in sys.argv[1].split(",")]
     out_path = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "tests", "golden", "engine_large_m.json")
     H = J1J2XXZModel_SquareLattice(Lx=c["Lx"], Ly=c["Ly"], J1=c["J1"], Jz1=c["Jz1"], J2=c["J2"], Jz2=c["Jz2"])
-    o = DMRGOracle(H, c["mwarmup"], qn_sector=float(c["qn_sector"]), matrix_free_above=20000)
+    o = DMRGOracle(H, c["mwarmup"], qn_sector=float(c["qn_sector"]), matrix_free_above=3000)
     t0 = time.time()
     o.Warmup()
     m_of_step = [c["mwarmup"]] * len(o.steps)

@@ -401,7 +401,9 @@ def _rdm_check(sbm, ls, rs, blocks, psi, tol_orth=1e-13):
             U = rdm.eigenvectors(side, k, n).cpu().numpy()
             assert np.abs(U @ U.T - np.eye(n)).max() < tol_orth, (n, side)
             assert np.abs(U @ rho @ U.T - np.diag(w)).max() < 1e-11 * np.linalg.norm(rho) + 1e-16, (n, side)
+    rep = {k: getattr(rdm.report, k) for k, _ in rdm.report._fields_}      # which solver path ran (dmrgx_rdm_info)
     rdm.destroy()
+    return rep
 
 
 def test_rdm_direct_solver_degenerate_and_boundary_cases(mods):
@@ -438,7 +440,14 @@ def test_rdm_direct_solver_large_orders(mods):
     rng = np.random.default_rng(12)
     for n, r in ((1500, 700), (2200, 300)):
         psi = rng.standard_normal(n * r)
-        _rdm_check(sbm, [n], [r], [(0, 0)], psi / np.linalg.norm(psi), tol_orth=2e-13)
+        rep = _rdm_check(sbm, [n], [r], [(0, 0)], psi / np.linalg.norm(psi), tol_orth=2e-13)
+        # the path is REPORTED (dmrgx_rdm_info): persistent kernel with the rows of one matrix dealt over many workgroups, a deep merge tree and
+        # dozens of WY blocks at 1500; at 2200 the larger matrix goes by launches by design, the smaller one stays persistent; no time-out
+        assert rep["solver"] == 0 and rep["timed_out"] == 0 and rep["persistent_off"] == 0 and rep["merge_levels"] >= 6 and rep["wy_blocks_max"] >= 23, rep
+        if n == 1500:
+            assert rep["trid_persistent_matrices"] == 2 and rep["trid_launch_matrices"] == 0 and rep["max_workgroups_per_matrix"] >= 100, rep
+        else:
+            assert rep["trid_launch_matrices"] == 1 and rep["trid_persistent_matrices"] == 1, rep
 
 
 @pytest.mark.parametrize("env", [dict(DMRGX_TRID="launch"), dict(DMRGX_RDM_SOLVER="jacobi")])
@@ -450,9 +459,14 @@ def test_rdm_alternative_paths_stay_correct(mods, env):
             "from __graft_entry__ import load_package; load_package();"
             "import test_gpu_kron as t; from dmrgx_amd import superblock as sbm;"
             "rng = np.random.default_rng(5); ls, rs = [300, 77], [120, 260]; psi = rng.standard_normal(300 * 120 + 77 * 260);"
-            "t._rdm_check(sbm, ls, rs, [(0, 0), (1, 1)], psi / np.linalg.norm(psi)); print('alt path ok')") % (ROOT, os.path.join(ROOT, "tests"))
+            "rep = t._rdm_check(sbm, ls, rs, [(0, 0), (1, 1)], psi / np.linalg.norm(psi)); print('alt path ok', rep)") % (ROOT, os.path.join(ROOT, "tests"))
     p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "alt path ok" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
+    rep = eval(p.stdout[p.stdout.index("{"):p.stdout.rindex("}") + 1])
+    if "DMRGX_TRID" in env:
+        assert rep["solver"] == 0 and rep["trid_launch_matrices"] == 4 and rep["trid_persistent_matrices"] == 0 and rep["timed_out"] == 0, rep
+    else:
+        assert rep["solver"] == 1 and rep["n_sweeps"] > 0 and rep["trid_launch_matrices"] == 0 and rep["trid_persistent_matrices"] == 0, rep
 
 
 def test_persistent_tridiagonalisation_time_out_falls_back_and_stays_correct(mods):
@@ -465,10 +479,12 @@ def test_persistent_tridiagonalisation_time_out_falls_back_and_stays_correct(mod
             "from __graft_entry__ import load_package; load_package();"
             "import test_gpu_kron as t; from dmrgx_amd import superblock as sbm;"
             "rng = np.random.default_rng(5); ls, rs = [300, 77], [120, 260]; psi = rng.standard_normal(300 * 120 + 77 * 260);"
-            "t._rdm_check(sbm, ls, rs, [(0, 0), (1, 1)], psi / np.linalg.norm(psi)); print('first call ok');"
-            "t._rdm_check(sbm, ls, rs, [(0, 0), (1, 1)], psi / np.linalg.norm(psi)); print('second call ok')") % (ROOT, os.path.join(ROOT, "tests"))
+            "r1 = t._rdm_check(sbm, ls, rs, [(0, 0), (1, 1)], psi / np.linalg.norm(psi)); print('first call ok');"
+            "r2 = t._rdm_check(sbm, ls, rs, [(0, 0), (1, 1)], psi / np.linalg.norm(psi)); print('second call ok');"
+            "assert r1['timed_out'] == 1 and r1['trid_launch_matrices'] == 4 and r1['trid_persistent_matrices'] == 0 and r1['process_timeouts'] == 1 and r1['persistent_off'] == 1, r1;"
+            "assert r2['timed_out'] == 0 and r2['trid_launch_matrices'] == 4 and r2['process_timeouts'] == 1 and r2['persistent_off'] == 1, r2; print('reports ok')") % (ROOT, os.path.join(ROOT, "tests"))
     p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, DMRGX_TRID_FAULT="1"), capture_output=True, text=True, timeout=600)
-    assert p.returncode == 0 and "first call ok" in p.stdout and "second call ok" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
+    assert p.returncode == 0 and "first call ok" in p.stdout and "second call ok" in p.stdout and "reports ok" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
     assert "persistent tridiagonalisation timed out" in p.stderr, p.stderr[-2000:]
 
 
