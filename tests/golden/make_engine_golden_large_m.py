@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
-"""Golden step table at m = 250 ... 400: the sizes at which the engine's density-matrix solver runs its
-PRODUCTION paths inside a sweep -- matrices of order 150-300 dealt over several workgroups of the persistent tridiagonalisation
+"""Golden step table at m = 250 ... 480: the sizes at which the engine's density-matrix solver runs its
+PRODUCTION paths inside a sweep -- matrices of order 140-260 dealt over several workgroups of the persistent tridiagonalisation
 (`trid_coop_kernel`, csrc/symeig.hip), >= 3 divide-and-conquer merge levels, more than one compact-WY block in the back-transformation
--- and superblocks of 10^5 states (thousands of GEMM tiles per MatMult).
+-- and superblocks of 0.5-1.8 x 10^5 states (thousands of GEMM tiles per MatMult).
 
 Same recipe as make_engine_golden_medium_m.py (warm-up at m = 6, m grown by ~1.45 x per sweep, `min_block` = 4: see its docstring),
 one lattice: a J1-J2 4 x 8 cylinder (the Ly = 8 bond topology of the headline configuration), anisotropic couplings, Sz = 1, and
 `min_block` = 8 = Ly: blocks of up to Ly sites are exact (include/DMRGBlockContainer.hpp:786-790), so the block the sweep turns round on
-has 256 states and the density matrices of the steps next to it have rank >= m up to m ~ 400.  Every m is EVEN: at the centre step
+has 256 states and the density matrices of the steps next to it have rank >= m up to m ~ 500 (its enlarged block has 512 states).  Every m is EVEN: at the centre step
 system and environment are the same block, the density-matrix spectra of the sectors q and 1 - q are then identical, every eigenvalue
 comes in an exact pair and an odd m would cut one.  Two things differ at this size:
   * the oracle solves superblocks above 3 000 states matrix-free (oracle/kron.py: KronSumOperator, the same operator as the explicit
@@ -18,14 +18,14 @@ comes in an exact pair and an odd m would cut one.  Two things differ at this si
     dropped eigenvector, eps |rho| / (lk - ld), and its effect on later energies, ~ (that angle)^2 (lk - ld): with eps ~ 1e-15 an
     absolute gap above 1e-12 keeps both far below the 1e-10 the comparison asks for.  Both numbers (lk, ld) of every cut are recorded,
     so the test can state the rule it applies.
-Run time: ~1-2 h on 3 cores (python3 tests/golden/make_engine_golden_large_m.py); writes tests/golden/engine_large_m.json.
+Run time: ~6 minutes on 4 cores (python3 tests/golden/make_engine_golden_large_m.py); writes tests/golden/engine_large_m.json.
 """
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 CASE = dict(Lx=4, Ly=8, J1=1.0, Jz1=0.8, J2=0.5, Jz2=0.3, qn_sector=1, min_block=8, mwarmup=6,
-            msweeps=[8, 12, 18, 26, 38, 56, 82, 120, 174, 252, 366])
+            msweeps=[8, 12, 18, 26, 38, 56, 82, 120, 174, 252, 366, 480])
 KEYS = ("NSites_Sys", "NSites_Env", "NStates_SysEnl", "NStates_EnvEnl", "NumStates_H", "NStates_SysRot", "NStates_EnvRot", "GSEnergy", "TruncErr_Sys", "TruncErr_Env")
 ABS_GAP = 1e-12
 

@@ -1,8 +1,11 @@
 #!/usr/bin/env python3
-"""profiles/traffic.json entry for one workload from a tools/profile.sh output directory (gpurun_out/prof_<tag>): per-launch FETCH_SIZE x 2 +
-WRITE_SIZE of the dominant kernel (the gfx950 correction of MI355X_MICROARCH.md's HBM section, calibrated on the known-byte run of
-tools/ggemm_probe that profile.sh makes), L2 hit rate, MFMA-busy fraction, and the hash of the kernel / plan sources it was measured on
-(bench.py refuses to quote it for other sources).   usage: make_traffic_json.py gpurun_out/prof_r04 cfg4real [summary file name]"""
+"""profiles/traffic.json entry for one workload from a tools/profile.sh output directory (gpurun_out/prof_<tag>): per-launch FETCH_SIZE x c +
+WRITE_SIZE of the dominant kernel, L2 hit rate, MFMA-busy fraction, and the hash of the kernel / plan sources it was measured on (bench.py
+refuses to quote it for other sources).  The factor c: MI355X_MICROARCH.md's HBM section gives x 2 for 16-byte-per-lane streaming reads and
+says "other access widths are uncalibrated: calibrate on a known byte count in your own access pattern" -- this kernel loads 8 bytes per lane
+(global_load_dwordx2, 16 lanes per 128-byte row segment), so c is the ratio known / reported bytes of the known-byte run of the SAME kernel
+that profile.sh makes in the same session (tools/ggemm_probe: 4.29 GB streamed from beyond the Infinity Cache; 1.49 in round 4, 1.89 for the
+round-1 loader).  The x 2 figure is kept beside it for comparison with rounds 1-4 (VERDICT round 4, K1 item d).   usage: make_traffic_json.py gpurun_out/prof_r04 cfg4real [summary file name]"""
 import csv, glob, json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -36,9 +39,11 @@ for f in glob.glob(os.path.join(d, "trace", "**", "*kernel_stats.csv"), recursiv
 commit = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
 entry = {
     "kernel": "dmrgx::" + KERNEL,
-    "bytes_per_launch": (2.0 * fetch + write) * 1024.0,
+    "bytes_per_launch": ((4294967296 / 1024.0 / cf) * fetch + write) * 1024.0,
+    "bytes_per_launch_with_the_x2_of_16B_loads": (2.0 * fetch + write) * 1024.0,
     "fetch_size_kib_per_launch": fetch, "write_size_kib_per_launch": write,
-    "correction": "FETCH_SIZE x2 (gfx950: 128-B requests tallied at 64 B, MI355X_MICROARCH.md HBM section), WRITE_SIZE x1; both in KiB",
+    "correction": "FETCH_SIZE x (known / reported bytes of the same kernel's known-byte run in the same session: 8-byte-per-lane loads are an "
+                  "access width MI355X_MICROARCH.md's HBM section leaves to calibration; its x2 holds for 16-byte-per-lane loads), WRITE_SIZE x1; both in KiB",
     "calibration": {"probe": "tools/ggemm_probe 1024 2048 0 0 3 (same kernel, every group its own operands)", "known_read_bytes": 4294967296,
                     "fetch_size_kib": cf, "ratio_known_over_reported": (4294967296 / 1024.0 / cf) if cf else None,
                     "known_write_bytes": 268435456, "write_size_kib": cw},
