@@ -211,3 +211,40 @@ def test_oracle_correlators_match_exact_diagonalisation():
     for t in ham.H(8):
         bond += t.a * vals[((t.Iop, t.Isite), (t.Jop, t.Jsite))]
     assert abs(bond - e0) <= 1e-12 * abs(e0)
+
+
+def test_matrix_free_superblock_operator_equals_the_explicit_matrix():
+    """oracle/kron.py: KronSumOperator (what the oracle solves superblocks above `matrix_free_above` states with: the golden table of
+    tests/golden/make_engine_golden_large_m.py) against KronSumConstruct_explicit (src/DMRGKron.cpp:1340-1477) on a truncated Ly = 4 J1-J2 run
+    with NNN terms: same matrix-vector product to round-off, same ground state, and the step records of a sweep solved matrix-free equal those
+    of the same sweep solved on the explicit matrix."""
+    import copy
+    import numpy as np
+    from oracle.kron import KronSumOperator, KronSumConstruct_explicit
+    from oracle.dmrg import lowest_eigenpair
+    ham = J1J2XXZModel_SquareLattice(Lx=6, Ly=4, J1=1.0, Jz1=0.8, J2=0.5, Jz2=0.3)
+    orc = DMRGOracle(ham, 6, qn_sector=1.0)          # (the recipe of tests/golden/engine_medium_m.json's j1j2_6x4_sz1: every cut well-defined)
+    orc.Warmup()
+    for m in (8, 12):
+        orc.SingleSweep(m, min_block=4)
+    kb, terms = orc.last["kb"], orc.last["Terms"]
+    He, Hm = KronSumConstruct_explicit(kb, terms), KronSumOperator(kb, terms)
+    rng = np.random.default_rng(3)
+    for _ in range(3):
+        x = rng.standard_normal(kb.NumStates())
+        y = He @ x
+        assert np.abs(Hm.matvec(x) - y).max() <= 1e-14 * np.abs(y).max()
+    H = np.stack([Hm.matvec(e) for e in np.eye(kb.NumStates())], axis=1)
+    assert np.abs(H - H.T).max() <= 1e-14 * np.abs(H).max() and np.abs(H - He.toarray()).max() <= 1e-14 * np.abs(H).max()
+    if kb.NumStates() > 1500:
+        e1, v1 = lowest_eigenpair(He, seed=5)
+        e2, v2 = lowest_eigenpair(Hm, seed=5)
+        assert abs(e1 - e2) <= 1e-12 * abs(e1) and abs(abs(v1 @ v2) - 1.0) <= 1e-10
+    a, b = copy.deepcopy(orc), copy.deepcopy(orc)
+    b.matrix_free_above = 0
+    a.SingleSweep(18, min_block=4); b.SingleSweep(18, min_block=4)
+    n0 = len(orc.steps)
+    for sa, sb_ in zip(a.steps[n0:], b.steps[n0:]):
+        assert sa["NumStates_H"] == sb_["NumStates_H"] and sa["NStates_SysRot"] == sb_["NStates_SysRot"]
+        assert abs(sa["GSEnergy"] - sb_["GSEnergy"]) <= 1e-11 * abs(sa["GSEnergy"])
+        assert abs(sa["TruncErr_Sys"] - sb_["TruncErr_Sys"]) <= 1e-9 * abs(sa["TruncErr_Sys"]) + 1e-14
