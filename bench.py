@@ -126,7 +126,8 @@ def engine_run(opts, timeout=300, ranks=1, rehearsal=False):
                 raise RuntimeError("sweep engine failed: " + (r.stdout + r.stderr)[-1000:])
         else:
             base = dict(os.environ, WORLD_SIZE=str(ranks), HSA_ENABLE_IPC_MODE_LEGACY="0", DMRGX_RDZV_FILE=os.path.join(d, "rdzv"),
-                        DMRGX_SHM_NAME="dmrgx_bench_eng_%d" % os.getpid(), DMRGX_COMM="shm" if rehearsal else "rccl")
+                        DMRGX_SHM_NAME="dmrgx_bench_eng_%d" % os.getpid(), DMRGX_COMM="shm" if rehearsal else "rccl",
+                        DMRGX_LAUNCH_NONCE="bench_%d_%d" % (os.getpid(), time.time_ns()))      # the rendezvous file says which launch it belongs to
             # every rank writes its output to a file of its own: a pipe that nobody drains while rank 0 is awaited blocks its writer
             # after 64 KB, the blocked rank stops taking part in the collectives and the whole job hangs
             logs = [open(os.path.join(d, "rank%d.log" % r), "w") for r in range(ranks)]

@@ -7,7 +7,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdmrgx_hip.so")
+# DMRGX_LIB: another build of the SAME library (tools/ab.sh bench: same-box A/B of saved builds) -- never a different implementation; the
+# product file itself is never overwritten by a tool
+LIB_PATH = os.environ.get("DMRGX_LIB") or os.path.join(_HERE, "libdmrgx_hip.so")
 
 DMRGX_OK = 0
 DMRGX_ERR_ARG = 62

@@ -132,25 +132,33 @@ inline int CommBootstrap()
         int ndev = 0;
         if (dmrgx_device_count(&ndev) == 0 && world > ndev && !getenv("DMRGX_MULTI_NODE")) {
             fprintf(stderr, "[dmrgx] WORLD_SIZE %d exceeds the %d GPU(s) of this node (the rendezvous file is node-local)\n", world, ndev); return 1; }
+        /* The file carries the launch it belongs to: a 64-byte nonce in front of the id -- DMRGX_LAUNCH_NONCE where the launcher exports
+           one (bench.py does), else the per-launch tag above (launcher pid, port, run id, restart count: the same on every rank of one
+           launch, different for the next).  The other ranks wait for a file with THEIR nonce, so the leftover of a run that died before
+           rank 0 removed it is never taken for this launch's, however recent it is and whatever the clocks say (the
+           round-3 guard compared the file's mtime with the local clock). */
+        char nonce[64];
+        memset(nonce, 0, sizeof(nonce));
+        strncpy(nonce, getenv("DMRGX_LAUNCH_NONCE") ? getenv("DMRGX_LAUNCH_NONCE") : tag.c_str(), sizeof(nonce) - 1);
         if (rank == 0) {
             if (dmrgx_comm_unique_id(id)) { fprintf(stderr, "[dmrgx] %s\n", dmrgx_last_error()); return 1; }
             const std::string tmp = path + ".tmp";
             unlink(path.c_str());                                  /* a file left behind by a run that died before its barrier */
             FILE* f = fopen(tmp.c_str(), "wb");
-            if (!f || fwrite(id, 1, sizeof(id), f) != sizeof(id)) { fprintf(stderr, "[dmrgx] cannot write %s\n", tmp.c_str()); return 1; }
+            if (!f || fwrite(nonce, 1, sizeof(nonce), f) != sizeof(nonce) || fwrite(id, 1, sizeof(id), f) != sizeof(id)) { fprintf(stderr, "[dmrgx] cannot write %s\n", tmp.c_str()); return 1; }
             fclose(f);
             if (rename(tmp.c_str(), path.c_str()) != 0) { fprintf(stderr, "[dmrgx] cannot publish %s\n", path.c_str()); return 1; }
         } else {
             const auto t0 = std::chrono::steady_clock::now();
-            /* a file older than this launch is the leftover of a run that died before rank 0 removed it: rank 0 of THIS launch unlinks it
-               before it publishes, but a faster rank could read it first -- only a file written within the two minutes
-               before this process started, or later, is taken */
-            const time_t started = time(nullptr);
             while (true) {
-                struct stat sb;
-                FILE* f = (stat(path.c_str(), &sb) == 0 && sb.st_mtime >= started - 120) ? fopen(path.c_str(), "rb") : nullptr;
-                if (f) { const size_t n = fread(id, 1, sizeof(id), f); fclose(f); if (n == sizeof(id)) break; }
-                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(300)) { fprintf(stderr, "[dmrgx] rank %d: no rendezvous file %s\n", rank, path.c_str()); return 1; }
+                char seen[64];
+                FILE* f = fopen(path.c_str(), "rb");
+                if (f) {
+                    const size_t n1 = fread(seen, 1, sizeof(seen), f), n2 = fread(id, 1, sizeof(id), f);
+                    fclose(f);
+                    if (n1 == sizeof(seen) && n2 == sizeof(id) && memcmp(seen, nonce, sizeof(nonce)) == 0) break;
+                }
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(300)) { fprintf(stderr, "[dmrgx] rank %d: no rendezvous file %s of this launch\n", rank, path.c_str()); return 1; }
                 std::this_thread::sleep_for(std::chrono::milliseconds(10));
             }
         }

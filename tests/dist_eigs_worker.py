@@ -17,7 +17,7 @@ dist.init_process_group("gloo", rank=rank, world_size=world)
 load_package()
 from dmrgx_amd.superblock import KronPlan
 from dmrgx_amd.workloads import synthetic_superblock
-from dmrgx_amd.collectives import _view
+from torch_collective_hooks import _view
 
 torch.cuda.set_device(0)
 dev = torch.device("cuda", 0)

@@ -13,7 +13,7 @@ from __graft_entry__ import load_package
 torch.cuda.set_device(0)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 load_package()
-from dmrgx_amd import collectives
+import torch_collective_hooks as collectives
 
 hooks = collectives.torch_hooks(dist, 0, 1)
 full = torch.arange(4096, dtype=torch.float64, device="cuda")

@@ -19,6 +19,11 @@ for name, tl in lists:
     tl = np.array(tl)
     live = tl[:, 1] >= 0
     s, tl = s[live], tl[live]
+    # stamp 1 ("descriptors read, first operands issued") is only taken when a tile starts cold; a tile whose first operands were fetched
+    # beside the previous tile's epilogue leaves it unset (0 or a value of an earlier launch): those two phases are then zero for it
+    warm = (s[:, 1] < s[:, 0]) | (s[:, 1] > s[:, 2])
+    s = s.copy()
+    s[warm, 1] = s[warm, 0]
     t0 = s[:, 0].min()
     T = (s[:, :6] - t0) * TICK * 1e-3     # us
     dur = T[:, 5] - T[:, 0]
@@ -32,7 +37,7 @@ for name, tl in lists:
     cu = (hw >> 8) & 0xf; sh = (hw >> 12) & 1; se = (hw >> 13) & 7
     cuid = ((xcc * 8 + se) * 2 + sh) * 16 + cu
     print(f"== {name}: {len(s)} tiles, launch span {span:.1f} us; slot-time sum {dur.sum()/1e3:.2f} ms = {dur.sum()/span:.0f} slots busy on average (of 1024)")
-    print(f"   distinct CUs seen {len(np.unique(cuid))}, XCCs {len(np.unique(xcc))}")
+    print(f"   distinct CUs seen {len(np.unique(cuid))}, XCCs {len(np.unique(xcc))}; {int(warm.sum())} tiles started warm (first operands fetched beside the previous epilogue)")
     ph = [("descriptors", T[:, 1] - T[:, 0]), ("first operands -> LDS", T[:, 2] - T[:, 1]), ("k-step stream", T[:, 3] - T[:, 2]),
           ("scaled copies", T[:, 4] - T[:, 3]), ("epilogue stores", T[:, 5] - T[:, 4])]
     for nm, v in ph:
