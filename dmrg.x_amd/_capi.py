@@ -122,6 +122,7 @@ SIGNATURES = {
                                C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
     "dmrgx_rdm_eigenvectors": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
     "dmrgx_rdm_info": (C.c_int32, [C.c_void_p, C.POINTER(RdmReport)]),
+    "dmrgx_rdm_select": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
     "dmrgx_rdm_destroy": (C.c_int32, [C.c_void_p]),
     "dmrgx_cells_axpy": (C.c_int32, [C.c_int32, C.POINTER(AxpyTask), C.c_void_p]),
     "dmrgx_rotate_ops": (C.c_int32, [C.POINTER(Sectors), C.POINTER(Rotation), C.c_int32, C.POINTER(SecOp), C.POINTER(C.POINTER(C.c_void_p)), C.c_void_p]),

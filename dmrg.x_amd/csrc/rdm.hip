@@ -465,7 +465,42 @@ struct dmrgx_rdm {
     int32_t sweeps = 0;
     int32_t solver = 0;                        // 0: tridiagonalisation + divide and conquer (symeig.hip), 1: block Jacobi
     SymEigReport symeig;                       // what the direct solver did (solver == 0)
+    // ---- second phase (dmrgx_rdm_select; direct solver only): the eigenvectors of the kept states are formed once the caller has cut ----
+    SymEigDeferred deferred;                   // pending: the spectra are final, the eigenvectors are not formed yet
+    std::vector<int32_t> have;                 // per matrix: eigenvectors (and Rayleigh quotients) exist for the `have` largest eigenvalues
+    const double* psi = nullptr;               // the state the matrices were built from: must stay alive until the selection
+    std::vector<int64_t> off, diag_off;        // offsets of the KronBlocks in psi; of every matrix in the per-position arrays
+    std::vector<int32_t> nl, nr;               // sector sizes of every KronBlock
+    int64_t psiT_off = 0, w_base = 0, rq_base = 0, ew_base = 0, diag_base = 0, dtot = 0;
+    // the Rayleigh quotients of the selected states travel to the host behind the launches that follow them and are compared with the
+    // solver's own eigenvalues when the object is destroyed (or verified): no synchronisation of their own
+    double* rq_host = nullptr;                 // pinned, from pinned_take
+    size_t rq_cap = 0;
+    std::vector<int32_t> check_cols;
+    hipStream_t check_stream = nullptr;
+    bool check_pending = false;
+    ~dmrgx_rdm();
 };
+
+// Pinned host blocks for those read-backs, recycled per host thread (hipHostMalloc / hipHostFree per truncation would cost more than the
+// synchronisation they replace).
+namespace {
+struct PinnedCache { std::vector<std::pair<double*, size_t>> free; ~PinnedCache() { for (auto& b : free) (void)hipHostFree(b.first); } };
+PinnedCache& pinned_cache() { static thread_local PinnedCache c; return c; }
+double* pinned_take(size_t count, size_t* cap)
+{
+    auto& f = pinned_cache().free;
+    for (size_t i = 0; i < f.size(); ++i) if (f[i].second >= count) { double* p = f[i].first; *cap = f[i].second; f.erase(f.begin() + (std::ptrdiff_t)i); return p; }
+    double* p = nullptr;
+    const size_t n = std::max<size_t>(count + count / 4, 4096);
+    if (hipHostMalloc((void**)&p, n * sizeof(double), hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    *cap = n;
+    return p;
+}
+}  // namespace
+dmrgx_rdm::~dmrgx_rdm() { if (rq_host) pinned_cache().free.push_back({rq_host, rq_cap}); }
+
+static dmrgx_status rdm_rayleigh(dmrgx_rdm* P, const std::vector<int32_t>& cols, bool check_against_direct, hipStream_t st);
 
 static dmrgx_status rdm_create_impl(const dmrgx_sectors* left, const dmrgx_sectors* right, int32_t nblocks,
                                     const int32_t* block_il, const int32_t* block_ir, const double* psi_dev,
@@ -695,7 +730,7 @@ static dmrgx_status rdm_create_impl(const dmrgx_sectors* left, const dmrgx_secto
             const MatDesc& m = P->mats[mi];
             if (m.n > 0) sm.push_back(SymEigMat{m.n, m.npad, m.npad, 0, buf + m.a_off, buf + m.v_off, buf + ew_base + (diag_off[mi] - diag_base)});
         }
-        DMRGX_CHK(symeig_batched(sm, st, &P->symeig));
+        DMRGX_CHK(symeig_batched(sm, st, &P->symeig, &P->deferred));
         stage("symeig");
     }
     bool any_warm = false;
@@ -798,77 +833,121 @@ static dmrgx_status rdm_create_impl(const dmrgx_sectors* left, const dmrgx_secto
         DMRGX_HIP(hipGetLastError());
     }
     stage("jacobi");
-    // ---- eigenvalues as Rayleigh quotients of the renormalised eigenvectors: lambda = |Psi^T u|^2 (rho_L) / |Psi v|^2
-    //      (rho_R).  Relative accuracy ~eps instead of the c*n*eps*||rho|| of the rotated diagonal, which matters for
-    //      TruncErr = 1 - sum of kept eigenvalues (include/DMRGBlockContainer.hpp:1872-1875).
-    std::vector<double> rq((size_t)dtot);
+    // ---- what the second phase needs ------------------------------------------------------------------------------------------
+    P->psi = psi_dev; P->off = off; P->diag_off = diag_off;
+    P->psiT_off = psiT_off; P->w_base = w_base; P->rq_base = rq_base; P->ew_base = ew_base; P->diag_base = diag_base; P->dtot = dtot;
+    for (int32_t k = 0; k < nblocks; ++k) { P->nl.push_back(left->size[block_il[k]]); P->nr.push_back(right->size[block_ir[k]]); }
+    P->eig.resize(nm); P->perm.resize(nm); P->perm_off.resize(nm); P->have.assign((size_t)nm, 0);
+    if (use_dc) {
+        // Direct solver, first phase: the spectra are final (secular equations of the divide and conquer), ascending per matrix; the
+        // eigenvectors are formed by dmrgx_rdm_select for the states the caller keeps (or for all of them at the first request).
+        std::vector<double> ew((size_t)dtot);
+        if (!ew.empty()) DMRGX_HIP(hipMemcpyAsync(ew.data(), buf + ew_base, ew.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+        DMRGX_HIP(hipStreamSynchronize(st));
+        std::vector<int32_t> allperm;
+        for (int mi = 0; mi < nm; ++mi) {
+            const MatDesc& m = P->mats[mi];
+            const double* a = ew.data() + (diag_off[mi] - diag_base);
+            P->eig[mi].resize(m.n); P->perm[mi].resize(m.n);
+            for (int32_t r = 0; r < m.n; ++r) {
+                const double v = a[m.n - 1 - r];
+                if (!(v == v)) DMRGX_FAIL(DMRGX_ERR_NOTCONV, "rdm_create: density matrix %d (n = %d): the direct solver returned NaN", mi, m.n);
+                P->eig[mi][r] = v; P->perm[mi][r] = m.n - 1 - r;      // r-th largest eigenvalue = column n - 1 - r
+            }
+            P->perm_off[mi] = (int64_t)allperm.size();
+            allperm.insert(allperm.end(), P->perm[mi].begin(), P->perm[mi].end());
+        }
+        DMRGX_CHK(upload(P->d_perm, allperm, st));
+        stage("spectra");
+        *out = P.release();
+        return DMRGX_OK;
+    }
+    // ---- block Jacobi: eigenvalues as Rayleigh quotients of the renormalised eigenvectors, all columns ------------------------------
+    {
+        std::vector<int32_t> cols((size_t)nm);
+        for (int mi = 0; mi < nm; ++mi) cols[(size_t)mi] = P->mats[mi].n;
+        DMRGX_CHK(rdm_rayleigh(P.get(), cols, false, st));
+    }
+    stage("rayleigh");
+    *out = P.release();
+    return DMRGX_OK;
+}
+
+// Eigenvalues as Rayleigh quotients of the finished eigenvectors: lambda = |Psi^T u|^2 (rho_L) / |Psi v|^2 (rho_R).  Relative accuracy ~eps
+// instead of the c*n*eps*||rho|| of a rotated diagonal / a secular root, which matters for TruncErr = 1 - sum of kept eigenvalues
+// (include/DMRGBlockContainer.hpp:1872-1875).  cols[mi] columns of matrix mi are evaluated: for the block-Jacobi solver all of them, in
+// whatever order the iteration left them (sorted here); for the direct solver the LAST cols[mi] columns -- the kept states -- whose
+// D&C eigenvalues they replace (and are checked against).
+static dmrgx_status rdm_rayleigh(dmrgx_rdm* P, const std::vector<int32_t>& cols, bool direct, hipStream_t st)
+{
+    const int nm = (int)P->mats.size();
+    const int32_t nblocks = P->nblocks;
+    double* buf = P->buf.as<double>();
+    const int64_t dtot = P->dtot;
+    std::vector<double> rq((size_t)dtot, 0.0);
     {
         std::vector<GProd> prods;
         std::vector<GGroup> groups;
         std::vector<GTile> gt, gb;
         std::vector<ColNormTask> cn;
         for (int32_t k = 0; k < nblocks; ++k) {
-            const int32_t nl = left->size[block_il[k]], nr = right->size[block_ir[k]];
-            const double* Psi = psi_dev + off[k];
-            const double* PsiT = buf + psiT_off + off[k];
+            const int32_t nl = P->nl[(size_t)k], nr = P->nr[(size_t)k];
+            const double* Psi = P->psi + P->off[(size_t)k];
+            const double* PsiT = buf + P->psiT_off + P->off[(size_t)k];
             const MatDesc& mL = P->mats[2 * k];
             const MatDesc& mR = P->mats[2 * k + 1];
-            double* WL = buf + w_base + 2 * off[k];                     // n_R x n_L
-            double* WR = WL + (int64_t)nl * nr;                          // n_L x n_R
-            if (P->selected[2 * k]) {
-                prods.push_back(GProd{PsiT, buf + mL.v_off, nl, mL.npad, nl, GPROD_GEMM, 1.0});
-                groups.push_back(GGroup{WL, nl, nr, nl, (int32_t)prods.size() - 1, (int32_t)prods.size(), 0, 0});
-                ggemm_append_tiles_mixed(gb, gt, (int32_t)groups.size() - 1, nr, nl, (nl + GG_BK - 1) / GG_BK);
-                cn.push_back(ColNormTask{w_base + 2 * off[k], rq_base + (diag_off[2 * k] - diag_base), nr, nl, nl, 0});
+            double* WL = buf + P->w_base + 2 * P->off[(size_t)k];                     // n_R x (columns of V_L)
+            double* WR = WL + (int64_t)nl * nr;                                        // n_L x (columns of V_R)
+            const int32_t cL = P->selected[2 * k] ? cols[(size_t)(2 * k)] : 0, cR = P->selected[2 * k + 1] ? cols[(size_t)(2 * k + 1)] : 0;
+            if (cL > 0) {
+                const int32_t c0 = nl - cL;
+                prods.push_back(GProd{PsiT, buf + mL.v_off + c0, nl, mL.npad, nl, GPROD_GEMM, 1.0});
+                groups.push_back(GGroup{WL, cL, nr, cL, (int32_t)prods.size() - 1, (int32_t)prods.size(), 0, 0});
+                ggemm_append_tiles_mixed(gb, gt, (int32_t)groups.size() - 1, nr, cL, (nl + GG_BK - 1) / GG_BK);
+                cn.push_back(ColNormTask{P->w_base + 2 * P->off[(size_t)k], P->rq_base + (P->diag_off[2 * k] - P->diag_base) + c0, nr, cL, cL, 0});
             }
-            if (P->selected[2 * k + 1]) {
-                prods.push_back(GProd{Psi, buf + mR.v_off, nr, mR.npad, nr, GPROD_GEMM, 1.0});
-                groups.push_back(GGroup{WR, nr, nl, nr, (int32_t)prods.size() - 1, (int32_t)prods.size(), 0, 0});
-                ggemm_append_tiles_mixed(gb, gt, (int32_t)groups.size() - 1, nl, nr, (nr + GG_BK - 1) / GG_BK);
-                cn.push_back(ColNormTask{w_base + 2 * off[k] + (int64_t)nl * nr, rq_base + (diag_off[2 * k + 1] - diag_base), nl, nr, nr, 0});
+            if (cR > 0) {
+                const int32_t c0 = nr - cR;
+                prods.push_back(GProd{Psi, buf + mR.v_off + c0, nr, mR.npad, nr, GPROD_GEMM, 1.0});
+                groups.push_back(GGroup{WR, cR, nl, cR, (int32_t)prods.size() - 1, (int32_t)prods.size(), 0, 0});
+                ggemm_append_tiles_mixed(gb, gt, (int32_t)groups.size() - 1, nl, cR, (nr + GG_BK - 1) / GG_BK);
+                cn.push_back(ColNormTask{P->w_base + 2 * P->off[(size_t)k] + (int64_t)nl * nr, P->rq_base + (P->diag_off[2 * k + 1] - P->diag_base) + c0, nl, cR, cR, 0});
             }
         }
-        if (prods.empty()) prods.push_back(GProd{nullptr, nullptr, 0, 0, 0, GPROD_GEMM, 0.0});
-        if (groups.empty()) groups.push_back(GGroup{nullptr, 0, 0, 0, 0, 0, 0, 0});
+        if (prods.empty()) return DMRGX_OK;                 // (nothing selected on this rank)
         ggemm_schedule(gt, groups); ggemm_schedule(gb, groups, 2);
         DevBuf dtab;
         PackedUpload pk;
         const size_t o_p = pk.add(prods), o_g = pk.add(groups), o_t = pk.add(gt), o_b = pk.add(gb), o_c = pk.add(cn);
         DMRGX_CHK(pk.upload(dtab, st));
-        DMRGX_HIP(zero_async(buf + rq_base, (size_t)dtot * sizeof(double), st));
+        DMRGX_HIP(zero_async(buf + P->rq_base, (size_t)dtot * sizeof(double), st));
         DMRGX_CHK(ggemm_launch(packed_at<GTile>(dtab, o_b), packed_at<GGroup>(dtab, o_g), packed_at<GProd>(dtab, o_p), (int32_t)gb.size(), st, 1));
         DMRGX_CHK(ggemm_launch(packed_at<GTile>(dtab, o_t), packed_at<GGroup>(dtab, o_g), packed_at<GProd>(dtab, o_p), (int32_t)gt.size(), st, 0));
         int maxc = 1;
         for (auto& c : cn) maxc = std::max(maxc, c.ncols);
-        if (!cn.empty()) hipLaunchKernelGGL(colnorm_kernel, dim3((maxc + 63) / 64, (unsigned)cn.size()), dim3(256), 0, st, (const ColNormTask*)packed_at<ColNormTask>(dtab, o_c), buf, buf);
+        hipLaunchKernelGGL(colnorm_kernel, dim3((maxc + 63) / 64, (unsigned)cn.size()), dim3(256), 0, st, (const ColNormTask*)packed_at<ColNormTask>(dtab, o_c), buf, buf);
         DMRGX_HIP(hipGetLastError());
-        if (!rq.empty()) DMRGX_HIP(hipMemcpyAsync(rq.data(), buf + rq_base, rq.size() * sizeof(double), hipMemcpyDeviceToHost, st));
-        std::vector<double> ew(use_dc ? rq.size() : 0);
-        if (!ew.empty()) DMRGX_HIP(hipMemcpyAsync(ew.data(), buf + ew_base, ew.size() * sizeof(double), hipMemcpyDeviceToHost, st));
-        DMRGX_HIP(hipStreamSynchronize(st));
-        // Two independent routes to every eigenvalue: the secular equations of the divide and conquer (ew, ascending, column c of V) and
-        // the Rayleigh quotient of the finished column c (rq, what the caller gets).  They agree to round-off; a failed leaf or secular
-        // solve (NaN, a wrong root) shows here instead of as a wrong truncation further down.
-        for (int mi = 0; mi < nm && !ew.empty(); ++mi) {
-            const MatDesc& m = P->mats[mi];
-            if (m.n <= 0) continue;
-            const double *a = ew.data() + (diag_off[mi] - diag_base), *b = rq.data() + (diag_off[mi] - diag_base);
-            double scale = 0.0, worst = 0.0;
-            bool bad = false;
-            for (int32_t c = 0; c < m.n; ++c) { scale = std::max(scale, std::fabs(a[c])); const double d = std::fabs(a[c] - b[c]); if (!(d <= worst)) worst = d; if (!(d == d)) bad = true; }
-            if (bad || !(worst <= 1e-8 * scale + 1e-300))
-                DMRGX_FAIL(DMRGX_ERR_NOTCONV, "rdm_create: density matrix %d (n = %d): the direct solver's eigenvalues and the Rayleigh quotients of its vectors differ by %.3e (largest eigenvalue %.3e)", mi, m.n, worst, scale);
+        if (direct) {
+            // Direct solver: the spectrum the caller has (and cut on) is the solver's own; the Rayleigh quotients of the finished columns are
+            // the second, independent route to the kept eigenvalues -- compared when the object is destroyed, after the caller's own
+            // synchronisation (dmrgx_rdm_destroy returns DMRGX_ERR_NOTCONV on a mismatch).  Nothing waits here.
+            if (!P->rq_host) P->rq_host = pinned_take((size_t)dtot, &P->rq_cap);
+            if (!P->rq_host) DMRGX_FAIL(DMRGX_ERR_MEM, "rdm_select: no pinned host memory for the verification read-back");
+            DMRGX_HIP(hipMemcpyAsync(P->rq_host, buf + P->rq_base, (size_t)dtot * sizeof(double), hipMemcpyDeviceToHost, st));
+            P->check_cols = cols; P->check_stream = st; P->check_pending = true;
+            for (int mi = 0; mi < nm; ++mi) if (P->selected[mi] && P->mats[mi].n > 0) P->have[(size_t)mi] = cols[(size_t)mi];
+            return DMRGX_OK;
         }
+        DMRGX_HIP(hipMemcpyAsync(rq.data(), buf + P->rq_base, rq.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+        DMRGX_HIP(hipStreamSynchronize(st));
     }
-    stage("rayleigh");
-    // ---- sort descending on the host, remember the column of V for each rank ------------------------------------
-    P->eig.resize(nm); P->perm.resize(nm); P->perm_off.resize(nm);
+    // ---- block Jacobi: sort descending on the host, remember the column of V for each rank ----------------------------------------------
     std::vector<int32_t> allperm;
     for (int mi = 0; mi < nm; ++mi) {
         const MatDesc& m = P->mats[mi];
         // Padding indices (>= n) are decoupled (zero off-diagonals, rotations with a_pq == 0 are skipped), so the real
         // eigenvectors are exactly the columns [0, n) of V and the padding columns stay unit vectors.
-        const double* q = rq.data() + (diag_off[mi] - diag_base);
+        const double* q = rq.data() + (P->diag_off[mi] - P->diag_base);
         std::vector<int32_t> real(m.n);
         std::iota(real.begin(), real.end(), 0);
         std::stable_sort(real.begin(), real.end(), [&](int32_t a, int32_t b) { return q[a] > q[b]; });
@@ -877,11 +956,40 @@ static dmrgx_status rdm_create_impl(const dmrgx_sectors* left, const dmrgx_secto
         for (int32_t r = 0; r < m.n; ++r) P->eig[mi][r] = q[real[r]];
         P->perm_off[mi] = (int64_t)allperm.size();
         allperm.insert(allperm.end(), real.begin(), real.end());
+        P->have[(size_t)mi] = m.n;
     }
     DMRGX_CHK(upload(P->d_perm, allperm, st));
-    stage("sort");
-    *out = P.release();
     return DMRGX_OK;
+}
+
+// counts == NULL: every eigenvector of every matrix
+static dmrgx_status rdm_select_impl(dmrgx_rdm* R, const int32_t* counts, hipStream_t st)
+{
+    if (!R->deferred.pending) return DMRGX_OK;
+    const int nm = (int)R->mats.size();
+    std::vector<int32_t> cols((size_t)nm, 0), keep;
+    for (int mi = 0; mi < nm; ++mi) {
+        const int32_t n = R->mats[mi].n;
+        if (n <= 0) continue;
+        const int32_t c = counts ? counts[mi] : n;
+        if (c < 0 || c > n) DMRGX_FAIL(DMRGX_ERR_ARG, "rdm_select: matrix (block %d, side %d) of order %d cannot keep %d states", mi / 2, mi % 2, n, c);
+        cols[(size_t)mi] = c;
+        keep.push_back(c);                               // (the direct solver saw the matrices of order > 0, in this order)
+    }
+    DMRGX_CHK(symeig_finish(R->deferred, keep, st));
+    return rdm_rayleigh(R, cols, true, st);
+}
+
+extern "C" dmrgx_status dmrgx_rdm_select(dmrgx_rdm* R, const int32_t* counts, void* stream)
+{
+    if (!R) DMRGX_FAIL(DMRGX_ERR_ARG, "rdm_select: bad argument");
+    if (!R->deferred.pending && R->solver == 0 && counts) {
+        // a second selection can only narrow what the first one formed
+        for (size_t mi = 0; mi < R->mats.size(); ++mi)
+            if (R->selected[mi] && R->mats[mi].n > 0 && counts[mi] > R->have[mi])
+                DMRGX_FAIL(DMRGX_ERR_ARG, "rdm_select: the eigenvectors of matrix (block %d, side %d) were formed for %d states, %d asked", (int)mi / 2, (int)mi % 2, R->have[mi], counts[mi]);
+    }
+    return rdm_select_impl(R, counts, (hipStream_t)stream);
 }
 
 extern "C" dmrgx_status dmrgx_rdm_eigenvalues(const dmrgx_rdm* R, int32_t side, int32_t k, double* host_out)
@@ -901,6 +1009,9 @@ extern "C" dmrgx_status dmrgx_rdm_eigenvectors(const dmrgx_rdm* R, int32_t side,
     const MatDesc& m = R->mats[mi];
     if (count > m.n || (count > 0 && (!dst_dev || ld < m.n))) DMRGX_FAIL(DMRGX_ERR_ARG, "rdm_eigenvectors: count %d > n %d or bad destination", count, m.n);
     if (count == 0) return DMRGX_OK;
+    // (a caller that never selected gets every eigenvector, formed at its first request: the one-phase behaviour)
+    if (R->deferred.pending) DMRGX_CHK(rdm_select_impl(const_cast<dmrgx_rdm*>(R), nullptr, (hipStream_t)stream));
+    if (count > R->have[(size_t)mi]) DMRGX_FAIL(DMRGX_ERR_ARG, "rdm_eigenvectors: %d eigenvectors asked of (block %d, side %d), dmrgx_rdm_select formed %d", count, k, side, R->have[(size_t)mi]);
     hipLaunchKernelGGL(gather_vec_kernel, dim3((m.n + 255) / 256, count), dim3(256), 0, (hipStream_t)stream,
                        R->buf.as<double>() + m.v_off, m.npad, m.n, R->d_perm.as<int32_t>() + R->perm_off[mi], count, dst_dev, ld);
     DMRGX_HIP(hipGetLastError());
@@ -923,10 +1034,37 @@ extern "C" dmrgx_status dmrgx_rdm_info(const dmrgx_rdm* R, dmrgx_rdm_report* out
     return DMRGX_OK;
 }
 
+// Two independent routes to every kept eigenvalue: the secular equations of the divide and conquer (what the caller cut on) and the Rayleigh
+// quotient |Psi^T u|^2 of the finished eigenvector.  They agree to round-off; a failed leaf or secular solve (a wrong root) or a broken
+// eigenvector shows here instead of as a wrong truncation further down -- the counterpart of the reference's "all eigenpairs
+// converged" check (include/DMRGBlockContainer.hpp:1987).
+static dmrgx_status rdm_verify(dmrgx_rdm* R)
+{
+    if (!R->check_pending) return DMRGX_OK;
+    R->check_pending = false;
+    DMRGX_HIP(hipStreamSynchronize(R->check_stream));
+    for (size_t mi = 0; mi < R->mats.size(); ++mi) {
+        const MatDesc& m = R->mats[mi];
+        const int32_t c = R->selected[mi] ? R->check_cols[mi] : 0;
+        if (m.n <= 0 || c <= 0) continue;
+        const double* b = R->rq_host + (R->diag_off[mi] - R->diag_base);
+        const double scale = std::fabs(R->eig[mi][0]);
+        double worst = 0.0;
+        bool bad = false;
+        for (int32_t r = 0; r < c; ++r) { const double d = std::fabs(R->eig[mi][r] - b[m.n - 1 - r]); if (!(d <= worst)) worst = d; if (!(d == d)) bad = true; }
+        if (bad || !(worst <= 1e-8 * scale + 1e-300))
+            DMRGX_FAIL(DMRGX_ERR_NOTCONV, "rdm: density matrix (block %d, side %d, n = %d): the direct solver's eigenvalues and the Rayleigh quotients of its vectors differ by %.3e (largest eigenvalue %.3e)",
+                       (int)mi / 2, (int)mi % 2, m.n, worst, scale);
+    }
+    return DMRGX_OK;
+}
+
 extern "C" dmrgx_status dmrgx_rdm_destroy(dmrgx_rdm* R)
 {
     if (!R) return DMRGX_OK;
-    // no synchronisation: the blocks go back to the pool and are recycled in stream order (pool.hip)
+    // The verification of the selected eigenpairs is read here (it waits for the stream they were computed on, which a caller that has used the
+    // eigenvectors has long synchronised); otherwise no synchronisation: the blocks go back to the pool and are recycled in stream order (pool.hip)
+    const dmrgx_status rc = rdm_verify(R);
     delete R;
-    return DMRGX_OK;
+    return rc;
 }

@@ -38,7 +38,19 @@ struct SymEigReport {
     int32_t wy_blocks_max = 0;           // compact-WY blocks of the back-transformation of the largest matrix
     int32_t timed_out = 0;               // this call's persistent round ran into its bounded spin (1) or was lapped (2) and was repeated by launches
 };
-dmrgx_status symeig_batched(const std::vector<SymEigMat>& mats, hipStream_t st, SymEigReport* report = nullptr);
+// Two-phase use (round 5): a truncation keeps about half of the eigenvectors, and which ones is only known once every spectrum has been seen
+// on the host.  With `deferred` the call stops behind the last level's secular equations -- the eigenvalues w are final, the eigenvectors are
+// not formed: the last merge's GEMM and the whole back-transformation are left to symeig_finish, which runs them for the `keep[i]` LARGEST
+// eigenvalues of matrix i only (the last keep[i] columns of X; the other columns of X are then undefined).  The object owns the workspace
+// in between and must be finished (or dropped) on the same stream.
+struct SymEigDeferred {
+    struct Mat { SymEigMat m; int64_t VT, Vc, TV, Q1, U, W; int32_t nblk, depth; };
+    std::vector<Mat> mats;               // the matrices of order > 0, in the order of the call
+    DevBuf dbuf, ibuf;                   // workspace of the call
+    bool pending = false;
+};
+dmrgx_status symeig_batched(const std::vector<SymEigMat>& mats, hipStream_t st, SymEigReport* report = nullptr, SymEigDeferred* deferred = nullptr);
+dmrgx_status symeig_finish(SymEigDeferred& d, const std::vector<int32_t>& keep, hipStream_t st);
 
 // The tridiagonalisation normally runs as ONE persistent launch with the matrices resident in the LDS of most CUs of the
 // chip; processes that share a GPU with other ranks (the host-staged rehearsal communicator) switch it off and use one launch per

@@ -1042,7 +1042,7 @@ void symeig_process_state(int32_t* timeouts, int32_t* persistent_off)
     if (persistent_off) *persistent_off = g_coop_disabled ? 1 : 0;
 }
 
-dmrgx_status symeig_batched(const std::vector<SymEigMat>& mats_in, hipStream_t st, SymEigReport* report)
+dmrgx_status symeig_batched(const std::vector<SymEigMat>& mats_in, hipStream_t st, SymEigReport* report, SymEigDeferred* deferred)
 {
     SymEigReport rep_local;
     SymEigReport& rep = report ? *report : rep_local;
@@ -1306,6 +1306,7 @@ dmrgx_status symeig_batched(const std::vector<SymEigMat>& mats_in, hipStream_t s
                 const int lo = pb[u], mid = cb[2 * u + 1], hi = pb[u + 1];
                 merges.push_back(DcMerge{i, lo, mid, hi, src, 0});
                 s.nlmax = std::max(s.nlmax, hi - lo);
+                if (deferred && lev == 0) continue;                 // the root's GEMM: symeig_finish, for the kept columns only
                 double* Qd = dm[i].Q[dst]; const int ldd = dm[i].ldq[dst];
                 const double* Qs = dm[i].Q[src]; const int lds_ = dm[i].ldq[src];
                 const double* U = dm[i].U; const int ldu = dm[i].ldu;
@@ -1319,7 +1320,7 @@ dmrgx_status symeig_batched(const std::vector<SymEigMat>& mats_in, hipStream_t s
 
     // ---- 3b. back-transformation steps (last block first), aligned at the end of every matrix's block list ------------------------
     std::vector<GemmSet> bt_w((size_t)max_nblk), bt_x((size_t)max_nblk);
-    for (int s = 0; s < max_nblk; ++s) {
+    for (int s = 0; s < max_nblk && !deferred; ++s) {
         std::vector<GTile> wb, wsm, xb, xs;
         for (int i = 0; i < nm; ++i) {
             const Ws& w = ws[i];
@@ -1443,13 +1444,102 @@ dmrgx_status symeig_batched(const std::vector<SymEigMat>& mats_in, hipStream_t s
 
     // ---- 3b: launches ------------------------------------------------------------------------------------------------------------
     if (any_blk) DMRGX_HIP(hipStreamWaitEvent(st, ev_join, 0));
-    for (int s = 0; s < max_nblk; ++s) { DMRGX_CHK(run_set(bt_w[(size_t)s])); DMRGX_CHK(run_set(bt_x[(size_t)s])); }
+    for (int s = 0; s < max_nblk && !deferred; ++s) { DMRGX_CHK(run_set(bt_w[(size_t)s])); DMRGX_CHK(run_set(bt_x[(size_t)s])); }
+    if (deferred) {
+        // everything symeig_finish needs: the matrices, where their factors sit in the workspace, and the workspace itself
+        deferred->mats.clear();
+        for (int i = 0; i < nm; ++i) deferred->mats.push_back(SymEigDeferred::Mat{M[i], ws[i].VT, ws[i].Vc, ws[i].TV, ws[i].Q1, ws[i].U, ws[i].W, ws[i].nblk, depth[i]});
+        deferred->dbuf.release(); deferred->ibuf.release();
+        std::swap(deferred->dbuf.p, dbuf.p); std::swap(deferred->dbuf.bytes, dbuf.bytes);
+        std::swap(deferred->ibuf.p, ibuf.p); std::swap(deferred->ibuf.bytes, ibuf.bytes);
+        deferred->pending = true;
+    }
     hmark("all queued");
     if (host_trace) {
         fprintf(stderr, "[symeig host] %d matrices, nmax %d:", nm, nmax);
         for (const auto& hm : hmarks) fprintf(stderr, "  %s %.0f us", hm.first, hm.second);
         fprintf(stderr, "\n");
     }
+    return DMRGX_OK;
+}
+
+// Second phase of a deferred call: the root merge's GEMM X[:, kept] = blockdiag(Q_a, Q_b) U[:, kept] and the blocked back-transformation
+// X[:, kept] <- H_0 ... H_{n-3} X[:, kept], for the keep[i] largest eigenvalues (the last columns) of every matrix -- half of the flops of
+// both, and GEMM launches half as wide, when a truncation keeps half of the states.
+dmrgx_status symeig_finish(SymEigDeferred& d, const std::vector<int32_t>& keep, hipStream_t st)
+{
+    if (!d.pending) return DMRGX_OK;
+    const int nm = (int)d.mats.size();
+    if ((int)keep.size() != nm) DMRGX_FAIL(DMRGX_ERR_ARG, "symeig_finish: %d counts for %d matrices", (int)keep.size(), nm);
+    double* B = d.dbuf.as<double>();
+    std::vector<GProd> prods;
+    std::vector<GGroup> groups;
+    std::vector<GTile> tiles;
+    auto add_set = [&](std::vector<GTile>& big, std::vector<GTile>& small) {
+        GemmSet s;
+        ggemm_schedule(big, groups, 2); ggemm_schedule(small, groups);
+        s.big_off = tiles.size(); s.nbig = (int32_t)big.size(); tiles.insert(tiles.end(), big.begin(), big.end());
+        s.small_off = tiles.size(); s.nsmall = (int32_t)small.size(); tiles.insert(tiles.end(), small.begin(), small.end());
+        return s;
+    };
+    auto add_gemm = [&](std::vector<GTile>& big, std::vector<GTile>& small, double* C, int ldc, int Mr, int Nc, const double* A, int lda, const double* Bm, int ldb, int K, int accumulate) {
+        if (Mr <= 0 || Nc <= 0 || K <= 0) return;
+        prods.push_back(GProd{A, Bm, lda, ldb, K, GPROD_GEMM, 1.0});
+        groups.push_back(GGroup{C, ldc, Mr, Nc, (int32_t)prods.size() - 1, (int32_t)prods.size(), 0, accumulate});
+        ggemm_append_tiles_mixed(big, small, (int32_t)groups.size() - 1, Mr, Nc, (K + GG_BK - 1) / GG_BK);
+    };
+    int max_nblk = 0;
+    GemmSet root;
+    {
+        std::vector<GTile> gb, gs;
+        for (int i = 0; i < nm; ++i) {
+            const SymEigDeferred::Mat& q = d.mats[(size_t)i];
+            const int n = q.m.n, c = keep[(size_t)i];
+            if (c < 0 || c > n) DMRGX_FAIL(DMRGX_ERR_ARG, "symeig_finish: matrix %d of order %d cannot keep %d eigenvectors", i, n, c);
+            if (c > 0) max_nblk = std::max(max_nblk, q.nblk);
+            if (q.depth < 1 || c == 0) continue;                  // (a single leaf: its eigenvectors are complete)
+            const int mid = tree_bounds(n, 1)[1], c0 = n - c;
+            double* X = q.m.X; const int ldx = q.m.ldx;
+            const double* Qs = B + q.Q1; const double* U = B + q.U;        // the root's children live in Q[1] (ld n), its merge matrix in U (ld n)
+            add_gemm(gb, gs, X + c0, ldx, mid, c, Qs, n, U + c0, n, mid, 0);
+            add_gemm(gb, gs, X + (int64_t)mid * ldx + c0, ldx, n - mid, c, Qs + (int64_t)mid * n + mid, n, U + (int64_t)mid * n + c0, n, n - mid, 0);
+        }
+        root = add_set(gb, gs);
+    }
+    std::vector<GemmSet> bt_w((size_t)max_nblk), bt_x((size_t)max_nblk);
+    for (int s = 0; s < max_nblk; ++s) {
+        std::vector<GTile> wb, wsm, xb, xs;
+        for (int i = 0; i < nm; ++i) {
+            const SymEigDeferred::Mat& q = d.mats[(size_t)i];
+            const int b = q.nblk - 1 - s, n = q.m.n, c = keep[(size_t)i];
+            if (b < 0 || c == 0) continue;
+            const int b0 = b * WY_NB, kb = std::min(WY_NB, n - 2 - b0), r0 = b0 + 1, c0 = n - c;
+            double* X = q.m.X; const int ldx = q.m.ldx;
+            add_gemm(wb, wsm, B + q.W, n, kb, c, B + q.TV + (int64_t)b0 * n + r0, n, X + (int64_t)r0 * ldx + c0, ldx, n - r0, 0);      // W = -(T V^T) X[:, kept]
+            add_gemm(xb, xs, X + (int64_t)r0 * ldx + c0, ldx, n - r0, c, B + q.Vc + (int64_t)r0 * n + b0, n, B + q.W, n, kb, 1);       // X[:, kept] += V W
+        }
+        bt_w[(size_t)s] = add_set(wb, wsm);
+        bt_x[(size_t)s] = add_set(xb, xs);
+    }
+    if (!tiles.empty()) {
+        DevBuf d_tab;
+        PackedUpload pk;
+        const size_t o_prods = pk.add(prods), o_groups = pk.add(groups), o_tiles = pk.add(tiles);
+        DMRGX_CHK(pk.upload(d_tab, st));
+        const GProd* d_prods = packed_at<GProd>(d_tab, o_prods);
+        const GGroup* d_groups = packed_at<GGroup>(d_tab, o_groups);
+        const GTile* d_tiles = packed_at<GTile>(d_tab, o_tiles);
+        auto run_set = [&](const GemmSet& s) -> dmrgx_status {
+            DMRGX_CHK(ggemm_launch(d_tiles + s.big_off, d_groups, d_prods, s.nbig, st, 1));
+            DMRGX_CHK(ggemm_launch(d_tiles + s.small_off, d_groups, d_prods, s.nsmall, st, 0));
+            return DMRGX_OK;
+        };
+        DMRGX_CHK(run_set(root));
+        for (int s = 0; s < max_nblk; ++s) { DMRGX_CHK(run_set(bt_w[(size_t)s])); DMRGX_CHK(run_set(bt_x[(size_t)s])); }
+    }
+    // (the tables and the workspace go back to the stream-ordered pool: later users are ordered behind the launches above)
+    d.dbuf.release(); d.ibuf.release();
+    d.pending = false;
     return DMRGX_OK;
 }
 

@@ -1431,6 +1431,10 @@ public:
                                              LLD(nb), LLD(nwarm), rr.n_sweeps, rr.trid_persistent_matrices, rr.trid_launch_matrices, rr.max_workgroups_per_matrix, rr.merge_levels, tr1 - tr0);
         }
         BasisTransformation* BT[2] = {&BT_L, &BT_R};
+        /* Two phases (round 5): first the m-cut of both sides on the spectra alone, then -- dmrgx_rdm_select -- the eigenvectors of the kept
+           states only (the solver's last merge, back-transformation and Rayleigh quotients run on half-width matrices when half of the
+           states are kept), then the rotations. */
+        std::map<PetscInt, std::pair<PetscInt, PetscInt>> per_side[2];       /* blkIdx -> (KronBlock, count) */
         for (int side = 0; side < 2; ++side) {
             std::vector<Eigen_t> eigen;
             eigen.reserve((size_t)(spec_off[(size_t)(2 * nb)] / 2 + 1));
@@ -1467,8 +1471,16 @@ public:
             for (const Eigen_t& e : eigen) trunc -= (e.eigval > 0) * e.eigval;
             BT[side]->TruncErr = trunc;
             /* kept states per sector are the top ones of that sector's spectrum, in decreasing order */
-            std::map<PetscInt, std::pair<PetscInt, PetscInt>> per;       /* blkIdx -> (KronBlock, count) */
+            std::map<PetscInt, std::pair<PetscInt, PetscInt>>& per = per_side[side];
             for (const Eigen_t& e : eigen) { auto& p = per[e.blkIdx]; p.first = e.seqIdx; p.second += 1; }
+        }
+        {
+            std::vector<int32_t> counts((size_t)(2 * nb), 0);
+            for (int side = 0; side < 2; ++side) for (const auto& kv : per_side[side]) counts[(size_t)(2 * kv.second.first + side)] = (int32_t)kv.second.second;
+            if (dmrgx_rdm_select(rdm, counts.data(), nullptr)) { dmrgx_rdm_destroy(rdm); SETERRQ1(mpi_comm, 1, "dmrgx_rdm_select: %s", dmrgx_last_error()); }
+        }
+        for (int side = 0; side < 2; ++side) {
+            const std::map<PetscInt, std::pair<PetscInt, PetscInt>>& per = per_side[side];
             auto rot = std::make_shared<dmrgx_host::BasisRotation>();
             rot->old_sizes = M[side]->Sizes32();
             std::vector<PetscReal> qn_list; std::vector<PetscInt> qn_size;
@@ -1518,7 +1530,8 @@ public:
             ierr = BT[side]->QN.Initialize(mpi_comm, qn_list, qn_size); CHKERRQ(ierr);
         }
         dmrgx_stream_sync(nullptr);
-        dmrgx_rdm_destroy(rdm);
+        /* (the solver's verification of the kept eigenpairs -- its eigenvalues against the Rayleigh quotients of the finished vectors -- is read here) */
+        if (dmrgx_rdm_destroy(rdm)) SETERRQ1(mpi_comm, 1, "dmrgx_rdm_destroy: %s", dmrgx_last_error());
         return 0;
     }
 

@@ -210,6 +210,11 @@ class ReducedDensityMatrices:
         _capi.check(_capi.lib().dmrgx_rdm_eigenvalues(self._handle, side, k, out))
         return np.array(out)
 
+    def select(self, counts):
+        """Second phase (dmrgx_rdm_select): form the eigenvectors of the counts[2*k + side] largest eigenvalues of every density matrix only."""
+        arr = (C.c_int32 * (2 * len(self.blocks)))(*[int(c) for c in counts])
+        _capi.check(_capi.lib().dmrgx_rdm_select(self._handle, arr, None))
+
     def eigenvectors(self, side, k, count):
         n = self.size(side, k)
         dst = torch.empty((count, n), dtype=torch.float64, device="cuda")
@@ -219,8 +224,8 @@ class ReducedDensityMatrices:
 
     def destroy(self):
         if self._handle:
-            _capi.check(_capi.lib().dmrgx_rdm_destroy(self._handle))
-            self._handle = C.c_void_p()
+            h, self._handle = self._handle, C.c_void_p()      # (the object is gone whatever the verdict of its verification)
+            _capi.check(_capi.lib().dmrgx_rdm_destroy(h))
 
     def __del__(self):
         try:

@@ -285,6 +285,17 @@ dmrgx_status dmrgx_rdm_eigenvalues(const dmrgx_rdm* rdm, int32_t side, int32_t k
 /* dst_dev[r*ld + i], r < count: the eigenvector of the r-th largest eigenvalue as a ROW (a row of RotMatT,
  * == FillRotation_BlockDiag, include/DMRGBlockContainer.hpp:2032-2054). */
 dmrgx_status dmrgx_rdm_eigenvectors(const dmrgx_rdm* rdm, int32_t side, int32_t k, int32_t count, double* dst_dev, int64_t ld, void* stream);
+/* Optional second phase between the spectra and the eigenvectors.  dmrgx_rdm_create* returns with every spectrum final but -- with the direct
+ * solver -- no eigenvector formed: the m-cut of GetTruncation (include/DMRGBlockContainer.hpp:1795-1875) is taken on the spectra, and only
+ * then are the eigenvectors of the KEPT states computed: counts[2*k + side] = number of (largest) eigenvalues of that density matrix whose
+ * eigenvectors are wanted (entries of matrices this rank did not build are ignored).  The last merge of the divide and conquer, the
+ * back-transformation and the verification then run on half-width matrices when half of the states are kept.  The spectra do not change
+ * (dmrgx_rdm_eigenvalues: the solver's own eigenvalues, descending); dmrgx_rdm_eigenvectors serves count <= counts[..].  A caller that never
+ * selects gets every eigenvector at its first dmrgx_rdm_eigenvectors call.  `psi_dev` of the create call must stay unchanged until then.
+ * Verification: every selected eigenvalue is computed a second time as the Rayleigh quotient |Psi^T u|^2 of its finished eigenvector; the two
+ * are compared when the object is destroyed -- dmrgx_rdm_destroy returns DMRGX_ERR_NOTCONV if they disagree (the counterpart of the
+ * reference's "all eigenpairs converged" check, include/DMRGBlockContainer.hpp:1987) -- so the comparison costs no synchronisation. */
+dmrgx_status dmrgx_rdm_select(dmrgx_rdm* rdm, const int32_t* counts, void* stream);
 /* What the solver of this set of density matrices did.  The reference checks "all eigenpairs converged" after every LAPACK call
  * (include/DMRGBlockContainer.hpp:1987); here a failure would not be a wrong result but a silently slower path, so the path is reported:
  * DMRGRun.json counts TridFallbacks / TridLaunchPathCalls from it and bench.py refuses a leg that took an unexpected path. */

@@ -450,6 +450,44 @@ def test_rdm_direct_solver_large_orders(mods):
             assert rep["trid_launch_matrices"] == 1 and rep["trid_persistent_matrices"] == 1, rep
 
 
+def test_rdm_select_forms_only_the_kept_eigenvectors(mods):
+    """Two-phase truncation (dmrgx_rdm_select, round 5): the spectra come first, the cut is taken on them, and only the eigenvectors of the
+    kept states are formed -- the last divide-and-conquer merge, the back-transformation and the Rayleigh quotients on half-width matrices.
+    Against LAPACK: the spectrum before and after the selection (the solver's own eigenvalues, unchanged), the kept eigenpairs after it
+    (orthonormal rows that diagonalise rho on the kept subspace), every kept count from 0 to n incl. orders below one leaf and a
+    matrix nothing is kept of; asking for more than was selected is refused."""
+    sbm, _, capi = mods
+    rng = np.random.default_rng(21)
+    ls, rs = [300, 77, 12, 150], [120, 260, 40, 150]
+    blocks = [(i, i) for i in range(4)]
+    psi = rng.standard_normal(sum(a * b for a, b in zip(ls, rs)))
+    psi /= np.linalg.norm(psi)
+    rdm = sbm.ReducedDensityMatrices(ls, rs, blocks, torch.from_numpy(psi).cuda())
+    rhos, off = [], 0
+    for a, b in zip(ls, rs):
+        Psi = psi[off:off + a * b].reshape(a, b); off += a * b
+        rhos += [Psi @ Psi.T, Psi.T @ Psi]
+    w_ref = [np.linalg.eigvalsh(r)[::-1] for r in rhos]
+    for mi, r in enumerate(rhos):
+        w = rdm.eigenvalues(mi % 2, mi // 2)
+        assert np.abs(w - w_ref[mi]).max() <= 3e-15 * r.shape[0] * w_ref[mi][0] + 1e-17
+    counts = [150, 60, 77, 0, 5, 40, 1, 150]                  # half, a part, all, nothing, below a leaf, all of a small one, one, all
+    rdm.select(counts)
+    for mi, r in enumerate(rhos):
+        n, c = r.shape[0], counts[mi]
+        w = rdm.eigenvalues(mi % 2, mi // 2)
+        assert np.abs(w - w_ref[mi]).max() <= 3e-15 * n * w_ref[mi][0] + 1e-17 and np.all(np.diff(w) <= 0)
+        if c:
+            U = rdm.eigenvectors(mi % 2, mi // 2, c).cpu().numpy()
+            assert np.abs(U @ U.T - np.eye(c)).max() < 1e-13
+            assert np.abs(U @ r @ U.T - np.diag(w[:c])).max() < 1e-11 * np.linalg.norm(r) + 1e-16
+            assert np.abs(r @ U.T - U.T * w[:c]).max() < 1e-11 * np.linalg.norm(r) + 1e-16          # eigenvectors of rho, not only of its restriction
+        if c < n:
+            with pytest.raises(capi.DmrgxError):
+                rdm.eigenvectors(mi % 2, mi // 2, c + 1)
+    rdm.destroy()                                              # (returns the verdict of the Rayleigh-quotient verification: raises on a mismatch)
+
+
 @pytest.mark.parametrize("env", [dict(DMRGX_TRID="launch"), dict(DMRGX_RDM_SOLVER="jacobi")])
 def test_rdm_alternative_paths_stay_correct(mods, env):
     """The launch-per-column tridiagonalisation (the fallback of the persistent kernel) and the round-2 block-Jacobi solver are chosen
