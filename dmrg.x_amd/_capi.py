@@ -57,6 +57,10 @@ class RdmReport(C.Structure):
                                          "merge_levels", "wy_blocks_max", "timed_out", "process_timeouts", "persistent_off")]
 
 
+class RdmVecTask(C.Structure):
+    _fields_ = [("side", C.c_int32), ("k", C.c_int32), ("count", C.c_int32), ("pad", C.c_int32), ("dst_dev", C.c_void_p), ("ld", C.c_int64)]
+
+
 class KronInfo(C.Structure):
     _fields_ = [("n_states", C.c_int64), ("vec_len", C.c_int64), ("local_offset", C.c_int64), ("local_len", C.c_int64),
                 ("seg_stride", C.c_int64), ("flops_alg", C.c_double), ("bytes_alg", C.c_double), ("flops_exec", C.c_double),
@@ -123,6 +127,7 @@ SIGNATURES = {
     "dmrgx_rdm_eigenvectors": (C.c_int32, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
     "dmrgx_rdm_info": (C.c_int32, [C.c_void_p, C.POINTER(RdmReport)]),
     "dmrgx_rdm_select": (C.c_int32, [C.c_void_p, C.POINTER(C.c_int32), C.c_void_p]),
+    "dmrgx_rdm_eigenvectors_batch": (C.c_int32, [C.c_void_p, C.c_int32, C.POINTER(RdmVecTask), C.c_void_p]),
     "dmrgx_rdm_destroy": (C.c_int32, [C.c_void_p]),
     "dmrgx_cells_axpy": (C.c_int32, [C.c_int32, C.POINTER(AxpyTask), C.c_void_p]),
     "dmrgx_rotate_ops": (C.c_int32, [C.POINTER(Sectors), C.POINTER(Rotation), C.c_int32, C.POINTER(SecOp), C.POINTER(C.POINTER(C.c_void_p)), C.c_void_p]),

@@ -448,6 +448,19 @@ __global__ void gather_vec_kernel(const double* __restrict__ V, int npad, int n,
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dst[(int64_t)r * ld + i] = V[(int64_t)i * npad + col];
 }
 
+// the same for up to GATHER_MAX (matrix, destination) pairs in one launch; the descriptors travel in the kernel-argument segment
+constexpr int GATHER_MAX = 48;
+struct GatherOne { const double* V; const int32_t* perm; double* dst; int64_t ld; int32_t npad, n, count, pad; };
+struct GatherArgs { GatherOne t[GATHER_MAX]; };
+__global__ void gather_vec_batch_kernel(const GatherArgs a)
+{
+    const GatherOne g = a.t[blockIdx.z];
+    for (int r = blockIdx.y; r < g.count; r += gridDim.y) {
+        const int col = g.perm[r];
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < g.n; i += gridDim.x * blockDim.x) g.dst[(int64_t)r * g.ld + i] = g.V[(int64_t)i * g.npad + col];
+    }
+}
+
 }  // namespace
 }  // namespace dmrgx
 
@@ -1015,6 +1028,38 @@ extern "C" dmrgx_status dmrgx_rdm_eigenvectors(const dmrgx_rdm* R, int32_t side,
     hipLaunchKernelGGL(gather_vec_kernel, dim3((m.n + 255) / 256, count), dim3(256), 0, (hipStream_t)stream,
                        R->buf.as<double>() + m.v_off, m.npad, m.n, R->d_perm.as<int32_t>() + R->perm_off[mi], count, dst_dev, ld);
     DMRGX_HIP(hipGetLastError());
+    return DMRGX_OK;
+}
+
+extern "C" dmrgx_status dmrgx_rdm_eigenvectors_batch(const dmrgx_rdm* R, int32_t ntasks, const dmrgx_rdm_vec_task* tasks, void* stream)
+{
+    if (!R || ntasks < 0 || (ntasks > 0 && !tasks)) DMRGX_FAIL(DMRGX_ERR_ARG, "rdm_eigenvectors_batch: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    for (int32_t t = 0; t < ntasks; ++t) {
+        const dmrgx_rdm_vec_task& q = tasks[t];
+        if (q.side < 0 || q.side > 1 || q.k < 0 || q.k >= R->nblocks || q.count < 0) DMRGX_FAIL(DMRGX_ERR_ARG, "rdm_eigenvectors_batch: task %d: bad argument", t);
+        const int mi = 2 * q.k + q.side;
+        if (!R->selected[mi]) DMRGX_FAIL(DMRGX_ERR_ARG, "rdm_eigenvectors_batch: the density matrix (block %d, side %d) was left to another rank", q.k, q.side);
+        const MatDesc& m = R->mats[mi];
+        if (q.count > m.n || (q.count > 0 && (!q.dst_dev || q.ld < m.n))) DMRGX_FAIL(DMRGX_ERR_ARG, "rdm_eigenvectors_batch: task %d: count %d > n %d or bad destination", t, q.count, m.n);
+    }
+    if (R->deferred.pending) DMRGX_CHK(rdm_select_impl(const_cast<dmrgx_rdm*>(R), nullptr, st));
+    for (int32_t t0 = 0; t0 < ntasks; t0 += GATHER_MAX) {
+        GatherArgs a;
+        int na = 0, nmax = 1, cmax = 1;
+        for (int32_t t = t0; t < std::min(ntasks, t0 + GATHER_MAX); ++t) {
+            const dmrgx_rdm_vec_task& q = tasks[t];
+            const int mi = 2 * q.k + q.side;
+            const MatDesc& m = R->mats[mi];
+            if (q.count == 0) continue;
+            if (q.count > R->have[(size_t)mi]) DMRGX_FAIL(DMRGX_ERR_ARG, "rdm_eigenvectors_batch: %d eigenvectors asked of (block %d, side %d), dmrgx_rdm_select formed %d", q.count, q.k, q.side, R->have[(size_t)mi]);
+            a.t[na++] = GatherOne{R->buf.as<double>() + m.v_off, R->d_perm.as<int32_t>() + R->perm_off[mi], q.dst_dev, q.ld, m.npad, m.n, q.count, 0};
+            nmax = std::max(nmax, m.n); cmax = std::max(cmax, q.count);
+        }
+        if (na == 0) continue;
+        hipLaunchKernelGGL(gather_vec_batch_kernel, dim3((unsigned)((nmax + 255) / 256), (unsigned)std::min(cmax, 4096), (unsigned)na), dim3(256), 0, st, a);
+        DMRGX_HIP(hipGetLastError());
+    }
     return DMRGX_OK;
 }
 

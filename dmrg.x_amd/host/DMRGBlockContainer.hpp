@@ -1498,6 +1498,7 @@ public:
             std::vector<std::shared_ptr<dmrgx_host::DevBuffer>> staging((size_t)W);
             if (W > 1) for (int w = 0; w < W; ++w) if (stage_len[(size_t)w] > 0) staging[(size_t)w] = std::make_shared<dmrgx_host::DevBuffer>((size_t)stage_len[(size_t)w], dmrgx_host::DevBuffer::device_only_t{});
             size_t si = 0;
+            std::vector<dmrgx_rdm_vec_task> vec_tasks;
             for (const auto& kv : per) {
                 const PetscInt blk = kv.first, k = kv.second.first, cnt = kv.second.second, n = M[side]->Sizes(blk);
                 rot->old_sector.push_back((int32_t)blk); rot->kept.push_back((int32_t)cnt);
@@ -1506,10 +1507,12 @@ public:
                 if (own < 0) { rot->rt.push_back(nullptr); qn_list.push_back(M[side]->List(blk)); qn_size.push_back(cnt); continue; }   /* spectrum only */
                 auto buf = std::make_shared<dmrgx_host::DevBuffer>((size_t)cnt * n, dmrgx_host::DevBuffer::device_only_t{});
                 double* dst = W > 1 ? staging[(size_t)own]->dev_uninitialised() + soff : buf->dev_uninitialised();
-                if (own == me && dmrgx_rdm_eigenvectors(rdm, side, (int32_t)k, (int32_t)cnt, dst, n, nullptr)) { dmrgx_rdm_destroy(rdm); SETERRQ1(mpi_comm, 1, "dmrgx_rdm_eigenvectors: %s", dmrgx_last_error()); }
+                if (own == me) vec_tasks.push_back(dmrgx_rdm_vec_task{side, (int32_t)k, (int32_t)cnt, 0, dst, (int64_t)n});
                 rot->rt.push_back(buf);
                 qn_list.push_back(M[side]->List(blk)); qn_size.push_back(cnt);
             }
+            /* the kept rows of all sectors of this side in one launch */
+            if (!vec_tasks.empty() && dmrgx_rdm_eigenvectors_batch(rdm, (int32_t)vec_tasks.size(), vec_tasks.data(), nullptr)) { dmrgx_rdm_destroy(rdm); SETERRQ1(mpi_comm, 1, "dmrgx_rdm_eigenvectors_batch: %s", dmrgx_last_error()); }
             if (W > 1) {
                 for (int w = 0; w < W; ++w)
                     if (staging[(size_t)w] && dmrgx_comm_bcast(comm, staging[(size_t)w]->dev_uninitialised(), (size_t)stage_len[(size_t)w] * sizeof(double), w, nullptr)) { dmrgx_rdm_destroy(rdm); SETERRQ1(mpi_comm, 1, "dmrgx_comm_bcast: %s", dmrgx_last_error()); }

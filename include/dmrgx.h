@@ -285,6 +285,10 @@ dmrgx_status dmrgx_rdm_eigenvalues(const dmrgx_rdm* rdm, int32_t side, int32_t k
 /* dst_dev[r*ld + i], r < count: the eigenvector of the r-th largest eigenvalue as a ROW (a row of RotMatT,
  * == FillRotation_BlockDiag, include/DMRGBlockContainer.hpp:2032-2054). */
 dmrgx_status dmrgx_rdm_eigenvectors(const dmrgx_rdm* rdm, int32_t side, int32_t k, int32_t count, double* dst_dev, int64_t ld, void* stream);
+/* The same for several (density matrix, destination) pairs in one launch (the rotation of a truncation step asks for one block of rows
+ * per kept sector: a dozen launches of a few microseconds each at m = 512). */
+typedef struct { int32_t side, k, count, pad; double* dst_dev; int64_t ld; } dmrgx_rdm_vec_task;
+dmrgx_status dmrgx_rdm_eigenvectors_batch(const dmrgx_rdm* rdm, int32_t ntasks, const dmrgx_rdm_vec_task* tasks, void* stream);
 /* Optional second phase between the spectra and the eigenvectors.  dmrgx_rdm_create* returns with every spectrum final but -- with the direct
  * solver -- no eigenvector formed: the m-cut of GetTruncation (include/DMRGBlockContainer.hpp:1795-1875) is taken on the spectra, and only
  * then are the eigenvectors of the KEPT states computed: counts[2*k + side] = number of (largest) eigenvalues of that density matrix whose
