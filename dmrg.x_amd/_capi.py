@@ -178,7 +178,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError if the ABI symbol is missing
             fn.restype, fn.argtypes = res, args
-        if L.dmrgx_abi_version() != 2:
+        if L.dmrgx_abi_version() != 3:
             raise ImportError("dmrgx ABI version mismatch")
         _lib = L
     return _lib

@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define DMRGX_ABI_VERSION 2
+#define DMRGX_ABI_VERSION 3
 
 typedef int32_t dmrgx_status;
 enum {

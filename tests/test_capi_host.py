@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol(pkg):
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/dmrgx.h but not exported"
     assert declared == set(pkg._capi.SIGNATURES), "ctypes binding out of sync with the header"
-    assert lib.dmrgx_abi_version() == 2
+    assert lib.dmrgx_abi_version() == 3
 
 
 def test_integration_document_prints_the_header_signatures(pkg):
