@@ -273,30 +273,47 @@ constexpr int RITZ_THREADS = 64;
 __global__ void __launch_bounds__(RITZ_THREADS)
 gd_ritz_kernel(GdState* __restrict__ S, const double* __restrict__ col_src, int col_is_partial, int nblk, int mm, int warm, int restart, int keep)
 {
-    __shared__ double A[GD_MAX][GD_MAX + 1], Qa[GD_MAX][GD_MAX + 1], Yn[GD_MAX][GD_MAX + 1];
-    __shared__ double col[GD_MAX + 1], cs_c[GD_MAX / 2], cs_s[GD_MAX / 2], dg[GD_MAX];
+    __shared__ double A[GD_MAX][GD_MAX + 1], Qa[GD_MAX][GD_MAX + 1], Yn[GD_MAX][GD_MAX + 1], Yp[GD_MAX][GD_MAX + 1];
+    __shared__ double col[GD_MAX + 1], cs_c[GD_MAX / 2], cs_s[GD_MAX / 2], dg[GD_MAX], thp[GD_MAX], ths[GD_MAX];
     __shared__ int pp[GD_MAX / 2], qq[GD_MAX / 2], perm[GD_MAX];
     __shared__ double offn, dgn;
     const int tid = threadIdx.x, lane = tid;                                // ONE wave: every barrier below is a wait on the wave's own LDS traffic
     const int j = mm - 1;
+    // the device state that the loops below read goes to LDS in one pass, beside the partial sums' loads (a global load inside a serial
+    // loop of one wave is a microsecond per trip: the first build of this kernel took 47-67 us, most of it such loops)
+    if (warm && mm > 1) {
+        for (int e = tid; e < (mm - 1) * (mm - 1); e += RITZ_THREADS) Yp[e / (mm - 1)][e % (mm - 1)] = S->Y[(e / (mm - 1)) * GD_LD + e % (mm - 1)];
+        if (tid < mm - 1) thp[tid] = S->th[tid];
+    }
+    const double yold = tid < GD_MAX ? S->y[tid] : 0.0;
+    const int was_restart = S->after_restart;
     // ---- newest column of G: sums of the per-block partials in fixed order (all mm + 1 sums at once: one load latency) ---------------
     if (col_is_partial) {
-        double v[GD_MAX + 1];
+        // every load of a group of four sums is issued before the first is used (16 per lane and sum: left to a loop with a carried add the
+        // compiler waits for each load in turn -- ~130 dependent round trips to the L2 were 40 of this kernel's 45-60 us)
+        constexpr int PER = DOT_BLOCKS / RITZ_THREADS;
+        for (int i0 = 0; i0 <= mm; i0 += 4) {
+            double t[4][PER];
 #pragma unroll
-        for (int i = 0; i <= GD_MAX; ++i) {
-            v[i] = 0.0;
-            if (i <= mm) for (int b = tid; b < nblk; b += RITZ_THREADS) v[i] += col_src[(int64_t)i * nblk + b];
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int u = 0; u < PER; ++u) t[g][u] = (i0 + g <= mm && tid + u * RITZ_THREADS < nblk) ? col_src[(int64_t)(i0 + g) * nblk + tid + u * RITZ_THREADS] : 0.0;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                double v = 0.0;
+#pragma unroll
+                for (int u = 0; u < PER; ++u) v += t[g][u];
+                v = wave_sum(v);
+                if (lane == 0 && i0 + g <= mm) col[i0 + g] = v;
+            }
         }
-#pragma unroll
-        for (int i = 0; i <= GD_MAX; ++i) if (i <= mm) { const double s2 = wave_sum(v[i]); if (lane == 0) col[i] = s2; }
     } else if (tid <= mm) col[tid] = col_src[tid];
     __syncthreads();
     if (tid < mm) { S->G[tid * GD_LD + j] = col[tid]; S->G[j * GD_LD + tid] = col[tid]; }
     if (tid == 0 && mm == 1) S->hv0_2 = col[1];
     if (tid < GD_MAX && mm == 1) S->e0[tid] = tid == 0 ? 1.0 : 0.0;
     // the previous Ritz vector in this basis: its coefficients padded with a zero, or -- a restart since -- the first basis vector
-    if (tid < mm) S->yprev[tid] = S->after_restart ? (tid == 0 ? 1.0 : 0.0) : (tid < mm - 1 ? S->y[tid] : 0.0);
-    __syncthreads();
+    if (tid < mm) S->yprev[tid] = was_restart ? (tid == 0 ? 1.0 : 0.0) : (tid < mm - 1 ? yold : 0.0);
     if (tid == 0) S->after_restart = restart;
     const int n = (mm + 1) & ~1;                                          // even order for the pair schedule (padding: a decoupled zero row)
     // ---- matrix to diagonalise: arrowhead in the previous Ritz basis (warm) or G itself ------------------------------------------
@@ -306,11 +323,11 @@ gd_ritz_kernel(GdState* __restrict__ S, const double* __restrict__ col_src, int 
         double v = 0.0;
         if (a < mm && b < mm) {
             if (!warm || mp == 0) v = (a == j || b == j) ? col[a == j ? b : a] : S->G[a * GD_LD + b];
-            else if (a < mp && b < mp) v = a == b ? S->th[a] : 0.0;
+            else if (a < mp && b < mp) v = a == b ? thp[a] : 0.0;
             else if (a == mp && b == mp) v = col[j];
             else {                                                        // border: b_i = sum_k Yp[k][i] g[k]
                 const int i = a == mp ? b : a;
-                for (int k = 0; k < mp; ++k) v += S->Y[k * GD_LD + i] * col[k];
+                for (int k = 0; k < mp; ++k) v += Yp[k][i] * col[k];
             }
         }
         A[a][b] = v;
@@ -318,32 +335,51 @@ gd_ritz_kernel(GdState* __restrict__ S, const double* __restrict__ col_src, int 
     }
     __syncthreads();
     // ---- cyclic Jacobi, round-robin ordering: round r pairs (r, n-1) and ((r + k) mod (n-1), (r - k) mod (n-1)), k = 1 .. n/2 - 1 --
+    // (index arithmetic with a run-time divisor and f64 divisions / square roots are long instruction sequences on this ISA and a single
+    //  wave has nothing to hide them behind: the work items of a lane are decoded once, a rotation takes one division and two rsqrt-class
+    //  operations, the modulo of the schedule is a conditional subtraction)
+    constexpr int UMAX = (GD_MAX / 2 * GD_MAX + RITZ_THREADS - 1) / RITZ_THREADS;
+    int wk[UMAX], wi[UMAX];
+#pragma unroll
+    for (int u = 0; u < UMAX; ++u) { const int e = tid + u * RITZ_THREADS; wk[u] = e < (n / 2) * n ? e / n : -1; wi[u] = e % n; }
     for (int sweep = 0; sweep < 30 && n > 1; ++sweep) {
         {
             double off = 0.0, dgs = 0.0;
-            for (int e = lane; e < n * n; e += 64) { const int a = e / n, b = e % n; const double v = A[a][b]; if (a == b) dgs += v * v; else off += v * v; }
+#pragma unroll
+            for (int u = 0; u < UMAX; ++u) {                                   // (the n/2 x n work items cover the upper half of the rows: both halves here)
+                if (wk[u] < 0) continue;
+                const double v0 = A[wk[u]][wi[u]], v1 = A[wk[u] + n / 2][wi[u]];
+                if (wk[u] == wi[u]) dgs += v0 * v0; else off += v0 * v0;
+                if (wk[u] + n / 2 == wi[u]) dgs += v1 * v1; else off += v1 * v1;
+            }
             off = wave_sum(off); dgs = wave_sum(dgs);
             if (lane == 0) { offn = off; dgn = dgs; }
         }
         __syncthreads();
-        if (offn <= 1e-32 * (dgn + offn) || offn == 0.0) break;
+        if (offn <= 1e-29 * (dgn + offn) || offn == 0.0) break;               // off-diagonal norm <= 3e-15 ||A|| (n eps ||A|| is the floor of the rotations' own round-off)
         for (int r = 0; r < n - 1; ++r) {
             if (tid < n / 2) {
                 const int k = tid;
-                const int p0 = k == 0 ? r : (r + k) % (n - 1), q0 = k == 0 ? n - 1 : (r - k + (n - 1)) % (n - 1);
+                int p0 = r + k, q0 = r - k + (n - 1);
+                if (p0 >= n - 1) p0 -= n - 1;
+                if (q0 >= n - 1) q0 -= n - 1;
+                if (k == 0) { p0 = r; q0 = n - 1; }
                 const int p = min(p0, q0), q = max(p0, q0);
                 const double apq = A[p][q];
                 double c = 1.0, sn = 0.0;
                 if (apq != 0.0) {
-                    const double tau = (A[q][q] - A[p][p]) / (2.0 * apq);
-                    const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
-                    c = 1.0 / sqrt(1.0 + t * t); sn = t * c;
+                    const double th = 0.5 * (A[q][q] - A[p][p]);
+                    const double h = sqrt(th * th + apq * apq);
+                    const double t = apq / (th + (th >= 0.0 ? h : -h));             // the smaller root of t^2 + 2 (th / apq) t - 1 = 0
+                    c = rsqrt(1.0 + t * t); sn = t * c;
                 }
                 pp[k] = p; qq[k] = q; cs_c[k] = c; cs_s[k] = sn;
             }
             __syncthreads();
-            for (int e = tid; e < (n / 2) * n; e += RITZ_THREADS) {               // columns p, q of A and of the accumulated rotation
-                const int k = e / n, i = e % n;
+#pragma unroll
+            for (int u = 0; u < UMAX; ++u) {                                   // columns p, q of A and of the accumulated rotation
+                if (wk[u] < 0) continue;
+                const int k = wk[u], i = wi[u];
                 const int p = pp[k], q = qq[k];
                 const double c = cs_c[k], sn = cs_s[k];
                 const double aip = A[i][p], aiq = A[i][q];
@@ -352,12 +388,16 @@ gd_ritz_kernel(GdState* __restrict__ S, const double* __restrict__ col_src, int 
                 Qa[i][p] = c * qip - sn * qiq; Qa[i][q] = sn * qip + c * qiq;
             }
             __syncthreads();
-            for (int e = tid; e < (n / 2) * n; e += RITZ_THREADS) {               // rows p, q of A
-                const int k = e / n, i = e % n;
+#pragma unroll
+            for (int u = 0; u < UMAX; ++u) {                                   // rows p, q of A
+                if (wk[u] < 0) continue;
+                const int k = wk[u], i = wi[u];
                 const int p = pp[k], q = qq[k];
                 const double c = cs_c[k], sn = cs_s[k];
                 const double api = A[p][i], aqi = A[q][i];
-                A[p][i] = c * api - sn * aqi; A[q][i] = sn * api + c * aqi;
+                // (the rotated pair is annihilated exactly: computed, it is round-off of the size of the stopping rule's threshold and the
+                //  sweeps never end -- the first builds of this kernel ran all 30 sweeps of every call, 45-65 us)
+                A[p][i] = i == q ? 0.0 : c * api - sn * aqi; A[q][i] = i == p ? 0.0 : sn * api + c * aqi;
             }
             __syncthreads();
         }
@@ -377,12 +417,12 @@ gd_ritz_kernel(GdState* __restrict__ S, const double* __restrict__ col_src, int 
         const int src = perm[cidx];
         double v;
         if (!warm || mp == 0 || i == mp) v = Qa[i][src];
-        else { v = 0.0; for (int k = 0; k < mp; ++k) v += S->Y[i * GD_LD + k] * Qa[k][src]; }
+        else { v = 0.0; for (int k = 0; k < mp; ++k) v += Yp[i][k] * Qa[k][src]; }
         Yn[i][cidx] = v;
     }
     __syncthreads();
     for (int e = tid; e < mm * mm; e += RITZ_THREADS) S->Y[(e / mm) * GD_LD + (e % mm)] = Yn[e / mm][e % mm];
-    if (tid < mm) { S->th[tid] = dg[perm[tid]]; S->y[tid] = Yn[tid][0]; }
+    if (tid < mm) { ths[tid] = dg[perm[tid]]; S->th[tid] = ths[tid]; S->y[tid] = Yn[tid][0]; }
     if (tid == 0) S->theta = dg[perm[0]];
     if (!restart) return;
     // ---- restart: Q = [Ritz vectors 0 .. keep-1 | previous Ritz vector orthonormalised against them] (keep + 1 columns) -----------
@@ -410,14 +450,16 @@ gd_ritz_kernel(GdState* __restrict__ S, const double* __restrict__ col_src, int 
     __syncthreads();
     for (int e = tid; e < mm * kk; e += RITZ_THREADS) S->Q[e] = A[e / kk][e % kk];
     // G <- Q^T G Q: diag(theta) on the Ritz block exactly, the border through G q
-    if (tid < mm) { double v = 0.0; for (int b = 0; b < mm; ++b) v += S->G[tid * GD_LD + b] * A[b][keep]; col[tid] = v; }      // G q_last
+    for (int e = tid; e < mm * mm; e += RITZ_THREADS) Qa[e / mm][e % mm] = S->G[(e / mm) * GD_LD + e % mm];      // (Qa is free: G in LDS)
+    __syncthreads();
+    if (tid < mm) { double v = 0.0; for (int b = 0; b < mm; ++b) v += Qa[tid][b] * A[b][keep]; col[tid] = v; }      // G q_last
     __syncthreads();
     if (tid < kk) { double v = 0.0; for (int a = 0; a < mm; ++a) v += A[a][tid] * col[a]; dg[tid] = v; }                      // Q^T G q_last
     __syncthreads();
     for (int e = tid; e < GD_MAX * GD_LD; e += RITZ_THREADS) {
         const int a = e / GD_LD, b = e % GD_LD;
         double v = 0.0;
-        if (a < keep && b < keep) v = a == b ? S->th[a] : 0.0;
+        if (a < keep && b < keep) v = a == b ? ths[a] : 0.0;
         else if (a < kk && b < kk) v = dg[a == keep ? b : a];
         S->G[e] = v;
     }
