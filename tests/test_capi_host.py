@@ -140,3 +140,34 @@ def test_every_environment_switch_is_documented():
     missing = sorted(n for n in names if n not in design)
     assert not missing, missing
     assert len(names) <= 26, sorted(names)        # (37 at the end of round 3)
+
+
+def test_isa_checker_accepts_the_build_and_catches_planted_violations(tmp_path):
+    """tools/check_staging_regs.py is what turns three code-generation assumptions of the dominant kernel into checked properties (`make` runs
+    it on every build): here it must accept the ISA of the current build and refuse (a) a compiler-generated instruction that touches a
+    staging register, (b) a tile claim written into a second register, (c) a full-tile epilogue with a store missing, (d) a spilled register."""
+    import subprocess
+    import sys
+    isa = os.path.join(ROOT, "dmrg.x_amd", "csrc", "ggemm.isa.s")
+    if not os.path.exists(isa):
+        pytest.skip("no ISA listing (make has not run)")
+    tool = os.path.join(ROOT, "tools", "check_staging_regs.py")
+    run = lambda path: subprocess.run([sys.executable, tool, str(path)], capture_output=True, text=True)       # noqa: E731
+    ok = run(isa)
+    assert ok.returncode == 0, ok.stdout[-2000:]
+    text = open(isa).read()
+    k64 = text.index("ggemm_kernel_64")
+    claim = re.search(r"global_atomic_add v(\d+), v\d+, v\d+, s\[92:93\] sc0", text[k64:])
+    assert claim
+    planted = {
+        "staging": text.replace("s_endpgm", "v_mov_b32_e32 v100, v1\n\ts_endpgm", 1),
+        "claim": text[:k64] + text[k64:].replace(claim.group(0), claim.group(0).replace("v" + claim.group(1) + ",", "v1,", 1), 1),
+        "stores": text[:k64] + re.sub(r"\n\tglobal_store_dwordx2 [^\n]*\n\t;;#ASMEND", "\n\t;;#ASMEND", text[k64:], count=1),
+        "spill": text.replace(".vgpr_spill_count: 0", ".vgpr_spill_count: 3", 1),
+    }
+    for name, t in planted.items():
+        assert t != text, name
+        p = tmp_path / (name + ".s")
+        p.write_text(t)
+        r = run(p)
+        assert r.returncode != 0, (name, r.stdout[-1500:])

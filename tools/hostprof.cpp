@@ -60,6 +60,7 @@ __attribute__((constructor)) void start()
 __attribute__((destructor)) void stop()
 {
     if (!g_on) return;
+    if (g_n == 0) { g_on = 0; timer_delete(g_timer); return; }      // (a launcher process -- timeout, env -- that inherited the preload: it must not overwrite the engine's samples)
     g_on = 0;
     timer_delete(g_timer);
     FILE* f = fopen(getenv("HOSTPROF_OUT"), "w");
