@@ -543,6 +543,9 @@ public:
             if (guessed) { o.use_initial = 1; o.min_initial_norm2 = min_norm2; }
             dmrgx_eigs_stats st;
             memset(&st, 0, sizeof(st));
+            /* -step_profile 1: the solver's own wall time (KronStats.json: eigs_seconds) must not contain the plan's operator copies and the
+               start-vector GEMMs still queued in front of it -- bench.py's non-GEMM cost per MatMult is eigs_seconds minus the GEMM events */
+            if (step_profile) dmrgx_stream_sync(nullptr);
             if (H->plan_world > 1) {
                 /* striped solve: every rank owns a stripe of the right index of every KronBlock; the solver issues one
                    RCCL all-gather per MatMult and two fused all-reduces per Lanczos step itself.  The start vector goes in, and
