@@ -498,7 +498,7 @@ struct dmrgx_rdm {
 // Pinned host blocks for those read-backs, recycled per host thread (hipHostMalloc / hipHostFree per truncation would cost more than the
 // synchronisation they replace).
 namespace {
-struct PinnedCache { std::vector<std::pair<double*, size_t>> free; ~PinnedCache() { for (auto& b : free) (void)hipHostFree(b.first); } };
+struct PinnedCache { std::vector<std::pair<double*, size_t>> free; };      // (never freed: a thread-exit hipHostFree can run after the runtime's own teardown)
 PinnedCache& pinned_cache() { static thread_local PinnedCache c; return c; }
 double* pinned_take(size_t count, size_t* cap)
 {
