@@ -774,7 +774,16 @@ extern "C" dmrgx_status dmrgx_eigs_lowest(dmrgx_kron_plan* plan, const dmrgx_eig
 
     // how often the Ritz pair of a caller-supplied start vector is looked at: a look costs one small copy + a stream sync
     // (~50 us), a MatMult that turns out unnecessary 0.1 .. 10 ms
-    const int check_every = N >= 500000 ? 1 : (N >= 100000 ? 2 : 4);
+    // looks at the Ritz pair of a caller-supplied start vector: pinned slots + events of this host thread (see the step loop)
+    const bool looks = opts->use_initial && opts->max_matvec <= 0;
+    static thread_local double* look_buf = nullptr;
+    static thread_local hipEvent_t look_ev[2] = {nullptr, nullptr};
+    constexpr size_t look_stride = (size_t)(MAX_NCV + 1) * (MAX_NCV + 2);
+    if (looks && !look_buf) {
+        DMRGX_HIP(hipHostMalloc((void**)&look_buf, 2 * look_stride * sizeof(double), hipHostMallocDefault));
+        DMRGX_HIP(hipEventCreateWithFlags(&look_ev[0], hipEventDisableTiming)); DMRGX_HIP(hipEventCreateWithFlags(&look_ev[1], hipEventDisableTiming));
+    }
+    int look_mm[2] = {0, 0};                    // columns covered by the look in flight in each slot (0: none)
     std::vector<double> T((size_t)m * m, 0.0), theta, Q, hbuf((size_t)(m + 1) * row);
     int k = 0, n_matvec = 0, restarts = 0, converged = 0;
     double beta_m = 0.0, resid = 0.0, lambda = 0.0;
@@ -824,13 +833,24 @@ extern "C" dmrgx_status dmrgx_eigs_lowest(dmrgx_kron_plan* plan, const dmrgx_eig
             if (vec2) hipLaunchKernelGGL(axpy_normalise_kernel<true>, dim3(nblk), dim3(DOT_THREADS), 0, st, V, n, nv, c2, w, vec(j + 1), n, Hrow(j) + m + 1, Hrow(j));
             else hipLaunchKernelGGL(axpy_normalise_kernel<false>, dim3(nblk), dim3(DOT_THREADS), 0, st, V, n, nv, c2, w, vec(j + 1), n, Hrow(j) + m + 1, Hrow(j));
             DMRGX_HIP(hipGetLastError());
-            // A start vector supplied by the caller (the sweep engine's transformed ground state) is usually within a few
-            // Lanczos steps of convergence: look at the Ritz pair every 4 steps instead of only at the end of the cycle.
-            if (opts->use_initial && opts->max_matvec <= 0 && j + 1 < m && (j + 1 - k) % check_every == 0) {
-                DMRGX_HIP(hipMemcpyAsync(hbuf.data(), dScal.p, (size_t)(m + 1) * row * sizeof(double), hipMemcpyDeviceToHost, st));
-                DMRGX_HIP(hipStreamSynchronize(st));
-                if (null_start()) return redo_from_random();
-                const int mm = j + 1;
+            // A start vector supplied by the caller (the sweep engine's transformed ground state) is usually within a few Lanczos steps of
+            // convergence, so the Ritz pair is looked at after EVERY step -- one step behind the queue (round 5; rounds 2-4 looked every
+            // 1 / 2 / 4 steps with a blocking copy: 0.24 ms of idle GPU per configs[1] step and, on the small superblocks, 1-2 MatMults past
+            // convergence): the coefficients of step j travel to pinned memory behind an event, and the host reads the look of step j - 1
+            // while step j runs.  Convergence seen there ends the solve with the step already queued included.
+            if (looks && j + 1 < m) {
+                const int slot = j & 1;
+                DMRGX_HIP(hipMemcpyAsync(look_buf + (size_t)slot * look_stride, dScal.p, (size_t)(m + 1) * row * sizeof(double), hipMemcpyDeviceToHost, st));
+                DMRGX_HIP(hipEventRecord(look_ev[slot], st));
+                look_mm[slot] = j + 1;
+            }
+            if (looks && j > k && look_mm[(j - 1) & 1] == j) {
+                const int slot = (j - 1) & 1;
+                look_mm[slot] = 0;
+                DMRGX_HIP(hipEventSynchronize(look_ev[slot]));
+                std::copy(look_buf + (size_t)slot * look_stride, look_buf + (size_t)slot * look_stride + (size_t)(m + 1) * row, hbuf.begin());
+                if (null_start()) { DMRGX_HIP(hipStreamSynchronize(st)); return redo_from_random(); }
+                const int mm = j;
                 std::vector<double> A((size_t)mm * mm, 0.0), th, Qs;
                 for (int jj = 0; jj < mm; ++jj) for (int i = 0; i <= jj; ++i) {
                     const double v = (jj >= k) ? hbuf[(size_t)jj * row + i] : T[(size_t)i * m + jj];
@@ -839,10 +859,11 @@ extern "C" dmrgx_status dmrgx_eigs_lowest(dmrgx_kron_plan* plan, const dmrgx_eig
                 jacobi_eigh(mm, A, th, Qs);
                 const double r = std::fabs(std::sqrt(std::max(0.0, hbuf[(size_t)(mm - 1) * row + m + 1])) * Qs[(size_t)(mm - 1) * mm + 0]);
                 static const bool trace = getenv("DMRGX_EIGS_TRACE") != nullptr;      // developer aid: Ritz value and residual estimate per look
-                if (trace) fprintf(stderr, "[eigs] matvec %d: theta %.12f  |r| %.3e  (target %.3e)\n", n_matvec, th[0], r, tol * std::fabs(th[0]));
-                if (r <= tol * std::max(std::fabs(th[0]), 1e-300)) { jend = mm; early = true; break; }
+                if (trace) fprintf(stderr, "[eigs] look at matvec %d (queued: %d): theta %.12f  |r| %.3e  (target %.3e)\n", n_matvec - 1, n_matvec, th[0], r, tol * std::fabs(th[0]));
+                if (r <= tol * std::max(std::fabs(th[0]), 1e-300)) { jend = j + 1; early = true; break; }      // (step j is queued: its column is part of the final Rayleigh-Ritz)
             }
         }
+        look_mm[0] = look_mm[1] = 0;
         DMRGX_HIP(hipMemcpyAsync(hbuf.data(), dScal.p, (size_t)(m + 1) * row * sizeof(double), hipMemcpyDeviceToHost, st));
         DMRGX_HIP(hipStreamSynchronize(st));
         if (null_start()) return redo_from_random();
