@@ -490,7 +490,7 @@ struct dmrgx_rdm {
     double* rq_host = nullptr;                 // pinned, from pinned_take
     size_t rq_cap = 0;
     std::vector<int32_t> check_cols;
-    hipStream_t check_stream = nullptr;
+    hipEvent_t check_event = nullptr;          // recorded behind the read-back: the verification waits for IT, not for the stream
     bool check_pending = false;
     ~dmrgx_rdm();
 };
@@ -511,7 +511,11 @@ double* pinned_take(size_t count, size_t* cap)
     return p;
 }
 }  // namespace
-dmrgx_rdm::~dmrgx_rdm() { if (rq_host) pinned_cache().free.push_back({rq_host, rq_cap}); }
+dmrgx_rdm::~dmrgx_rdm()
+{
+    if (rq_host) pinned_cache().free.push_back({rq_host, rq_cap});
+    if (check_event) (void)hipEventDestroy(check_event);
+}
 
 static dmrgx_status rdm_rayleigh(dmrgx_rdm* P, const std::vector<int32_t>& cols, bool check_against_direct, hipStream_t st);
 
@@ -947,7 +951,9 @@ static dmrgx_status rdm_rayleigh(dmrgx_rdm* P, const std::vector<int32_t>& cols,
             if (!P->rq_host) P->rq_host = pinned_take((size_t)dtot, &P->rq_cap);
             if (!P->rq_host) DMRGX_FAIL(DMRGX_ERR_MEM, "rdm_select: no pinned host memory for the verification read-back");
             DMRGX_HIP(hipMemcpyAsync(P->rq_host, buf + P->rq_base, (size_t)dtot * sizeof(double), hipMemcpyDeviceToHost, st));
-            P->check_cols = cols; P->check_stream = st; P->check_pending = true;
+            if (!P->check_event) DMRGX_HIP(hipEventCreateWithFlags(&P->check_event, hipEventDisableTiming));
+            DMRGX_HIP(hipEventRecord(P->check_event, st));
+            P->check_cols = cols; P->check_pending = true;
             for (int mi = 0; mi < nm; ++mi) if (P->selected[mi] && P->mats[mi].n > 0) P->have[(size_t)mi] = cols[(size_t)mi];
             return DMRGX_OK;
         }
@@ -1087,7 +1093,7 @@ static dmrgx_status rdm_verify(dmrgx_rdm* R)
 {
     if (!R->check_pending) return DMRGX_OK;
     R->check_pending = false;
-    DMRGX_HIP(hipStreamSynchronize(R->check_stream));
+    DMRGX_HIP(hipEventSynchronize(R->check_event));      // (only the read-back: work queued on the stream since is not waited for)
     for (size_t mi = 0; mi < R->mats.size(); ++mi) {
         const MatDesc& m = R->mats[mi];
         const int32_t c = R->selected[mi] ? R->check_cols[mi] : 0;
@@ -1107,8 +1113,8 @@ static dmrgx_status rdm_verify(dmrgx_rdm* R)
 extern "C" dmrgx_status dmrgx_rdm_destroy(dmrgx_rdm* R)
 {
     if (!R) return DMRGX_OK;
-    // The verification of the selected eigenpairs is read here (it waits for the stream they were computed on, which a caller that has used the
-    // eigenvectors has long synchronised); otherwise no synchronisation: the blocks go back to the pool and are recycled in stream order (pool.hip)
+    // The verification of the selected eigenpairs is read here: it waits for the event behind its read-back only -- a caller that destroys the
+    // object one step later (the engine does) never waits at all; the blocks go back to the pool and are recycled in stream order (pool.hip)
     const dmrgx_status rc = rdm_verify(R);
     delete R;
     return rc;

@@ -434,6 +434,7 @@ public:
     PetscErrorCode Destroy()
     {
         if (!init) return 0;
+        if (rdm_pending) { dmrgx_rdm* r = rdm_pending; rdm_pending = nullptr; if (dmrgx_rdm_destroy(r)) SETERRQ1(mpi_comm, 1, "dmrgx_rdm_destroy: %s", dmrgx_last_error()); }
         for (Block& b : sys_blocks) { PetscErrorCode ierr = b.Destroy(); CHKERRQ(ierr); }
         PetscErrorCode ierr = SingleSite.Destroy(); CHKERRQ(ierr);
         if (fp_step) { fprintf(fp_step, "\n  ]\n}\n"); fclose(fp_step); fp_step = NULL; }
@@ -1535,9 +1536,14 @@ public:
             BT[side]->RotMatT->rot = rot;
             ierr = BT[side]->QN.Initialize(mpi_comm, qn_list, qn_size); CHKERRQ(ierr);
         }
-        dmrgx_stream_sync(nullptr);
-        /* (the solver's verification of the kept eigenpairs -- its eigenvalues against the Rayleigh quotients of the finished vectors -- is read here) */
-        if (dmrgx_rdm_destroy(rdm)) SETERRQ1(mpi_comm, 1, "dmrgx_rdm_destroy: %s", dmrgx_last_error());
+        /* The density-matrix object is destroyed one truncation LATER (one rank): its destruction reads the solver's verification of the kept
+           eigenpairs (eigenvalues against the Rayleigh quotients of the finished vectors), which by then has long arrived -- destroying it
+           here made the host wait for the GPU to drain (5 % of a configs[1] step, profiles/r05_hostprof_m512.txt) before it could queue the
+           rotations.  Everything queued above is stream-ordered; the rotation rows live in buffers of their own. */
+        if (W > 1) dmrgx_stream_sync(nullptr);
+        dmrgx_rdm* old_rdm = W > 1 ? rdm : rdm_pending;
+        rdm_pending = W > 1 ? nullptr : rdm;
+        if (old_rdm && dmrgx_rdm_destroy(old_rdm)) SETERRQ1(mpi_comm, 1, "dmrgx_rdm_destroy: %s", dmrgx_last_error());
         return 0;
     }
 
@@ -1774,6 +1780,7 @@ private:
     std::vector<int64_t> block_ver;                       /**< current version of every stored block (0: as initialised) */
     std::vector<std::shared_ptr<BasisOverlap>> block_ovl; /**< [i]: parent version of block_rot[i+1] -> current version of block i */
     int64_t ver_counter = 0;
+    dmrgx_rdm* rdm_pending = nullptr;          /**< the previous truncation's density matrices: destroyed (and their verification read) one truncation later */
     /** which path the density-matrix solver took, per truncation (dmrgx_rdm_info): DMRGRun.json RdmCalls ... RdmMaxWyBlocks */
     PetscInt rdm_calls = 0, rdm_jacobi_calls = 0, trid_persistent_calls = 0, trid_launch_calls = 0, trid_fallbacks = 0, trid_max_wgs = 0, rdm_max_levels = 0, rdm_max_wy_blocks = 0;
     PetscInt guesses_projected = 0, guesses_rejected = 0;                       /**< start vectors that went through a basis overlap */
