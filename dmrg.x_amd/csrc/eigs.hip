@@ -775,7 +775,9 @@ extern "C" dmrgx_status dmrgx_eigs_lowest(dmrgx_kron_plan* plan, const dmrgx_eig
     // how often the Ritz pair of a caller-supplied start vector is looked at: a look costs one small copy + a stream sync
     // (~50 us), a MatMult that turns out unnecessary 0.1 .. 10 ms
     // looks at the Ritz pair of a caller-supplied start vector: pinned slots + events of this host thread (see the step loop)
-    const bool looks = opts->use_initial && opts->max_matvec <= 0;
+    // (also from a random start vector: SLEPc looks at restarts only, but a look costs nothing here and a solve then ends up to ncv / 2 - 1
+    //  MatMults earlier -- the warm-up's cluster-growth steps and the reference-settings runs start random)
+    const bool looks = opts->max_matvec <= 0;
     static thread_local double* look_buf = nullptr;
     static thread_local hipEvent_t look_ev[2] = {nullptr, nullptr};
     constexpr size_t look_stride = (size_t)(MAX_NCV + 1) * (MAX_NCV + 2);
