@@ -795,6 +795,13 @@ void ggemm_schedule_core(std::vector<GTile>& tiles, const std::vector<int32_t>& 
     //  shifts instead of divisions, one pass per stage, the output written in place: profiles/r04_hostprof_glue_m2048.txt)
     constexpr int NX = 8;
     if (tiles.empty()) return;
+    // A list that fits a quarter of the chip's workgroup slots is launched one workgroup per entry, all at once: neither the order nor the
+    // balance of the eight queues matters, and at small m a sweep step schedules ~40 such lists (3 % of the host's time at m = 512,
+    // profiles/r05_hostprof_m512.txt).  Only the device meaning of GTile::pad is filled in.
+    if (tiles.size() <= (size_t)ggemm_slots(unit) / 4) {
+        for (GTile& t : tiles) t.pad = first_gemm[(size_t)t.group];
+        return;
+    }
     struct Cl { uint32_t begin, end; int32_t len16; int64_t cost; };
     static_assert(GG_CLUSTER == 8, "cluster edge as a shift");
     const int sh = unit == 2 ? 4 : 3;                 // tiles of 128 x 128 carry tm / tn in units of 64: a cluster is 16 units wide

@@ -741,8 +741,8 @@ static dmrgx_status rdm_create_impl(const dmrgx_sectors* left, const dmrgx_secto
         DMRGX_HIP(hipGetLastError());
     }
     stage("qr");
+    std::vector<SymEigMat> sm;
     if (use_dc) {
-        std::vector<SymEigMat> sm;
         for (int mi = 0; mi < nm; ++mi) {
             const MatDesc& m = P->mats[mi];
             if (m.n > 0) sm.push_back(SymEigMat{m.n, m.npad, m.npad, 0, buf + m.a_off, buf + m.v_off, buf + ew_base + (diag_off[mi] - diag_base)});
@@ -861,6 +861,17 @@ static dmrgx_status rdm_create_impl(const dmrgx_sectors* left, const dmrgx_secto
         std::vector<double> ew((size_t)dtot);
         if (!ew.empty()) DMRGX_HIP(hipMemcpyAsync(ew.data(), buf + ew_base, ew.size() * sizeof(double), hipMemcpyDeviceToHost, st));
         DMRGX_HIP(hipStreamSynchronize(st));
+        if (const int32_t bad = symeig_deferred_timed_out(P->deferred)) {
+            // the persistent tridiagonalisation did not get its partners: everything queued behind it ran on garbage.  Once more, by launches
+            // (the density matrices themselves were only read).
+            symeig_note_timeout(bad);
+            P->deferred.dbuf.release(); P->deferred.ibuf.release(); P->deferred.pending = false;
+            DMRGX_CHK(symeig_batched(sm, st, &P->symeig, &P->deferred));
+            P->symeig.timed_out = bad;
+            if (!ew.empty()) DMRGX_HIP(hipMemcpyAsync(ew.data(), buf + ew_base, ew.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+            DMRGX_HIP(hipStreamSynchronize(st));
+            if (symeig_deferred_timed_out(P->deferred)) DMRGX_FAIL(DMRGX_ERR_INTERNAL, "rdm_create: the tridiagonalisation by launches reported a persistent-kernel status");
+        }
         std::vector<int32_t> allperm;
         for (int mi = 0; mi < nm; ++mi) {
             const MatDesc& m = P->mats[mi];

@@ -48,7 +48,12 @@ struct SymEigDeferred {
     std::vector<Mat> mats;               // the matrices of order > 0, in the order of the call
     DevBuf dbuf, ibuf;                   // workspace of the call
     bool pending = false;
+    const int32_t* status_host = nullptr;   // (pinned) status word of the persistent rounds, valid behind the caller's next synchronisation of the stream
 };
+// After the caller has synchronised the stream: 0, or the status (1: time-out, 2: lapped) of a deferred call's persistent rounds -- its results are
+// then garbage: note the event (symeig_note_timeout: message, the persistent kernel is switched off for the process) and repeat the call.
+int32_t symeig_deferred_timed_out(const SymEigDeferred& d);
+void symeig_note_timeout(int32_t status);
 dmrgx_status symeig_batched(const std::vector<SymEigMat>& mats, hipStream_t st, SymEigReport* report = nullptr, SymEigDeferred* deferred = nullptr);
 dmrgx_status symeig_finish(SymEigDeferred& d, const std::vector<int32_t>& keep, hipStream_t st);
 

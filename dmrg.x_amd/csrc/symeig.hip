@@ -1036,6 +1036,15 @@ template <class K> dmrgx_status set_dyn_lds(K kernel, size_t bytes)
 }  // namespace
 
 void symeig_set_persistent(bool on) { g_coop_disabled = !on; }
+void symeig_note_timeout(int32_t status)
+{
+    if (!g_coop_disabled) fprintf(stderr, status == 2 ? "[dmrgx] persistent tridiagonalisation: a workgroup was lapped by its partners (protocol error): using one launch per column from now on\n"
+                                                       : "[dmrgx] persistent tridiagonalisation timed out waiting for a partner workgroup (GPU shared with another "
+                                                         "persistent kernel?): using one launch per column from now on\n");
+    g_coop_disabled = true;
+    ++g_coop_timeouts;
+}
+int32_t symeig_deferred_timed_out(const SymEigDeferred& d) { return d.status_host ? *d.status_host : 0; }
 void symeig_process_state(int32_t* timeouts, int32_t* persistent_off)
 {
     if (timeouts) *timeouts = g_coop_timeouts;
@@ -1047,6 +1056,7 @@ dmrgx_status symeig_batched(const std::vector<SymEigMat>& mats_in, hipStream_t s
     SymEigReport rep_local;
     SymEigReport& rep = report ? *report : rep_local;
     rep = SymEigReport();
+    if (deferred) deferred->status_host = nullptr;
     std::vector<SymEigMat> M;
     for (const SymEigMat& s : mats_in) {
         if (s.n < 0 || s.n > SYMEIG_MAX_N) DMRGX_FAIL(DMRGX_ERR_ARG, "symeig: matrix of order %d (supported: 0..%d)", s.n, SYMEIG_MAX_N);
@@ -1362,16 +1372,22 @@ dmrgx_status symeig_batched(const std::vector<SymEigMat>& mats_in, hipStream_t s
         DMRGX_HIP(hipMemcpy(pr, B + ws[coop_set[0]].y, sizeof(pr), hipMemcpyDeviceToHost));
         fprintf(stderr, "[trid-prof] n=%d: wave 0 of workgroup 1, 100 MHz ticks -> us: consume %.1f  vector work %.1f  own rows %.1f  end barrier %.1f\n", M[coop_set[0]].n, pr[0] / 100.0, pr[1] / 100.0, pr[2] / 100.0, pr[3] / 100.0);
     }
-    if (coop_ran) {
+    if (coop_ran && deferred) {
+        // Two-phase call: the status word travels to pinned memory behind the persistent rounds and is looked at by the CALLER behind its own
+        // synchronisation (the spectra's) -- symeig_deferred_timed_out -- so that everything below is queued while the tridiagonalisation still
+        // runs: the divide and conquer starts the moment it ends instead of one host hand-over later.  A time-out (never seen outside the
+        // test hook and GPUs shared with another persistent kernel) then costs the caller a second call, on the launch path.
+        static thread_local int32_t* pin_status = nullptr;
+        if (!pin_status) DMRGX_HIP(hipHostMalloc((void**)&pin_status, 64, hipHostMallocDefault));
+        *pin_status = 0;
+        DMRGX_HIP(hipMemcpyAsync(pin_status, gran.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        deferred->status_host = pin_status;
+    } else if (coop_ran) {
         DMRGX_HIP(hipMemcpyAsync(&coop_status, gran.p, sizeof(int32_t), hipMemcpyDeviceToHost, st));      // (a pageable copy: it may block, so it is issued here)
         DMRGX_HIP(hipStreamSynchronize(st));
         hmark("trid done (sync)");
         if (coop_status != 0) {
-            if (!g_coop_disabled) fprintf(stderr, coop_status == 2 ? "[dmrgx] persistent tridiagonalisation: a workgroup was lapped by its partners (protocol error): using one launch per column from now on\n"
-                                                                    : "[dmrgx] persistent tridiagonalisation timed out waiting for a partner workgroup (GPU shared with another "
-                                                                      "persistent kernel?): using one launch per column from now on\n");
-            g_coop_disabled = true;
-            ++g_coop_timeouts;
+            symeig_note_timeout(coop_status);
             rep.timed_out = coop_status; rep.launch_matrices += rep.persistent_matrices; rep.persistent_matrices = 0;
             DMRGX_CHK(trid_by_launches(coop_set));     // A was only read by the persistent kernel
         }
