@@ -215,6 +215,16 @@ class ReducedDensityMatrices:
         arr = (C.c_int32 * (2 * len(self.blocks)))(*[int(c) for c in counts])
         _capi.check(_capi.lib().dmrgx_rdm_select(self._handle, arr, None))
 
+    def eigenvectors_batch(self, requests):
+        """requests: [(side, k, count), ...] -> list of (count, n) tensors, all gathered by ONE launch (dmrgx_rdm_eigenvectors_batch)."""
+        outs, tasks = [], (_capi.RdmVecTask * max(len(requests), 1))()
+        for i, (side, k, count) in enumerate(requests):
+            n = self.size(side, k)
+            outs.append(torch.empty((count, n), dtype=torch.float64, device="cuda"))
+            tasks[i].side, tasks[i].k, tasks[i].count, tasks[i].dst_dev, tasks[i].ld = side, k, count, outs[-1].data_ptr(), n
+        _capi.check(_capi.lib().dmrgx_rdm_eigenvectors_batch(self._handle, len(requests), tasks, None))
+        return outs
+
     def eigenvectors(self, side, k, count):
         n = self.size(side, k)
         dst = torch.empty((count, n), dtype=torch.float64, device="cuda")

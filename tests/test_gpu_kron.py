@@ -485,6 +485,12 @@ def test_rdm_select_forms_only_the_kept_eigenvectors(mods):
         if c < n:
             with pytest.raises(capi.DmrgxError):
                 rdm.eigenvectors(mi % 2, mi // 2, c + 1)
+    # the same rows through the batched gather (one launch for all of them: what the engine's rotation uses)
+    req = [(mi % 2, mi // 2, c) for mi, c in enumerate(counts) if c > 0]
+    for (side, k, c), U in zip(req, rdm.eigenvectors_batch(req)):
+        assert torch.equal(U, rdm.eigenvectors(side, k, c))
+    with pytest.raises(capi.DmrgxError):
+        rdm.eigenvectors_batch([(0, 0, counts[0] + 1)])
     rdm.destroy()                                              # (returns the verdict of the Rayleigh-quotient verification: raises on a mismatch)
 
 
