@@ -44,7 +44,7 @@ struct PCell {              // plan-owned cell: dense data lives in the arena at
     int64_t off;
 };
 
-struct CopyTask {           // dst[i*ldd + j] (+)= a * src(i,j)
+struct CopyTask {           // dst[i*ldd + j] = (round 0) / += (later rounds) a * src(i,j): every contribution covers its whole destination cell
     int64_t dst_off;        // arena element offset
     const double* src;
     int64_t lds;
@@ -54,6 +54,16 @@ struct CopyTask {           // dst[i*ldd + j] (+)= a * src(i,j)
 };
 
 struct CopyTile { int32_t task, ti, tj, pad; };
+
+// The column segments of the intermediates T_{g,k} that no right-operator cell reaches are read by stage 2 as zeros: they are the only part of
+// the arena that is zeroed (round 5; rounds 1-4 zeroed the whole arena -- 1.4 GB at m = 2048 -- and added every operator into it)
+struct ZeroRect { int64_t off; int32_t ld, nr, nc, pad; };
+__global__ void __launch_bounds__(256) zero_rects_kernel(const ZeroRect* __restrict__ rects, double* __restrict__ arena)
+{
+    const ZeroRect r = rects[blockIdx.y];
+    const int64_t n = (int64_t)r.nr * r.nc;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) arena[r.off + (e / r.nc) * r.ld + e % r.nc] = 0.0;
+}
 
 __global__ void __launch_bounds__(256)
 cell_copy_kernel(const CopyTile* __restrict__ tiles, const CopyTask* __restrict__ tasks, double* __restrict__ arena)
@@ -67,7 +77,7 @@ cell_copy_kernel(const CopyTile* __restrict__ tiles, const CopyTask* __restrict_
     if (!k.tr) {
         for (int r = ty; r < 32; r += 8) {
             const int i = i0 + r, j = j0 + tx;
-            if (i < k.nr && j < k.nc) dst[(size_t)i * k.ldd + j] += k.a * k.src[(size_t)i * k.lds + j];
+            if (i < k.nr && j < k.nc) { const double v = k.a * k.src[(size_t)i * k.lds + j]; double& o = dst[(size_t)i * k.ldd + j]; o = k.round == 0 ? v : o + v; }
         }
     } else {
         // dst(i,j) = src[j*lds + i]: read coalesced along i, transpose through LDS
@@ -78,7 +88,7 @@ cell_copy_kernel(const CopyTile* __restrict__ tiles, const CopyTask* __restrict_
         __syncthreads();
         for (int r = ty; r < 32; r += 8) {
             const int i = i0 + r, j = j0 + tx;
-            if (i < k.nr && j < k.nc) dst[(size_t)i * k.ldd + j] += k.a * buf[tx][r];
+            if (i < k.nr && j < k.nc) { const double v = k.a * buf[tx][r]; double& o = dst[(size_t)i * k.ldd + j]; o = k.round == 0 ? v : o + v; }
         }
     }
 }
@@ -574,6 +584,7 @@ extern "C" dmrgx_status dmrgx_kron_plan_create(const dmrgx_kron_desc* d, void* s
     //           X_src[:, contraction range of the cell] * cellT.  A merged right operator may hold several cells with the
     //           same output columns (e.g. O (x) 1 cell (2,2) and the new site's identity cell (2,1)), so groups are built
     //           per output-column SEGMENT with a product list -- never one overwriting group per cell.
+    std::vector<ZeroRect> zero_rects;
     auto stage1 = [&](const std::vector<PCell>& cellsT, int32_t sB, int32_t k, int32_t ksrc, int64_t toff) {
         (void)sB;
         const int32_t ir = d->block_ir[k], cs = cbeg(k, me), ce = cend(k, me), w = ce - cs;
@@ -593,7 +604,7 @@ extern "C" dmrgx_status dmrgx_kron_plan_create(const dmrgx_kron_desc* d, void* s
             if (o0 >= o1) continue;
             bool any = false;
             for (const PCell& c : cellsT) if (c.q == ir && c.c0 <= o0 && c.c0 + c.nc >= o1) { any = true; break; }
-            if (!any) continue;                                  // T is zero there (arena memset at plan creation)
+            if (!any) { zero_rects.push_back(ZeroRect{toff + (o0 - cs), w, M, o1 - o0, 0}); continue; }      // T is zero there: zero_rects_kernel at plan creation
             const int32_t g = B.open(BASE_ARENA, toff + (o0 - cs), w, M, o1 - o0, 0);
             for (const PCell& c : cellsT) {
                 if (c.q != ir || c.c0 > o0 || c.c0 + c.nc < o1) continue;
@@ -681,13 +692,15 @@ extern "C" dmrgx_status dmrgx_kron_plan_create(const dmrgx_kron_desc* d, void* s
     P->world = W; P->rank = me;
     DMRGX_CHK(P->arena.alloc((size_t)std::max<int64_t>(arena_ops + arena_T + arena_slabs, 1) * sizeof(double)));
     P->n_red_tiles = (int32_t)B.red_tiles.size();
-    DMRGX_HIP(zero_async(P->arena.p, P->arena.bytes, st));
-    {   // operator copies, one launch per accumulation round
+    {   // operator copies, one launch per accumulation round (round 0 writes); the unreached segments of the intermediates are zeroed.
+        // Nothing else of the arena is read before it is written: every dense operator cell has a round-0 copy, stage 1 writes the reached
+        // segments of every T_{g,k} whole, the split-K segments write their slabs whole.
         int32_t max_round = -1;
         for (auto& c : copies) max_round = std::max(max_round, c.round);
         DevBuf d_tab;                                   // the copy tasks and the tile lists of all rounds in one upload
         PackedUpload pk;
         const size_t o_tasks = pk.add(copies);
+        const size_t o_zero = pk.add(zero_rects);
         std::vector<std::pair<size_t, size_t>> lists;
         for (int32_t r = 0; r <= max_round; ++r) {
             std::vector<CopyTile> ct;
@@ -698,6 +711,13 @@ extern "C" dmrgx_status dmrgx_kron_plan_create(const dmrgx_kron_desc* d, void* s
             lists.push_back({pk.add(ct), ct.size()});
         }
         DMRGX_CHK(pk.upload(d_tab, st));
+        if (!zero_rects.empty()) {
+            int64_t big = 1;
+            for (const ZeroRect& r : zero_rects) big = std::max(big, (int64_t)r.nr * r.nc);
+            hipLaunchKernelGGL(zero_rects_kernel, dim3((unsigned)std::min<int64_t>((big + 2047) / 2048, 512), (unsigned)zero_rects.size()), dim3(256), 0, st,
+                               (const ZeroRect*)packed_at<ZeroRect>(d_tab, o_zero), P->arena.as<double>());
+            DMRGX_HIP(hipGetLastError());
+        }
         for (const auto& l : lists) {
             hipLaunchKernelGGL(cell_copy_kernel, dim3((unsigned)l.second), dim3(256), 0, st, (const CopyTile*)packed_at<CopyTile>(d_tab, l.first), (const CopyTask*)packed_at<CopyTask>(d_tab, o_tasks), P->arena.as<double>());
             DMRGX_HIP(hipGetLastError());
