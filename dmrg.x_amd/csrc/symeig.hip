@@ -334,7 +334,10 @@ trid_coop_kernel(const TcArgs args)
     const bool prof = args.prof && mi == 0 && g == (G > 1 ? 1 : 0) && tid == 0;
     long long pt[4] = {0, 0, 0, 0}, pc = 0;
     for (int j = 0; j < n; ++j) {
-        if (g != glast && j >= ilast) return;                         // (uniform per workgroup) nothing left to publish: see above
+        if (g != glast && j >= ilast) {                                // (uniform per workgroup) nothing left to publish: see above
+            if (prof) for (int q = 0; q < 4; ++q) args.prof[q] = pt[q] / (j > 0 ? j : 1);      // (developer aid: mean ticks per column of the columns it took part in)
+            return;
+        }
         if (prof) pc = wall_clock64();
         { double* t = svp; svp = svj; svj = t; }                      // svp = v_{j-1}
         const u64* rb = m.rowbuf + (size_t)(j & 1) * 2 * n;              // row j, epoch j+1
@@ -467,7 +470,7 @@ trid_coop_kernel(const TcArgs args)
         __syncthreads();
         if (prof) { const long long c = wall_clock64(); pt[3] += c - pc; pc = c; }
     }
-    if (prof) for (int q = 0; q < 4; ++q) args.prof[q] = pt[q];
+    if (prof) for (int q = 0; q < 4; ++q) args.prof[q] = pt[q] / (n > 0 ? n : 1);
 }
 
 // dst (n x n, ld) = src^T for every matrix (V from V^T)
@@ -1370,7 +1373,7 @@ dmrgx_status symeig_batched(const std::vector<SymEigMat>& mats_in, hipStream_t s
     if (coop_ran && getenv("DMRGX_TRID_PROF")) {
         long long pr[4];
         DMRGX_HIP(hipMemcpy(pr, B + ws[coop_set[0]].y, sizeof(pr), hipMemcpyDeviceToHost));
-        fprintf(stderr, "[trid-prof] n=%d: wave 0 of workgroup 1, 100 MHz ticks -> us: consume %.1f  vector work %.1f  own rows %.1f  end barrier %.1f\n", M[coop_set[0]].n, pr[0] / 100.0, pr[1] / 100.0, pr[2] / 100.0, pr[3] / 100.0);
+        fprintf(stderr, "[trid-prof] n=%d: wave 0 of workgroup 1, mean per column [us]: consume %.2f  vector work %.2f  own rows %.2f  end barrier %.2f\n", M[coop_set[0]].n, pr[0] / 100.0, pr[1] / 100.0, pr[2] / 100.0, pr[3] / 100.0);
     }
     if (coop_ran && deferred) {
         // Two-phase call: the status word travels to pinned memory behind the persistent rounds and is looked at by the CALLER behind its own
