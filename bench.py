@@ -252,13 +252,18 @@ def sweep_legs():
     assert run3["GSEnergy"] < -121.10624750033969, run3["GSEnergy"]
     # configs[1]: three sweeps (0.3 s): `sites_per_s` stays the FIRST sweep after the warm-up, as in every earlier round (its environment blocks still
     # come from the warm-up: start vectors through basis overlaps, a third more MatMults); the settled rate of the later sweeps is printed beside it
-    run1c = engine_run(["-Lx", 8, "-Ly", 4, "-mwarmup", 512, *j1j2, "-nsweeps", 3])
-    out["configs_1"] = leg(run1c, "configs[1]: J1-J2 8x4 cylinder, J2=0.5, m=512, warm-up + three finite-system sweeps (real engine run); sites_per_s is the "
-                                  "first sweep, sites_per_s_settled the third")
+    # -H_eps_type gd here too since round 5 (as on every other leg): with the projected problem on the device it is the faster type at m = 512 as
+    # well (same box, first sweep: 304-311 against 294 sites/s, profiles/r05_configs1_solver_type_ab.txt); the default type's first sweep is listed beside it
+    run1c = engine_run(["-Lx", 8, "-Ly", 4, "-mwarmup", 512, *j1j2, "-nsweeps", 3, "-H_eps_type", "gd"])
+    out["configs_1"] = leg(run1c, "configs[1]: J1-J2 8x4 cylinder, J2=0.5, m=512, warm-up + three finite-system sweeps (real engine run, -H_eps_type gd); sites_per_s is the "
+                                  "first sweep, sites_per_s_settled the third, sites_per_s_default_solver the first sweep with the default (Krylov-Schur / Lanczos) type")
     p0, p2 = run1c["PerSweep"][0], run1c["PerSweep"][-1]
     out["configs_1"].update({"sites_per_s": p0["steps"] / p0["seconds"], "sweep_steps": p0["steps"], "sweep_seconds": p0["seconds"], "sweep_matmults": p0["matmults"],
                              "matmults_per_s_in_sweep": p0["matmults"] / p0["seconds"], "sites_per_s_settled": p2["steps"] / p2["seconds"],
                              "sweep_matmults_settled": p2["matmults"]})
+    run1d = engine_run(["-Lx", 8, "-Ly", 4, "-mwarmup", 512, *j1j2, "-nsweeps", 1])
+    out["configs_1"]["sites_per_s_default_solver"] = run1d["LastSweepSteps"] / run1d["LastSweepSeconds"]
+    out["configs_1"]["sweep_matmults_default_solver"] = run1d["LastSweepMatMults"]
     # configs[2]'s lattice and m on ONE GPU (BASELINE names it for 2 GPUs: the N = 2 bench line runs it there); its geometry is tied
     # to the oracle step by step at reduced m (tests/test_gpu_engine.py, golden table: E = -51.658556812379 at m = 4, Sz = 2)
     run2 = engine_run(["-Lx", 16, "-Ly", 6, "-heisenberg", 1, "-mwarmup", 1024, "-nsweeps", 1, "-H_eps_type", "gd"], timeout=600)
