@@ -263,6 +263,12 @@ typedef u64 __attribute__((address_space(1))) gu64;
 #define DMRGX_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 constexpr int TC_THREADS = 512, TC_WAVES = TC_THREADS / 64;
 constexpr int TC_SPIN_LIMIT = 1 << 19;               // polls of one batch of granules before giving up (~0.5 s)
+#ifndef TC_FIRST_SLEEP
+#define TC_FIRST_SLEEP 10                            // s_sleep units (64 clocks) before the first poll of a column: the partners' publications are still on their way
+#endif                                               // then, and polls that come back empty are traffic in their way: 0 / 6 / 8 / 10 / 12 / 14 -> 752 / 721 / 709 / 701 / 706 / 715 us
+#ifndef TC_RETRY_SLEEP                               // per call at m = 512, 4556 / 4309 / 4265 / 4262 / 4291 / 4335 at m = 2048 (profiles/r05_trid_first_poll_delay.txt)
+#define TC_RETRY_SLEEP 1                             // between polls of what is still missing (0 / 1 / 2 / 4: 700 / 701 / 706 / 765 us)
+#endif
 constexpr int TC_KB = 4;                             // columns per thread whose granules are in flight together
 constexpr int TC_MB = 4;                             // chunks of 64 columns of the row pass whose LDS reads are in flight together
 constexpr int TC_VECS = 4;                           // O(n) vectors every workgroup keeps beside its rows
@@ -330,7 +336,7 @@ trid_coop_kernel(const TcArgs args)
     if (g == 0) for (int k = tid; k < n; k += TC_THREADS) put_f64(m.rowbuf + 2 * (size_t)k, 1u, m.A[k]);     // row 0, epoch 1
     if (tid == 0) sfail = 0;
     __syncthreads();
-    double tau_p = 0.0;
+    double tau_p = 0.0, out_d = 0.0, out_e = 0.0;
     const bool prof = args.prof && mi == 0 && g == (G > 1 ? 1 : 0) && tid == 0;
     long long pt[4] = {0, 0, 0, 0}, pc = 0;
     for (int j = 0; j < n; ++j) {
@@ -340,12 +346,22 @@ trid_coop_kernel(const TcArgs args)
         }
         if (prof) pc = wall_clock64();
         { double* t = svp; svp = svj; svj = t; }                      // svp = v_{j-1}
+        // `glast` (which everybody waits for in every column) writes column j-1's results HERE, where it would otherwise only wait for
+        // the partners' publications, instead of in front of its own rows
+        if (g == glast && j > 0) {
+            double* vt = m.VT + (int64_t)(j - 1) * m.ldv;
+            for (int k = tid; k < n; k += TC_THREADS) vt[k] = k > j - 1 ? svp[k] : 0.0;
+            if (tid == 0) { m.d[j - 1] = out_d; m.e[j - 1] = out_e; m.tau[j - 1] = tau_p; }
+        }
         const u64* rb = m.rowbuf + (size_t)(j & 1) * 2 * n;              // row j, epoch j+1
         const u64* yb = m.ybuf + (size_t)((j + 1) & 1) * 2 * n;          // y_{j-1}, epoch j
         double s = 0.0;
         bool ok = true, lap = false;
         // every granule this thread needs is requested before the first tag is looked at (TC_KB columns x 4 loads in flight), and only
         // the columns that were not there yet are asked for again
+#if TC_FIRST_SLEEP > 0
+        if (j > 0) __builtin_amdgcn_s_sleep(TC_FIRST_SLEEP);      // the partners' publications are in flight: a poll that leaves now comes back empty and is in their way
+#endif
         for (int k0 = j + tid; k0 < n; k0 += TC_THREADS * TC_KB) {
             unsigned pending = 0;
 #pragma unroll
@@ -382,7 +398,7 @@ trid_coop_kernel(const TcArgs args)
                 }
                 if (pending) {
                     if (spins > TC_SPIN_LIMIT) { ok = false; break; }
-                    __builtin_amdgcn_s_sleep(1);
+                    __builtin_amdgcn_s_sleep(TC_RETRY_SLEEP);
                 }
             }
         }
@@ -419,11 +435,7 @@ trid_coop_kernel(const TcArgs args)
         for (int k = j + tid; k < n; k += TC_THREADS) svj[k] = (k <= j || tj == 0.0) ? 0.0 : (k == j + 1 ? 1.0 : svj[k] * scale);     // own columns only
         __syncthreads();
         { double* t = sw; sw = sw_next; sw_next = t; }          // sw = w_{j-1} (the y buffer of this column is the w buffer of the next)
-        if (g == glast) {
-            double* vt = m.VT + (int64_t)j * m.ldv;
-            for (int k = tid; k < n; k += TC_THREADS) vt[k] = k > j ? svj[k] : 0.0;
-            if (tid == 0) { m.d[j] = dj; if (j + 1 < n) m.e[j] = beta; m.tau[j] = tj; }
-        }
+        out_d = dj; out_e = beta;                                // (written out by `glast` at the top of the next column, see there)
         tau_p = tj;
         if (prof) { const long long c = wall_clock64(); pt[1] += c - pc; pc = c; }
         // ---- own rows (in LDS): update with reflector j-1, multiply by v_j; the owner of row j+1 publishes it while it is in hand.
@@ -469,6 +481,11 @@ trid_coop_kernel(const TcArgs args)
         if (prof) { const long long c = wall_clock64(); pt[2] += c - pc; pc = c; }
         __syncthreads();
         if (prof) { const long long c = wall_clock64(); pt[3] += c - pc; pc = c; }
+    }
+    if (g == glast && n > 0) {                                     // the last column's results (its reflector is the zero vector)
+        double* vt = m.VT + (int64_t)(n - 1) * m.ldv;
+        for (int k = tid; k < n; k += TC_THREADS) vt[k] = 0.0;
+        if (tid == 0) { m.d[n - 1] = out_d; m.tau[n - 1] = tau_p; }
     }
     if (prof) for (int q = 0; q < 4; ++q) args.prof[q] = pt[q] / (n > 0 ? n : 1);
 }
