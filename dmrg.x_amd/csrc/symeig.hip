@@ -592,7 +592,13 @@ __global__ void __launch_bounds__(DC_LEAF_THREADS) dc_leaf_kernel(const DcMat* _
     __syncthreads();
     // round-robin tournament over pe = p rounded up to even players (a leaf of 17 needs 17 rounds of 9 pairs per sweep, not the 31 x 16
     // of the full 32 x 32 array; the odd player out meets the padding index p, whose row and column are zero: no rotation)
-    const int pe = (p + 1) & ~1, hp = pe / 2;
+    const int pe = (p + 1) & ~1, hp = pe / 2, pm = pe - 1;
+    // (pair, index) of the elements this thread rotates in every round: fixed for the whole solve -- the divisions by the run-time pe
+    // and the modulo of the pairing were a third of a round's instructions
+    constexpr int NE = (H * P + DC_LEAF_THREADS - 1) / DC_LEAF_THREADS;
+    int et[NE], ei[NE];
+#pragma unroll
+    for (int u = 0; u < NE; ++u) { const int e = tid + u * DC_LEAF_THREADS; et[u] = e < hp * pe ? e / pe : -1; ei[u] = e % pe; }
     for (int sweep = 0; sweep < 20; ++sweep) {
         double off = 0.0, dg = 0.0;
         for (int e = tid; e < P * P; e += DC_LEAF_THREADS) { const int i = e / P, c = e % P; const double v = S[i][c]; if (i == c) dg += v * v; else off += v * v; }
@@ -600,8 +606,8 @@ __global__ void __launch_bounds__(DC_LEAF_THREADS) dc_leaf_kernel(const DcMat* _
         dg = block_sum<DC_LEAF_THREADS / 64>(dg, red, tid);
         if (off <= 2e-31 * dg || off == 0.0) break;          // off-diagonal norm <= 2 eps |T|; uniform over the workgroup
         for (int r = 0; r < pe - 1; ++r) {
-            auto pair_of = [&](int t, int& a, int& bq) {
-                if (t == 0) { a = pe - 1; bq = r; } else { a = (r + t) % (pe - 1); bq = (r - t + pe - 1) % (pe - 1); }
+            auto pair_of = [&](int t, int& a, int& bq) {          // 0 <= r < pm, 1 <= t < hp: (r + t) mod pm and (r - t) mod pm by one conditional step
+                if (t == 0) { a = pm; bq = r; } else { a = r + t; if (a >= pm) a -= pm; bq = r - t; if (bq < 0) bq += pm; }
                 if (a > bq) { const int x = a; a = bq; bq = x; }
             };
             if (tid < hp) {                                  // pair tid of round r
@@ -617,8 +623,10 @@ __global__ void __launch_bounds__(DC_LEAF_THREADS) dc_leaf_kernel(const DcMat* _
                 rc[tid] = c; rs[tid] = s;
             }
             __syncthreads();
-            for (int e = tid; e < hp * pe; e += DC_LEAF_THREADS) {         // columns: S <- S J, R <- R J
-                const int t = e / pe, i = e % pe;
+#pragma unroll
+            for (int u = 0; u < NE; ++u) {                                 // columns: S <- S J, R <- R J
+                const int t = et[u], i = ei[u];
+                if (t < 0) continue;
                 int a, bq;
                 pair_of(t, a, bq);
                 const double c = rc[t], s = rs[t];
@@ -628,8 +636,10 @@ __global__ void __launch_bounds__(DC_LEAF_THREADS) dc_leaf_kernel(const DcMat* _
                 R[i][a] = c * rp - s * rq; R[i][bq] = s * rp + c * rq;
             }
             __syncthreads();
-            for (int e = tid; e < hp * pe; e += DC_LEAF_THREADS) {         // rows: S <- J^T S
-                const int t = e / pe, i = e % pe;
+#pragma unroll
+            for (int u = 0; u < NE; ++u) {                                 // rows: S <- J^T S
+                const int t = et[u], i = ei[u];
+                if (t < 0) continue;
                 int a, bq;
                 pair_of(t, a, bq);
                 const double c = rc[t], s = rs[t];
