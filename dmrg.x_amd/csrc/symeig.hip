@@ -792,12 +792,9 @@ __global__ void __launch_bounds__(1024) dc_deflate_kernel(const DcMat* __restric
     if (tid == 0) {
         int k = 0, nd = 0, nrot = 0, pj = -1;
         double zpj = 0.0, dpj = 0.0;
-        double zn = zs[0], dn = ds[0];
-        for (int jj = 0; jj < nl; ++jj) {
-            const double zj = zn, dj = dn;
-            if (jj + 1 < nl) { zn = zs[jj + 1]; dn = ds[jj + 1]; }          // (requested one element ahead of its use)
-            if (rho * fabs(zj) <= tol) { deflpos[nd++] = jj; continue; }
-            if (pj < 0) { pj = jj; zpj = zj; dpj = dj; continue; }
+        auto step = [&](int jj, double zj, double dj) {
+            if (rho * fabs(zj) <= tol) { deflpos[nd++] = jj; return; }
+            if (pj < 0) { pj = jj; zpj = zj; dpj = dj; return; }
             const double tau2 = zj * zj + zpj * zpj, t = dj - dpj;
             if (fabs(t * zj * zpj) <= tol * tau2) {
                 const double tau = sqrt(tau2), c_ = zj / tau, s_ = -zpj / tau;
@@ -809,7 +806,16 @@ __global__ void __launch_bounds__(1024) dc_deflate_kernel(const DcMat* __restric
                 pj = jj; zpj = tau; dpj = dnew;
                 ds[jj] = dnew; zs[jj] = tau;
             } else { polepos[k++] = pj; pj = jj; zpj = zj; dpj = dj; }
+        };
+        // four entries requested together (the scan only ever writes positions it has passed): one LDS round trip per four entries (eight: no further gain)
+        // instead of one per entry -- the scan is a chain of such round trips (~45 ns per entry before)
+        int jj = 0;
+        for (; jj + 4 <= nl; jj += 4) {
+            const double z0 = zs[jj], z1 = zs[jj + 1], z2 = zs[jj + 2], z3 = zs[jj + 3];
+            const double d0 = ds[jj], d1 = ds[jj + 1], d2 = ds[jj + 2], d3 = ds[jj + 3];
+            step(jj, z0, d0); step(jj + 1, z1, d1); step(jj + 2, z2, d2); step(jj + 3, z3, d3);
         }
+        for (; jj < nl; ++jj) step(jj, zs[jj], ds[jj]);
         polepos[k++] = pj;
         s_k = k; s_nd = nd; s_nrot = nrot;
     }
