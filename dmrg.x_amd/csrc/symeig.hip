@@ -926,6 +926,14 @@ __device__ __forceinline__ double sum16(double v)
     for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 16);
     return v;
 }
+// |zhat_i|^2 of pole i, formed by the 16 lanes q = 0 .. 15 of a group (every lane of the group must call it)
+__device__ __forceinline__ double loewner_weight(int i, int k, int q, const double* dl, const double* od, const double* tau)
+{
+    const double di = dl[i];
+    double w = q == 0 ? (di - od[i]) - tau[i] : 1.0;
+    for (int j = q; j < k; j += 16) if (j != i) w *= ((di - od[j]) - tau[j]) / (di - dl[j]);
+    return prod16(w);
+}
 __global__ void __launch_bounds__(1024) dc_zhat_kernel(const DcMat* __restrict__ mats, const DcMerge* __restrict__ merges, int nlmax)
 {
     extern __shared__ double sh[];
@@ -943,29 +951,47 @@ __global__ void __launch_bounds__(1024) dc_zhat_kernel(const DcMat* __restrict__
     const int ps = tid >> 4, q = tid & 15;
     for (int i0 = blockIdx.x * 64; i0 < k; i0 += DC_SPLIT * 64) {     // (uniform trip count: the shuffles below need all 16 lanes of a pole)
         const int i = min(i0 + ps, k - 1);
-        const double di = dl[i];
-        double w = q == 0 ? (di - od[i]) - tau[i] : 1.0;
-        for (int j = q; j < k; j += 16) if (j != i) w *= ((di - od[j]) - tau[j]) / (di - dl[j]);
-        w = prod16(w);
+        const double w = loewner_weight(i, k, q, dl, od, tau);
         if (q == 0 && i0 + ps < k) m.zhat[lo + i] = copysign(sqrt(fabs(w)), m.zl[lo + i]);
     }
 }
 
-// column norms of the merge's eigenvector block, and the final order of the node's eigenvalues
+// column norms of the merge's eigenvector block, and the final order of the node's eigenvalues.
+// WITH_ZHAT (small merges, nl <= DC_FUSE_NL: one launch instead of two): every workgroup of the merge forms ALL Loewner weights of the merge
+// itself first -- k^2 / 16 divisions per thread group instead of an eighth of them, which is cheaper than the ~10 us a launch costs
+// before it computes anything (profiles/r05_rdm_call_kernel_sequence_m2048.txt); same arithmetic, same results as dc_zhat_kernel + this.
+constexpr int DC_FUSE_NL = 384;
+template <bool WITH_ZHAT>
 __global__ void __launch_bounds__(1024) dc_norm_rank_kernel(const DcMat* __restrict__ mats, const DcMerge* __restrict__ merges, int nlmax)
 {
     extern __shared__ double sh[];
     double* dl = sh;
     double* zh = sh + nlmax;
     double* val = sh + 2 * (size_t)nlmax;
+    double* od = sh + 3 * (size_t)nlmax;      // (WITH_ZHAT only: d_origin(j) and tau_j)
+    double* tau = sh + 4 * (size_t)nlmax;
     const DcMerge mg = merges[blockIdx.y];
     const DcMat m = mats[mg.mat];
     const int lo = mg.lo, nl = mg.hi - mg.lo, k = m.mk[lo], tid = threadIdx.x;
     if ((int)blockIdx.x * 64 >= nl) return;
-    for (int j = tid; j < k; j += 1024) { dl[j] = m.dl[lo + j]; zh[j] = m.zhat[lo + j]; }
+    const int ps = tid >> 4, q = tid & 15;
+    for (int j = tid; j < k; j += 1024) { dl[j] = m.dl[lo + j]; if (WITH_ZHAT) tau[j] = m.tau[lo + j]; else zh[j] = m.zhat[lo + j]; }
     for (int x = tid; x < nl; x += 1024) val[x] = x < k ? m.lam[lo + x] : m.dval[lo + x - k];
     __syncthreads();
-    const int ps = tid >> 4, q = tid & 15;
+    if (WITH_ZHAT) {
+        for (int j = tid; j < k; j += 1024) od[j] = dl[m.org[lo + j]];
+        __syncthreads();
+        for (int i0 = 0; i0 < k; i0 += 64) {                           // (uniform trip count: the shuffles need all 16 lanes of a pole)
+            const int i = min(i0 + ps, k - 1);
+            const double w = loewner_weight(i, k, q, dl, od, tau);
+            if (q == 0 && i0 + ps < k) {
+                const double zv = copysign(sqrt(fabs(w)), m.zl[lo + i]);
+                zh[i] = zv;
+                if (blockIdx.x == 0) m.zhat[lo + i] = zv;              // (dc_fill_u reads it)
+            }
+        }
+        __syncthreads();
+    }
     for (int j0 = blockIdx.x * 64; j0 < k; j0 += DC_SPLIT * 64) {
         const int j = min(j0 + ps, k - 1);
         const double oj = dl[m.org[lo + j]], tj = m.tau[lo + j];
@@ -1506,11 +1532,18 @@ dmrgx_status symeig_batched(const std::vector<SymEigMat>& mats_in, hipStream_t s
         const size_t lds_wgt = (size_t)nl * 3 * sizeof(double);
         const size_t lds_rot = (size_t)nl * (2 * sizeof(double) + 3 * sizeof(int)) + 16;
         DMRGX_CHK(set_dyn_lds(dc_deflate_kernel, lds_defl)); DMRGX_CHK(set_dyn_lds(dc_secular_kernel, lds_sec));
-        DMRGX_CHK(set_dyn_lds(dc_zhat_kernel, lds_wgt)); DMRGX_CHK(set_dyn_lds(dc_norm_rank_kernel, lds_wgt)); DMRGX_CHK(set_dyn_lds(dc_rot_kernel, lds_rot));
+        const bool fuse_wgt = nl <= DC_FUSE_NL;
+        const size_t lds_fused = (size_t)nl * 5 * sizeof(double);
+        if (fuse_wgt) DMRGX_CHK(set_dyn_lds(dc_norm_rank_kernel<true>, lds_fused));
+        else { DMRGX_CHK(set_dyn_lds(dc_zhat_kernel, lds_wgt)); DMRGX_CHK(set_dyn_lds(dc_norm_rank_kernel<false>, lds_wgt)); }
+        DMRGX_CHK(set_dyn_lds(dc_rot_kernel, lds_rot));
         hipLaunchKernelGGL(dc_deflate_kernel, dim3((unsigned)s.nmerge), dim3(1024), lds_defl, st, ddm, mp, nl);
         hipLaunchKernelGGL(dc_secular_kernel, dim3((unsigned)((nl + 3) / 4), (unsigned)s.nmerge), dim3(256), lds_sec, st, ddm, mp, nl);
-        hipLaunchKernelGGL(dc_zhat_kernel, dim3(DC_SPLIT, (unsigned)s.nmerge), dim3(1024), lds_wgt, st, ddm, mp, nl);
-        hipLaunchKernelGGL(dc_norm_rank_kernel, dim3(DC_SPLIT, (unsigned)s.nmerge), dim3(1024), lds_wgt, st, ddm, mp, nl);
+        if (fuse_wgt) hipLaunchKernelGGL(dc_norm_rank_kernel<true>, dim3(DC_SPLIT, (unsigned)s.nmerge), dim3(1024), lds_fused, st, ddm, mp, nl);
+        else {
+            hipLaunchKernelGGL(dc_zhat_kernel, dim3(DC_SPLIT, (unsigned)s.nmerge), dim3(1024), lds_wgt, st, ddm, mp, nl);
+            hipLaunchKernelGGL(dc_norm_rank_kernel<false>, dim3(DC_SPLIT, (unsigned)s.nmerge), dim3(1024), lds_wgt, st, ddm, mp, nl);
+        }
         hipLaunchKernelGGL(dc_fill_u_kernel, dim3((unsigned)((nl + 63) / 64), (unsigned)((nl + 63) / 64), (unsigned)s.nmerge), dim3(256), 0, st, ddm, mp);
         hipLaunchKernelGGL(dc_rot_kernel, dim3((unsigned)((nl + 255) / 256), (unsigned)s.nmerge), dim3(256), lds_rot, st, ddm, mp, nl);
         DMRGX_HIP(hipGetLastError());
