@@ -486,22 +486,32 @@ ritz_precond_kernel(const double* __restrict__ V, const double* __restrict__ W, 
     double acc[NVMAX + 2];
 #pragma unroll
     for (int i = 0; i < NVMAX + 2; ++i) acc[i] = 0.0;
-    for (int64_t e = (int64_t)blockIdx.x * DOT_THREADS + threadIdx.x; e < n; e += (int64_t)gridDim.x * DOT_THREADS) {
-        double v[NVMAX];
-        double u = 0.0, hu = 0.0;
+    // two elements per lane and 16-byte loads: n and ldv are even, every row 16-byte aligned (the caller pads its vectors, eigs_davidson)
+    const double2* __restrict__ D2 = reinterpret_cast<const double2*>(D);
+    double2* __restrict__ t2 = reinterpret_cast<double2*>(t);
+    for (int64_t e = (int64_t)blockIdx.x * DOT_THREADS + threadIdx.x; e < n / 2; e += (int64_t)gridDim.x * DOT_THREADS) {
+        double2 v[NVMAX];
+        double2 u = {0.0, 0.0}, hu = {0.0, 0.0};
 #pragma unroll
-        for (int i = 0; i < NVMAX; ++i) if (i < nv) { v[i] = V[(int64_t)i * ldv + e]; u += ys[i] * v[i]; hu += ys[i] * W[(int64_t)i * ldv + e]; } else v[i] = 0.0;
-        const double r = hu - theta * u;
-        double den = theta - D[e];
-        if (fabs(den) < floor_) den = den < 0.0 ? -floor_ : floor_;
-        const double te = r / den;
-        t[e] = te;
+        for (int i = 0; i < NVMAX; ++i)
+            if (i < nv) {
+                v[i] = reinterpret_cast<const double2*>(V + (int64_t)i * ldv)[e];
+                const double2 w = reinterpret_cast<const double2*>(W + (int64_t)i * ldv)[e];
+                u.x += ys[i] * v[i].x; u.y += ys[i] * v[i].y; hu.x += ys[i] * w.x; hu.y += ys[i] * w.y;
+            } else v[i] = double2{0.0, 0.0};
+        const double2 r = {hu.x - theta * u.x, hu.y - theta * u.y};
+        const double2 dv = D2[e];
+        double2 den = {theta - dv.x, theta - dv.y};
+        if (fabs(den.x) < floor_) den.x = den.x < 0.0 ? -floor_ : floor_;
+        if (fabs(den.y) < floor_) den.y = den.y < 0.0 ? -floor_ : floor_;
+        const double2 te = {r.x / den.x, r.y / den.y};
+        t2[e] = te;
         if (DOTS) {
 #pragma unroll
-            for (int i = 0; i < NVMAX; ++i) if (i < nv) acc[i] += v[i] * te;
-            acc[NVMAX] += te * te;
+            for (int i = 0; i < NVMAX; ++i) if (i < nv) acc[i] += v[i].x * te.x + v[i].y * te.y;
+            acc[NVMAX] += te.x * te.x + te.y * te.y;
         }
-        acc[NVMAX + 1] += r * r;
+        acc[NVMAX + 1] += r.x * r.x + r.y * r.y;
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -524,6 +534,13 @@ ritz_precond_kernel(const double* __restrict__ V, const double* __restrict__ W, 
         for (int wv = 0; wv < DOT_THREADS / 64; ++wv) s2 += red[wv][NVMAX + 1];
         partial[blockIdx.x] = s2;
     }
+}
+
+// zero pads of the Davidson work vectors (eigs_davidson): W[j * ld + n] for j < count, t[n], D[n]
+__global__ void gd_zero_pads_kernel(double* __restrict__ W, int64_t ld, int count, int64_t n, double* __restrict__ t, double* __restrict__ D)
+{
+    for (int j = threadIdx.x; j < count; j += blockDim.x) W[(int64_t)j * ld + n] = 0.0;
+    if (threadIdx.x == 0) { t[n] = 0.0; D[n] = 0.0; }
 }
 
 // out[i] = sum_b partial[i * nblk + b] (as reduce_partials_kernel); the block of index `look_idx` also hands (|r|^2, theta, |H v_0|^2) to
@@ -954,6 +971,10 @@ static dmrgx_status eigs_davidson(dmrgx_kron_plan* plan, const dmrgx_eigs_opts* 
     const bool hooks = opts->allgather && opts->allreduce_sum;
     if (dist && !hooks && !opts->comm) DMRGX_FAIL(DMRGX_ERR_ARG, "eigs_lowest: a striped plan needs a communicator (opts->comm) or the allgather/allreduce hooks");
     const int64_t n = I.local_len, N = I.n_states;
+    // Every work vector is padded to an EVEN length ld with a zero in the pad: basis rows are then 16-byte aligned whatever n is, and the
+    // vector kernels run their two-doubles-per-lane form on odd n as well (half of all steps; multi_dot 42 -> 30 us at m = 2048).  The pad
+    // stays zero by construction: every kernel writes it as a combination of zeros, the MatMult never touches it.
+    const int64_t ld = (n + 1) & ~(int64_t)1;
     // search space: opts->ncv vectors at most (default GD_NV = 8: SLEPc's meaning of ncv for its gd solver), restarted to gd_minv Ritz
     // vectors + the previous Ritz vector.  A basis that could not grow after a restart (fewer than minv + 2 vectors) is widened.
     int m = opts->ncv > 0 ? opts->ncv : GD_NV;
@@ -977,11 +998,11 @@ static dmrgx_status eigs_davidson(dmrgx_kron_plan* plan, const dmrgx_eigs_opts* 
     };
     mark("enter");
     DevBuf dV, dW, dT, dX, dD, dTmp, dPartial, dScal, dState;
-    DMRGX_CHK(dV.alloc((size_t)(m + 1) * n * sizeof(double)));
-    DMRGX_CHK(dW.alloc((size_t)(m + 1) * n * sizeof(double)));
-    DMRGX_CHK(dT.alloc((size_t)n * sizeof(double)));
-    DMRGX_CHK(dD.alloc((size_t)n * sizeof(double)));
-    DMRGX_CHK(dTmp.alloc((size_t)kk * n * sizeof(double)));
+    DMRGX_CHK(dV.alloc((size_t)(m + 1) * ld * sizeof(double)));
+    DMRGX_CHK(dW.alloc((size_t)(m + 1) * ld * sizeof(double)));
+    DMRGX_CHK(dT.alloc((size_t)ld * sizeof(double)));
+    DMRGX_CHK(dD.alloc((size_t)ld * sizeof(double)));
+    DMRGX_CHK(dTmp.alloc((size_t)kk * ld * sizeof(double)));
     if (dist) DMRGX_CHK(dX.alloc((size_t)I.vec_len * sizeof(double)));
     DMRGX_CHK(dPartial.alloc((size_t)(MAX_NCV + DOT_CHUNK + 2) * DOT_BLOCKS * sizeof(double)));
     DMRGX_CHK(dScal.alloc((size_t)(3 * (MAX_NCV + 2)) * sizeof(double)));
@@ -996,8 +1017,8 @@ static dmrgx_status eigs_davidson(dmrgx_kron_plan* plan, const dmrgx_eigs_opts* 
     const double* const S_y = (const double*)((const char*)dState.p + offsetof(GdState, y));
     const double* const S_e0 = (const double*)((const char*)dState.p + offsetof(GdState, e0));
     const double* const S_Q = (const double*)((const char*)dState.p + offsetof(GdState, Q));
-    auto vec = [&](int j) { return V + (size_t)j * n; };
-    auto wvec = [&](int j) { return W + (size_t)j * n; };
+    auto vec = [&](int j) { return V + (size_t)j * ld; };
+    auto wvec = [&](int j) { return W + (size_t)j * ld; };
     // (every basis vector is written whole before it is read; only the padding of a striped segment relies on the initial zeros)
     if (dist) { DMRGX_HIP(zero_async(dV.p, dV.bytes, st)); DMRGX_HIP(zero_async(dW.p, dW.bytes, st)); }
     if (dist) DMRGX_HIP(zero_async(dT.p, dT.bytes, st));
@@ -1005,8 +1026,11 @@ static dmrgx_status eigs_davidson(dmrgx_kron_plan* plan, const dmrgx_eigs_opts* 
     if (dist) DMRGX_HIP(zero_async(dX.p, dX.bytes, st));
     mark("buffers");
     DMRGX_CHK(dmrgx_kron_diag(plan, dD.as<double>(), st));
+    if (ld != n) {              // the pads nobody writes: the MatMult's outputs (W), the start vector's copy (t), the diagonal
+        hipLaunchKernelGGL(gd_zero_pads_kernel, dim3(1), dim3(64), 0, st, W, ld, m + 1, n, t, dD.as<double>());
+        DMRGX_HIP(hipGetLastError());
+    }
     mark("diagonal");
-    const bool vec2 = (n % 2 == 0);
     auto allreduce = [&](double* buf, int64_t count) -> dmrgx_status {
         if (!dist) return DMRGX_OK;
         return hooks ? opts->allreduce_sum(opts->user, buf, count, st) : dmrgx_comm_allreduce_sum(opts->comm, buf, count, st);
@@ -1017,8 +1041,7 @@ static dmrgx_status eigs_davidson(dmrgx_kron_plan* plan, const dmrgx_eigs_opts* 
     // per-block partial sums of V[0..nv)^T x and x.x (dPartial); reduce == true: also out[0..nv] = the sums (all-reduced)
     auto multi_dot = [&](int nv, const double* x, double* out, bool reduce) -> dmrgx_status {
         const int chunks = (nv + 1 + DOT_CHUNK - 1) / DOT_CHUNK;
-        if (vec2) hipLaunchKernelGGL(multi_dot_kernel<true>, dim3(nblk, chunks), dim3(DOT_THREADS), 0, st, V, n, nv, x, n, dPartial.as<double>());
-        else hipLaunchKernelGGL(multi_dot_kernel<false>, dim3(nblk, chunks), dim3(DOT_THREADS), 0, st, V, n, nv, x, n, dPartial.as<double>());
+        hipLaunchKernelGGL(multi_dot_kernel<true>, dim3(nblk, chunks), dim3(DOT_THREADS), 0, st, V, ld, nv, x, ld, dPartial.as<double>());
         DMRGX_HIP(hipGetLastError());
         if (!reduce) return DMRGX_OK;
         hipLaunchKernelGGL(reduce_partials_kernel, dim3(nv + 1), dim3(DOT_THREADS), 0, st, dPartial.as<double>(), out, nv + 1, nblk);
@@ -1027,14 +1050,13 @@ static dmrgx_status eigs_davidson(dmrgx_kron_plan* plan, const dmrgx_eigs_opts* 
     };
     // second half of CGS2 on x, whose first-pass dots c1 = V^T x are reduced: dst = (x - V V^T x) / || . ||; x is overwritten
     auto orthonormalise_tail = [&](int nv, double* x, double* dst) -> dmrgx_status {
-        if (nv <= GD_NV) hipLaunchKernelGGL(axpy_dot_kernel<GD_NV>, dim3(nblk), dim3(DOT_THREADS), 0, st, V, n, nv, c1, x, n, dPartial.as<double>(), (double*)nullptr);
-        else hipLaunchKernelGGL(axpy_dot_kernel<FUSE_NV>, dim3(nblk), dim3(DOT_THREADS), 0, st, V, n, nv, c1, x, n, dPartial.as<double>(), (double*)nullptr);
+        if (nv <= GD_NV) hipLaunchKernelGGL(axpy_dot_kernel<GD_NV>, dim3(nblk), dim3(DOT_THREADS), 0, st, V, ld, nv, c1, x, ld, dPartial.as<double>(), (double*)nullptr);
+        else hipLaunchKernelGGL(axpy_dot_kernel<FUSE_NV>, dim3(nblk), dim3(DOT_THREADS), 0, st, V, ld, nv, c1, x, ld, dPartial.as<double>(), (double*)nullptr);
         DMRGX_HIP(hipGetLastError());
         hipLaunchKernelGGL(reduce_partials_kernel, dim3(nv + 1), dim3(DOT_THREADS), 0, st, dPartial.as<double>(), c2, nv + 1, nblk);
         DMRGX_HIP(hipGetLastError());
         DMRGX_CHK(allreduce(c2, nv + 1));
-        if (vec2) hipLaunchKernelGGL(axpy_normalise_kernel<true>, dim3(nblk), dim3(DOT_THREADS), 0, st, V, n, nv, c2, x, dst, n, (double*)nullptr, (double*)nullptr);
-        else hipLaunchKernelGGL(axpy_normalise_kernel<false>, dim3(nblk), dim3(DOT_THREADS), 0, st, V, n, nv, c2, x, dst, n, (double*)nullptr, (double*)nullptr);
+        hipLaunchKernelGGL(axpy_normalise_kernel<true>, dim3(nblk), dim3(DOT_THREADS), 0, st, V, ld, nv, c2, x, dst, ld, (double*)nullptr, (double*)nullptr);
         DMRGX_HIP(hipGetLastError());
         return DMRGX_OK;
     };
@@ -1094,10 +1116,10 @@ static dmrgx_status eigs_davidson(dmrgx_kron_plan* plan, const dmrgx_eigs_opts* 
         // correction vector (+ first Gram-Schmidt dots) and |r|^2
         const int look_idx = fused ? mm + 1 : 0;
         double* red_out = fused ? c1 : nrm;
-        if (fused) hipLaunchKernelGGL((ritz_precond_kernel<GD_NV, true>), dim3(nblk), dim3(DOT_THREADS), 0, st, (const double*)V, (const double*)W, n, mm, (const GdState*)S,
-                                      (const double*)dD.as<double>(), floor_rel, t, n, dPartial.as<double>());
-        else hipLaunchKernelGGL((ritz_precond_kernel<FUSE_NV, false>), dim3(nblk), dim3(DOT_THREADS), 0, st, (const double*)V, (const double*)W, n, mm, (const GdState*)S,
-                                (const double*)dD.as<double>(), floor_rel, t, n, dPartial.as<double>());
+        if (fused) hipLaunchKernelGGL((ritz_precond_kernel<GD_NV, true>), dim3(nblk), dim3(DOT_THREADS), 0, st, (const double*)V, (const double*)W, ld, mm, (const GdState*)S,
+                                      (const double*)dD.as<double>(), floor_rel, t, ld, dPartial.as<double>());
+        else hipLaunchKernelGGL((ritz_precond_kernel<FUSE_NV, false>), dim3(nblk), dim3(DOT_THREADS), 0, st, (const double*)V, (const double*)W, ld, mm, (const GdState*)S,
+                                (const double*)dD.as<double>(), floor_rel, t, ld, dPartial.as<double>());
         DMRGX_HIP(hipGetLastError());
         const int nred = fused ? mm + 2 : 1;
         hipLaunchKernelGGL(gd_reduce_look_kernel, dim3(nred), dim3(DOT_THREADS), 0, st, (const double*)dPartial.as<double>(), red_out, nred, nblk, look_idx, 0, (const GdState*)S, dLook.as<double>());
@@ -1116,10 +1138,10 @@ static dmrgx_status eigs_davidson(dmrgx_kron_plan* plan, const dmrgx_eigs_opts* 
             if (restart) {
                 // GD+k restart: V <- V Q, W <- W Q with Q = [lowest Ritz vectors | previous Ritz vector] from the device state; G <- Q^T G Q there
                 for (double* B : {V, W}) {
-                    hipLaunchKernelGGL(basis_rotate_kernel, dim3(1024, (kk + DOT_CHUNK - 1) / DOT_CHUNK), dim3(DOT_THREADS), 0, st, (const double*)B, n, m, S_Q, kk, kk,
-                                       dTmp.as<double>(), n, n);
+                    hipLaunchKernelGGL(basis_rotate_kernel, dim3(1024, (kk + DOT_CHUNK - 1) / DOT_CHUNK), dim3(DOT_THREADS), 0, st, (const double*)B, ld, m, S_Q, kk, kk,
+                                       dTmp.as<double>(), ld, ld);
                     DMRGX_HIP(hipGetLastError());
-                    DMRGX_HIP(hipMemcpyAsync(B, dTmp.p, (size_t)kk * n * sizeof(double), hipMemcpyDeviceToDevice, st));
+                    DMRGX_HIP(hipMemcpyAsync(B, dTmp.p, (size_t)kk * ld * sizeof(double), hipMemcpyDeviceToDevice, st));
                 }
                 j = kk - 1;
                 ++restarts;
@@ -1152,7 +1174,7 @@ static dmrgx_status eigs_davidson(dmrgx_kron_plan* plan, const dmrgx_eigs_opts* 
         if (n_matvec >= hand_over) {
             // a start vector that was not close after all (the preconditioned iteration then trails Lanczos, see above): hand the
             // current Ritz vector to the Lanczos path instead of iterating on
-            hipLaunchKernelGGL(basis_rotate_kernel, dim3(1024, 1), dim3(DOT_THREADS), 0, st, (const double*)V, n, mm, S_y, 1, 1,
+            hipLaunchKernelGGL(basis_rotate_kernel, dim3(1024, 1), dim3(DOT_THREADS), 0, st, (const double*)V, ld, mm, S_y, 1, 1,
                                dist ? psi_full + I.local_offset : psi_full, n, n);
             DMRGX_HIP(hipGetLastError());
             DMRGX_HIP(hipStreamSynchronize(st));
@@ -1173,7 +1195,7 @@ static dmrgx_status eigs_davidson(dmrgx_kron_plan* plan, const dmrgx_eigs_opts* 
         // the Ritz vector: V y in the basis the Ritz problem was solved in -- or, when a restart has been queued since, simply the
         // first vector of the new basis
         const int nb = rotated ? 1 : mm;
-        hipLaunchKernelGGL(basis_rotate_kernel, dim3(1024, 1), dim3(DOT_THREADS), 0, st, (const double*)V, n, nb, rotated ? S_e0 : S_y, 1, 1, t, n, n);
+        hipLaunchKernelGGL(basis_rotate_kernel, dim3(1024, 1), dim3(DOT_THREADS), 0, st, (const double*)V, ld, nb, rotated ? S_e0 : S_y, 1, 1, t, ld, ld);
         DMRGX_HIP(hipGetLastError());
         DMRGX_CHK(multi_dot(0, t, c1, true));
         DMRGX_HIP(hipMemcpyAsync(nrm, c1, sizeof(double), hipMemcpyDeviceToDevice, st));
